@@ -1,0 +1,72 @@
+/*
+ * fftw_baseline.c -- CPU speed baseline for bench.py's "cpu_baseline" leg (test/measurement
+ * infrastructure only, never part of the product path).
+ *
+ * north_star asks for "FFTW batched on the host cores of the GPU box in the same run".  Real FFTW
+ * is not installed in this image; Intel MKL's FFTW3 interface (libmkl_rt.so) is, so the library is
+ * resolved at run time:  libfftw3f.so.3  ->  libmkl_rt.so (FFTW3 wrappers)  ->  none (the caller
+ * then times oracle_ct_c2c_f32 from smfft_oracle.c instead).  The plan is the FFTW-API batched
+ * out-of-place C2C plan: fftwf_plan_many_dft(1,&N,howmany, in,NULL,1,N, out,NULL,1,N, sign, ESTIMATE).
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <stdio.h>
+#include <string.h>
+#include <time.h>
+
+typedef void* (*plan_many_t)(int, const int*, int, void*, const int*, int, int, void*, const int*, int, int, int, unsigned);
+typedef void (*execute_t)(void*);
+typedef void (*destroy_t)(void*);
+typedef int (*init_threads_t)(void);
+typedef void (*plan_threads_t)(int);
+
+static void* lib;
+static plan_many_t p_plan;
+static execute_t p_exec;
+static destroy_t p_destroy;
+static char backend[64] = "none";
+
+/* returns 1 if an FFTW3-API provider was found */
+int fftw_baseline_init(int threads) {
+    const char* cands[] = {"libfftw3f_omp.so.3", "libfftw3f_threads.so.3", "libfftw3f.so.3", "libmkl_rt.so",
+                           "/opt/conda/lib/libmkl_rt.so", "libmkl_rt.so.1", "/opt/conda/lib/libmkl_rt.so.1"};
+    for (unsigned i = 0; i < sizeof(cands) / sizeof(cands[0]) && !lib; ++i) {
+        void* h = dlopen(cands[i], RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        p_plan = (plan_many_t)dlsym(h, "fftwf_plan_many_dft");
+        p_exec = (execute_t)dlsym(h, "fftwf_execute");
+        p_destroy = (destroy_t)dlsym(h, "fftwf_destroy_plan");
+        if (p_plan && p_exec && p_destroy) {
+            lib = h;
+            snprintf(backend, sizeof backend, "%s", strstr(cands[i], "mkl") ? "mkl-fftw3-api" : "fftw3f");
+            init_threads_t it = (init_threads_t)dlsym(h, "fftwf_init_threads");
+            plan_threads_t pt = (plan_threads_t)dlsym(h, "fftwf_plan_with_nthreads");
+            if (it && pt && threads > 0) { it(); pt(threads); }
+            void (*mkl_set)(int) = (void (*)(int))dlsym(h, "MKL_Set_Num_Threads");
+            if (mkl_set && threads > 0) mkl_set(threads);
+        } else {
+            dlclose(h);
+        }
+    }
+    return lib != 0;
+}
+
+const char* fftw_baseline_backend(void) { return backend; }
+
+/* Executes the batched plan `reps` times; returns the best wall time in seconds, or -1. */
+double fftw_baseline_c2c(const float* in, float* out, int N, int nFFTs, int inverse, int reps) {
+    if (!lib) return -1.0;
+    void* plan = p_plan(1, &N, nFFTs, (void*)in, 0, 1, N, (void*)out, 0, 1, N, inverse ? +1 : -1, 1u << 6 /*FFTW_ESTIMATE*/);
+    if (!plan) return -1.0;
+    double best = 1e30;
+    for (int r = 0; r < reps; ++r) {
+        struct timespec a, b;
+        clock_gettime(CLOCK_MONOTONIC, &a);
+        p_exec(plan);
+        clock_gettime(CLOCK_MONOTONIC, &b);
+        double t = (b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec);
+        if (t < best) best = t;
+    }
+    p_destroy(plan);
+    return best;
+}
