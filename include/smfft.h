@@ -1,0 +1,96 @@
+/*
+ * smfft.h -- C ABI of libsmfft_amd.so, the MI355X (gfx950) shared-memory FFT library.
+ *
+ * This is the drop-in boundary for the hot path of KAdamek/SMFFT: plain pointers and sizes, no
+ * C++ or torch types.  Every entry point names the reference interface it replaces (paths are
+ * relative to the reference checkout; CT = SMFFT_CooleyTukey_C2C/FFT-GPU-32bit.cu,
+ * ST = SMFFT_Stockham_C2C/FFT-GPU-32bit-Stockham.cu, RC = SMFFT_Stockham_R2C_C2R/FFT-GPU-32bit-Stockham.cu).
+ * The same library also exports the reference's own C++-linkage symbols (FFT_init,
+ * FFT_external_benchmark, FFT_multiple_benchmark, GPU_smFFT_4elements, ...; see
+ * include/smfft_reference_api.h) so the reference's FFT.c harnesses link against it unchanged.
+ *
+ * Conventions shared with the reference:
+ *   - complex data is interleaved float (re, im) = float2; FFT f of a batch is at element f*N;
+ *   - d_* pointers are DEVICE pointers owned by the caller; transforms are out of place and leave
+ *     the input untouched; all transforms are un-normalised;
+ *   - the *_benchmark calls time exactly one kernel launch with events and ADD the milliseconds to
+ *     *FFT_time (CT:598,660-662); they are synchronous;
+ *   - return value 0 = ok.  Unsupported lengths print "Error wrong FFT length!" and return 0 with
+ *     nothing launched, as upstream (CT:656-658).
+ */
+#ifndef SMFFT_H_
+#define SMFFT_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMFFT_NREUSES 100 /* FFTs per load/store in the `multiple` path (CT:10) */
+
+/* FFT_init (CT:576-581).  The CUDA cache/bank configuration calls have no gfx950 meaning; this
+ * selects the device (SMFFT_DEVICE or the one already current) and reads the tuning environment
+ * (SMFFT_GRID_CAP: maximum workgroups per launch, 0 = one per 4096-element tile). */
+void smfft_init(void);
+
+/* ---- Cooley-Tukey C2C family, N = 32 .. 4096 ------------------------------------------------ */
+/* FFT_external_benchmark (CT:583-664): d_output[f] = FFT(d_input[f]), f < nFFTs.
+ * reorder != 0: natural-order DFT; reorder == 0: DFT of the bit-reversed-index input (the DIT
+ * butterfly network applied to natural-order data), exactly as fft_reorder = 0 upstream. */
+int smfft_ct_external_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs,
+                                int inverse, int reorder, double* FFT_time);
+/* FFT_multiple_benchmark (CT:666-752): the first nFFTs/100 FFTs are each transformed 100 times in
+ * LDS.  Returns 1 and sets *FFT_time = -1 when nFFTs/100 == 0 (CT:669-673). */
+int smfft_ct_multiple_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs,
+                                int inverse, int reorder, double* FFT_time);
+
+/* ---- Stockham C2C family (un-normalised INVERSE transform, ST:76), N = 256 .. 4096 ----------- */
+/* FFT_external_benchmark / FFT_multiple_benchmark (ST:306-346, :348-384). */
+int smfft_st_external_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, double* FFT_time);
+int smfft_st_multiple_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, double* FFT_time);
+
+/* ---- R2C / C2R family, real FFT_size = 512 .. 4096 -------------------------------------------- */
+/* FFT_external_benchmark (RC:396-432).  inverse == 0: d_input = nFFTs*FFT_size reals,
+ * d_output = nFFTs*FFT_size/2 float2 with element 0 = (X[0].re, X[N/2].re).  inverse != 0: the
+ * packed layout in, (FFT_size/2) * x out as reals. */
+int smfft_rc_external_benchmark(const float* d_input, float* d_output, int FFT_size, int nFFTs,
+                                int inverse, double* FFT_time);
+/* FFT_multiple_benchmark (RC:435-467), forward only as upstream. */
+int smfft_rc_multiple_benchmark(const float* d_input, float* d_output, int FFT_size, int nFFTs, double* FFT_time);
+
+/* ---- launch-only forms (no events, no synchronisation) on a caller-provided hipStream_t --------
+ * family: 0 = CT, 1 = ST, 2 = RC.  path: 0 = external, 1 = multiple.  For family 2, FFT_size is
+ * the REAL length.  Used by bench.py / graph capture; same kernels as the *_benchmark calls.
+ * Returns 0, a hipError_t, or -1 for an unsupported (family, FFT_size). */
+int smfft_launch(int family, int path, const void* d_input, void* d_output, int FFT_size, int nFFTs,
+                 int inverse, int reorder, void* hip_stream);
+
+/* ---- L3 wrappers: host buffers in, host buffers out (alloc, H2D, nRuns launches, D2H, free) ---- */
+/* GPU_smFFT_4elements (CT:827-908). */
+int smfft_gpu_ct(const void* h_input, void* h_output, int FFT_size, int nFFTs, int inverse, int reorder,
+                 int nRuns, double* single_ex_time, double* multi_ex_time);
+/* GPU_FFT_C2C_Stockham (ST:457-530). */
+int smfft_gpu_st(const void* h_input, void* h_output, int FFT_size, int nFFTs, int nRuns,
+                 double* single_ex_time, double* multi_ex_time);
+/* GPU_smFFT_R2C (RC:572-650) / GPU_smFFT_C2R (RC:652-688). */
+int smfft_gpu_r2c(void* h_output, const float* h_input, int FFT_size, int nFFTs, int nRuns);
+int smfft_gpu_c2r(float* h_output, const void* h_input, int FFT_size, int nFFTs, int nRuns);
+
+/* ---- tuning / introspection ------------------------------------------------------------------- */
+void smfft_set_grid_cap(int max_workgroups); /* 0 = one workgroup per tile (default) */
+int smfft_get_grid_cap(void);
+int smfft_device_count(void);
+int smfft_set_device(int device);
+const char* smfft_version(void);
+
+/* ---- plain device-memory helpers so a C / ctypes caller needs no other HIP binding ----------- */
+void* smfft_malloc(unsigned long long bytes);
+int smfft_free(void* d_ptr);
+int smfft_memcpy_h2d(void* d_dst, const void* h_src, unsigned long long bytes);
+int smfft_memcpy_d2h(void* h_dst, const void* d_src, unsigned long long bytes);
+int smfft_memset(void* d_ptr, int value, unsigned long long bytes);
+int smfft_synchronize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMFFT_H_ */

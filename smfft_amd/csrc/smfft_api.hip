@@ -1,0 +1,360 @@
+// smfft_api.hip -- host side of libsmfft_amd.so: the C ABI of include/smfft.h and the reference's
+// own C++-linkage entry points (include/smfft_reference_api.h).
+//
+// Mirrors, in behaviour (return codes, printed lines, timing convention), the host code of the
+// three reference programs: CT:576-752 + :827-908, ST:299-384 + :457-530, RC:388-467 + :572-688.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/smfft.h"
+#include "../../include/smfft_reference_api.h"
+#include "debug.h"
+#include "smfft_launch.hpp"
+#include "timer.h"
+#include "utils_hip.h"
+
+namespace {
+
+int g_device = 0;       // the reference's global `int device = 0` (CT:15)
+int g_grid_cap = 0;     // 0: one workgroup per 4096-element tile
+bool g_env_read = false;
+
+void read_env() {
+    if (g_env_read) return;
+    g_env_read = true;
+    if (const char* e = getenv("SMFFT_GRID_CAP")) g_grid_cap = atoi(e);
+    if (const char* e = getenv("SMFFT_DEVICE")) g_device = atoi(e);
+}
+
+// count of FFT slots the `multiple` path touches (CT:669-683; ST:351; RC:438)
+int ct_multiple_slots(int FFT_size, int nFFTs) {
+    if (FFT_size == 32) return (nFFTs / (4 * SMFFT_NREUSES)) * 4;
+    if (FFT_size == 64) return (nFFTs / (2 * SMFFT_NREUSES)) * 2;
+    return nFFTs / SMFFT_NREUSES;
+}
+
+using smfft::launch_ct;
+using smfft::launch_rc;
+using smfft::launch_st;
+
+// returns -1 for an unsupported length (nothing launched), else the launch status
+int dispatch_ct(const float2* in, float2* out, int N, int count, int inverse, int reorder, int path, hipStream_t st) {
+    switch (N) {
+        case 32:   return launch_ct<32>(in, out, count, inverse, reorder, path, g_grid_cap, st);
+        case 64:   return launch_ct<64>(in, out, count, inverse, reorder, path, g_grid_cap, st);
+        case 128:  return launch_ct<128>(in, out, count, inverse, reorder, path, g_grid_cap, st);
+        case 256:  return launch_ct<256>(in, out, count, inverse, reorder, path, g_grid_cap, st);
+        case 512:  return launch_ct<512>(in, out, count, inverse, reorder, path, g_grid_cap, st);
+        case 1024: return launch_ct<1024>(in, out, count, inverse, reorder, path, g_grid_cap, st);
+        case 2048: return launch_ct<2048>(in, out, count, inverse, reorder, path, g_grid_cap, st);
+        case 4096: return launch_ct<4096>(in, out, count, inverse, reorder, path, g_grid_cap, st);
+        default:   return -1;
+    }
+}
+int dispatch_st(const float2* in, float2* out, int N, int count, int path, hipStream_t st) {
+    switch (N) {
+        case 256:  return launch_st<256>(in, out, count, path, g_grid_cap, st);
+        case 512:  return launch_st<512>(in, out, count, path, g_grid_cap, st);
+        case 1024: return launch_st<1024>(in, out, count, path, g_grid_cap, st);
+        case 2048: return launch_st<2048>(in, out, count, path, g_grid_cap, st);
+        case 4096: return launch_st<4096>(in, out, count, path, g_grid_cap, st);
+        default:   return -1;
+    }
+}
+// FFT_size is the REAL length; the kernels are instantiated on the complex length L = FFT_size/2 (RC:404-428)
+int dispatch_rc(const float2* in, float2* out, int FFT_size, int count, int inverse, int path, hipStream_t st) {
+    switch (FFT_size) {
+        case 512:  return launch_rc<256>(in, out, count, inverse, path, g_grid_cap, st);
+        case 1024: return launch_rc<512>(in, out, count, inverse, path, g_grid_cap, st);
+        case 2048: return launch_rc<1024>(in, out, count, inverse, path, g_grid_cap, st);
+        case 4096: return launch_rc<2048>(in, out, count, inverse, path, g_grid_cap, st);
+        default:   return -1;
+    }
+}
+
+// One event-timed launch on stream 0, elapsed ms ADDED to *FFT_time (CT:598,660-662).
+template <class F>
+int timed(F&& launch, double* FFT_time) {
+    read_env();
+    GpuTimer timer;
+    timer.Start();
+    int rc = launch();
+    timer.Stop();
+    if (rc == -1) printf("Error wrong FFT length!\n");
+    else if (rc != 0) checkHipErrors((hipError_t)rc);
+    if (FFT_time) *FFT_time += timer.Elapsed();
+    return 0;
+}
+
+int select_device() {
+    read_env();
+    int devCount = 0;
+    checkHipErrors(hipGetDeviceCount(&devCount));
+    if (devCount > g_device) checkHipErrors(hipSetDevice(g_device));
+    return devCount;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+void smfft_init(void) {
+    read_env();
+    // cudaDeviceSetCacheConfig / cudaDeviceSetSharedMemConfig (CT:579-580) have no CDNA meaning.
+}
+
+int smfft_ct_external_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, int inverse, int reorder, double* FFT_time) {
+    return timed([&] { return dispatch_ct((const float2*)d_input, (float2*)d_output, FFT_size, nFFTs, inverse != 0, reorder != 0, 0, 0); }, FFT_time);
+}
+
+int smfft_ct_multiple_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, int inverse, int reorder, double* FFT_time) {
+    if (nFFTs / SMFFT_NREUSES == 0) {
+        if (FFT_time) *FFT_time = -1;
+        return 1;
+    }
+    const int slots = ct_multiple_slots(FFT_size, nFFTs);
+    return timed([&] { return dispatch_ct((const float2*)d_input, (float2*)d_output, FFT_size, slots, inverse != 0, reorder != 0, 1, 0); }, FFT_time);
+}
+
+int smfft_st_external_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, double* FFT_time) {
+    return timed([&] { return dispatch_st((const float2*)d_input, (float2*)d_output, FFT_size, nFFTs, 0, 0); }, FFT_time);
+}
+int smfft_st_multiple_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, double* FFT_time) {
+    return timed([&] { return dispatch_st((const float2*)d_input, (float2*)d_output, FFT_size, nFFTs / SMFFT_NREUSES, 1, 0); }, FFT_time);
+}
+
+int smfft_rc_external_benchmark(const float* d_input, float* d_output, int FFT_size, int nFFTs, int inverse, double* FFT_time) {
+    return timed([&] { return dispatch_rc((const float2*)d_input, (float2*)d_output, FFT_size, nFFTs, inverse != 0, 0, 0); }, FFT_time);
+}
+int smfft_rc_multiple_benchmark(const float* d_input, float* d_output, int FFT_size, int nFFTs, double* FFT_time) {
+    return timed([&] { return dispatch_rc((const float2*)d_input, (float2*)d_output, FFT_size, nFFTs / SMFFT_NREUSES, 0, 1, 0); }, FFT_time);
+}
+
+int smfft_launch(int family, int path, const void* d_input, void* d_output, int FFT_size, int nFFTs, int inverse, int reorder, void* hip_stream) {
+    read_env();
+    hipStream_t st = (hipStream_t)hip_stream;
+    const float2* in = (const float2*)d_input;
+    float2* out = (float2*)d_output;
+    if (family == 0) {
+        int count = path ? ct_multiple_slots(FFT_size, nFFTs) : nFFTs;
+        return dispatch_ct(in, out, FFT_size, count, inverse != 0, reorder != 0, path, st);
+    }
+    if (family == 1) return dispatch_st(in, out, FFT_size, path ? nFFTs / SMFFT_NREUSES : nFFTs, path, st);
+    if (family == 2) return dispatch_rc(in, out, FFT_size, path ? nFFTs / SMFFT_NREUSES : nFFTs, inverse != 0, path, st);
+    return -1;
+}
+
+// ---- L3 wrappers ---------------------------------------------------------------------------------
+int smfft_gpu_ct(const void* h_input, void* h_output, int FFT_size, int nFFTs, int inverse, int reorder, int nRuns, double* single_ex_time, double* multi_ex_time) {
+    select_device();
+    // edge cases the reference rejects (CT:835-836)
+    if (FFT_size == 32 && (nFFTs % 4) != 0) return 1;
+    if (FFT_size == 64 && (nFFTs % 2) != 0) return 1;
+
+    size_t free_mem, total_mem;
+    checkHipErrors(hipMemGetInfo(&free_mem, &total_mem));
+    if (DEBUG) printf("\n  Device has %0.3f MB of total memory, which %0.3f MB is available.\n", (float)total_mem / (1024.0 * 1024.0), (float)free_mem / (1024.0 * 1024.0));
+    const size_t bytes = (size_t)FFT_size * nFFTs * sizeof(float2);
+    if (2 * bytes > free_mem) {
+        printf("Error: Not enough memory! Input data is too big for the device.\n");
+        return 1;
+    }
+    float2 *d_input, *d_output;
+    checkHipErrors(hipMalloc((void**)&d_input, bytes));
+    checkHipErrors(hipMalloc((void**)&d_output, bytes));
+
+    double time_FFT_external = 0, time_FFT_multiple = 0;
+    if (MULTIPLE) {
+        if (DEBUG) printf("  Running shared memory FFT (Cooley-Tukey) 100 times per GPU kernel (eliminates device memory)... ");
+        smfft_init();
+        double total = 0;
+        for (int f = 0; f < nRuns; f++) {
+            checkHipErrors(hipMemcpy(d_input, h_input, bytes, hipMemcpyHostToDevice));
+            smfft_ct_multiple_benchmark(d_input, d_output, FFT_size, nFFTs, inverse, reorder, &total);
+        }
+        time_FFT_multiple = total / nRuns;
+        if (DEBUG) printf("done in %g ms.\n", time_FFT_multiple);
+        if (multi_ex_time) *multi_ex_time = time_FFT_multiple;
+    }
+    checkHipErrors(hipGetLastError());
+    if (EXTERNAL) {
+        if (DEBUG) printf("  Running shared memory FFT (Cooley-Tukey)... ");
+        smfft_init();
+        double total = 0;
+        for (int f = 0; f < nRuns; f++) {
+            checkHipErrors(hipMemcpy(d_input, h_input, bytes, hipMemcpyHostToDevice));
+            smfft_ct_external_benchmark(d_input, d_output, FFT_size, nFFTs, inverse, reorder, &total);
+        }
+        time_FFT_external = total / nRuns;
+        if (DEBUG) printf("done in %g ms.\n", time_FFT_external);
+        if (single_ex_time) *single_ex_time = time_FFT_external;
+    }
+    checkHipErrors(hipGetLastError());
+    printf("  SH FFT normal = %0.3f ms; SM FFT multiple times = %0.3f ms\n", time_FFT_external, time_FFT_multiple);
+    // MULTIPLE runs first, so d_output holds the EXTERNAL result (CT:862-890,898)
+    checkHipErrors(hipMemcpy(h_output, d_output, bytes, hipMemcpyDeviceToHost));
+    checkHipErrors(hipGetLastError());
+    checkHipErrors(hipFree(d_input));
+    checkHipErrors(hipFree(d_output));
+    return 0;
+}
+
+int smfft_gpu_st(const void* h_input, void* h_output, int FFT_size, int nFFTs, int nRuns, double* single_ex_time, double* multi_ex_time) {
+    select_device();
+    size_t free_mem, total_mem;
+    checkHipErrors(hipMemGetInfo(&free_mem, &total_mem));
+    const size_t bytes = (size_t)FFT_size * nFFTs * sizeof(float2);
+    if (2 * bytes > free_mem) {
+        printf("Error: Not enough memory! Input data is too big for the device.\n");
+        return 1;
+    }
+    float2 *d_input, *d_output;
+    checkHipErrors(hipMalloc((void**)&d_input, bytes));
+    checkHipErrors(hipMalloc((void**)&d_output, bytes));
+    double time_FFT_external = 0, time_FFT_multiple = 0;
+    if (MULTIPLE) {
+        smfft_init();
+        double total = 0;
+        for (int f = 0; f < nRuns; f++) {
+            checkHipErrors(hipMemcpy(d_input, h_input, bytes, hipMemcpyHostToDevice));
+            smfft_st_multiple_benchmark(d_input, d_output, FFT_size, nFFTs, &total);
+        }
+        time_FFT_multiple = total / nRuns;
+        if (multi_ex_time) *multi_ex_time = time_FFT_multiple;
+    }
+    if (EXTERNAL) {
+        smfft_init();
+        double total = 0;
+        for (int f = 0; f < nRuns; f++) {
+            checkHipErrors(hipMemcpy(d_input, h_input, bytes, hipMemcpyHostToDevice));
+            smfft_st_external_benchmark(d_input, d_output, FFT_size, nFFTs, &total);
+        }
+        time_FFT_external = total / nRuns;
+        if (single_ex_time) *single_ex_time = time_FFT_external;
+    }
+    checkHipErrors(hipMemcpy(h_output, d_output, bytes, hipMemcpyDeviceToHost));
+    checkHipErrors(hipGetLastError());
+    checkHipErrors(hipFree(d_input));
+    checkHipErrors(hipFree(d_output));
+    printf("  SH FFT normal = %0.3f ms; SM FFT multiple times = %0.3f ms\n", time_FFT_external, time_FFT_multiple);
+    return 0;
+}
+
+int smfft_gpu_r2c(void* h_output, const float* h_input, int FFT_size, int nFFTs, int nRuns) {
+    select_device();
+    size_t free_memory, total_memory;
+    checkHipErrors(hipMemGetInfo(&free_memory, &total_memory));
+    double FFT_external_time = 0, FFT_multiple_time = 0;
+    const size_t input_size_bytes = (size_t)FFT_size * nFFTs * sizeof(float);
+    const size_t output_size_bytes = (size_t)(FFT_size >> 1) * nFFTs * sizeof(float2);
+    if ((input_size_bytes + output_size_bytes) > free_memory) {
+        printf("Error not enough free memory!\n");
+        return 1;
+    }
+    float* d_input;
+    float2* d_output;
+    checkHipErrors(hipMalloc((void**)&d_input, input_size_bytes));
+    checkHipErrors(hipMalloc((void**)&d_output, output_size_bytes));
+    checkHipErrors(hipMemcpy(d_input, h_input, input_size_bytes, hipMemcpyHostToDevice));
+    if (MULTIPLE) {
+        for (int r = 0; r < nRuns; r++) {
+            smfft_init();
+            smfft_rc_multiple_benchmark(d_input, (float*)d_output, FFT_size, nFFTs, &FFT_multiple_time);
+        }
+    }
+    checkHipErrors(hipMemset(d_output, 0, output_size_bytes));
+    if (EXTERNAL) {
+        for (int r = 0; r < nRuns; r++) {
+            smfft_init();
+            smfft_rc_external_benchmark(d_input, (float*)d_output, FFT_size, nFFTs, 0, &FFT_external_time);
+        }
+    }
+    printf("  smFFT R2C time: ex: %0.3f ms; mul: %0.3f ms\n", FFT_external_time / nRuns, FFT_multiple_time / nRuns);
+    checkHipErrors(hipMemcpy(h_output, d_output, output_size_bytes, hipMemcpyDeviceToHost));
+    checkHipErrors(hipFree(d_input));
+    checkHipErrors(hipFree(d_output));
+    return 0;
+}
+
+int smfft_gpu_c2r(float* h_output, const void* h_input, int FFT_size, int nFFTs, int nRuns) {
+    select_device();
+    size_t free_memory, total_memory;
+    checkHipErrors(hipMemGetInfo(&free_memory, &total_memory));
+    double FFT_external_time = 0;
+    const size_t input_size_bytes = (size_t)(FFT_size >> 1) * nFFTs * sizeof(float2);
+    const size_t output_size_bytes = (size_t)FFT_size * nFFTs * sizeof(float);
+    if ((input_size_bytes + output_size_bytes) > free_memory) {
+        printf("Error not enough free memory!\n");
+        return 1;
+    }
+    float2* d_input;
+    float* d_output;
+    checkHipErrors(hipMalloc((void**)&d_input, input_size_bytes));
+    checkHipErrors(hipMalloc((void**)&d_output, output_size_bytes));
+    checkHipErrors(hipMemcpy(d_input, h_input, input_size_bytes, hipMemcpyHostToDevice));
+    if (EXTERNAL) {
+        for (int r = 0; r < nRuns; r++) {
+            smfft_init();
+            smfft_rc_external_benchmark((const float*)d_input, d_output, FFT_size, nFFTs, 1, &FFT_external_time);
+        }
+    }
+    printf("  smFFT C2R time: ex: %0.3f ms;\n", FFT_external_time / nRuns);
+    checkHipErrors(hipMemcpy(h_output, d_output, output_size_bytes, hipMemcpyDeviceToHost));
+    checkHipErrors(hipFree(d_input));
+    checkHipErrors(hipFree(d_output));
+    return 0;
+}
+
+// ---- tuning / introspection ------------------------------------------------------------------------
+void smfft_set_grid_cap(int max_workgroups) { read_env(); g_grid_cap = max_workgroups; }
+int smfft_get_grid_cap(void) { read_env(); return g_grid_cap; }
+int smfft_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+int smfft_set_device(int device) { read_env(); g_device = device; return (int)hipSetDevice(device); }
+const char* smfft_version(void) { return "smfft_amd 0.1 (gfx950)"; }
+
+void* smfft_malloc(unsigned long long bytes) { void* p = nullptr; return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr; }
+int smfft_free(void* d_ptr) { return (int)hipFree(d_ptr); }
+int smfft_memcpy_h2d(void* d_dst, const void* h_src, unsigned long long bytes) { return (int)hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice); }
+int smfft_memcpy_d2h(void* h_dst, const void* d_src, unsigned long long bytes) { return (int)hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost); }
+int smfft_memset(void* d_ptr, int value, unsigned long long bytes) { return (int)hipMemset(d_ptr, value, bytes); }
+int smfft_synchronize(void) { return (int)hipDeviceSynchronize(); }
+
+}  // extern "C"
+
+// =================================================================================================
+// The reference's C++-linkage names (what its FFT.c harnesses bind; include/smfft_reference_api.h)
+// =================================================================================================
+void FFT_init() { smfft_init(); }
+
+int FFT_external_benchmark(float2* d_input, float2* d_output, int FFT_size, int nFFTs, bool inverse, bool reorder, double* FFT_time) {
+    return smfft_ct_external_benchmark(d_input, d_output, FFT_size, nFFTs, inverse, reorder, FFT_time);
+}
+int FFT_multiple_benchmark(float2* d_input, float2* d_output, int FFT_size, int nFFTs, bool inverse, bool reorder, double* FFT_time) {
+    return smfft_ct_multiple_benchmark(d_input, d_output, FFT_size, nFFTs, inverse, reorder, FFT_time);
+}
+void FFT_external_benchmark(float2* d_input, float2* d_output, int FFT_size, int nFFTs, double* FFT_time) {
+    smfft_st_external_benchmark(d_input, d_output, FFT_size, nFFTs, FFT_time);
+}
+void FFT_multiple_benchmark(float2* d_input, float2* d_output, int FFT_size, int nFFTs, double* FFT_time) {
+    smfft_st_multiple_benchmark(d_input, d_output, FFT_size, nFFTs, FFT_time);
+}
+void FFT_external_benchmark(float* d_input, float* d_output, int FFT_size, int nFFTs, int inverse, double* FFT_time) {
+    smfft_rc_external_benchmark(d_input, d_output, FFT_size, nFFTs, inverse, FFT_time);
+}
+void FFT_multiple_benchmark(float* d_input, float* d_output, int FFT_size, int nFFTs, double* FFT_time) {
+    smfft_rc_multiple_benchmark(d_input, d_output, FFT_size, nFFTs, FFT_time);
+}
+
+int GPU_smFFT_4elements(float2* h_input, float2* h_output, int FFT_size, int nFFTs, bool inverse, bool reorder, int nRuns, double* single_ex_time, double* multi_ex_time) {
+    return smfft_gpu_ct(h_input, h_output, FFT_size, nFFTs, inverse, reorder, nRuns, single_ex_time, multi_ex_time);
+}
+int GPU_FFT_C2C_Stockham(float2* h_input, float2* h_smFFT_output, int FFT_size, int nFFTs, int nRuns, double* single_ex_time, double* multi_ex_time) {
+    return smfft_gpu_st(h_input, h_smFFT_output, FFT_size, nFFTs, nRuns, single_ex_time, multi_ex_time);
+}
+int GPU_smFFT_R2C(float2* h_output, float* h_input, int FFT_size, int nFFTs, int nRuns) { return smfft_gpu_r2c(h_output, h_input, FFT_size, nFFTs, nRuns); }
+int GPU_smFFT_C2R(float* h_output, float2* h_input, int FFT_size, int nFFTs, int nRuns) { return smfft_gpu_c2r(h_output, h_input, FFT_size, nFFTs, nRuns); }

@@ -1,0 +1,311 @@
+// smfft_engine.hpp -- the gfx950 shared-memory (LDS) FFT engine and the device-function surface.
+//
+// What it replaces (reference = KAdamek/SMFFT, CUDA):
+//   do_SMFFT_CT_DIT<P>           SMFFT_CooleyTukey_C2C/FFT-GPU-32bit.cu:334-532  (+ reorder_* :54-329)
+//   do_FFT_Stockham_mk6<P>       SMFFT_Stockham_C2C/FFT-GPU-32bit-Stockham.cu:97-240
+//   do_FFT_Stockham_C2C<P,D>     SMFFT_Stockham_R2C_C2R/FFT-GPU-32bit-Stockham.cu:106-266
+//   do_FFT_Stockham_R2C_C2R<P,D> SMFFT_Stockham_R2C_C2R/FFT-GPU-32bit-Stockham.cu:269-344
+// Same names, same results (semantics S1..S6 of SURVEY.md 8(a)); the algorithm is NOT the
+// reference's 4-elements-per-thread radix-2 ladder.  It is designed for the 64-lane wave:
+//
+//   * 16 elements per thread, N/16 threads per FFT: an FFT of N <= 1024 lives inside ONE wave,
+//     so its LDS exchanges need no s_barrier at all (a wave's DS instructions execute in order);
+//     N = 2048 / 4096 use 2 / 4 waves and workgroup barriers.
+//   * N = R1 * RM * 16.  Pass 1 (radix R1) and the last pass (radix 16) run entirely in
+//     registers, N >= 512 adds a middle radix-RM pass: 2 LDS exchanges for N >= 512, 1 below,
+//     against the reference's log2(N)-5 shared-memory stages + a 3-sync reorder.
+//   * The exchanges are a Stockham autosort: the digit reversal is folded into the LDS
+//     addressing, so "reorder" costs nothing.  Layouts are padded so that every ds_write_b64 is
+//     bank-conflict free (16-lane groups, float2 index mod 16) and every ds_read_b64 too
+//     (32-lane groups, mod 32); each FFT owns a region of 17N/16 float2 (the "33-stride" idea of
+//     the reference, re-derived for 64 banks / 64 lanes; tools/plan_model.py checks it).
+//   * Twiddles W_N^m come from a 4096-entry table rounded once from fp64 (<= 0.5 ulp); a thread
+//     needs only 15 + (RM-1) of them, loaded once and kept in VGPRs across a persistent loop.
+//
+// Data layout contract of the device functions: `s` points at the workgroup's LDS array of
+// P::fft_sm_required float2; FFT j of the workgroup (j < P::fft_per_block) occupies
+// s[j*P::fft_region + n], n in [0, N), natural order, before and after the call; the rest of each
+// region is scratch.  All 256 threads of the workgroup call the function (blockDim.x == 256).
+// Callers barrier (__syncthreads) between filling s and the call, and between the call and reading s.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "SM_FFT_parameters.hpp"
+
+namespace smfft {
+
+static __device__ const float2 twiddle_4096[4096] = {
+#include "smfft_twiddles.inc"
+};
+
+// ------------------------------------------------------------------------------------------------
+template <int N>
+struct Geometry {
+    static_assert(N >= 32 && N <= 4096 && (N & (N - 1)) == 0, "N must be a power of two in [32, 4096]");
+    static constexpr int T = N / 16;                      // threads per FFT
+    static constexpr int R1 = (N <= 256) ? N / 16 : 16;   // first-pass radix
+    static constexpr int RM = (N <= 256) ? 1 : N / 256;   // middle-pass radix (1 = no middle pass)
+    static constexpr int T1 = N / R1;                     // butterflies in pass 1
+    static constexpr int B1 = 16 / R1;                    // pass-1 butterflies per thread
+    static constexpr int BM = 16 / RM;                    // middle butterflies per thread
+    static constexpr int S1 = T1 + T1 / 16;               // row stride of exchange 1 (q1-major)
+    static constexpr int S2 = T + 1;                      // row stride of the last layout (t-major)
+    static constexpr int SF = 17 * (N / 16);              // LDS region of one FFT (float2)
+    static constexpr bool kMultiWave = (T > 64);
+    static constexpr int kFftsPerBlock = 4096 / N;
+};
+
+constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n >> 1); }
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) {
+    return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// W_N^m (forward sign) or its conjugate (inverse), from the fp64-rounded table.
+template <int DIR>
+__device__ __forceinline__ float2 twiddle(int m_times_4096_over_N) {
+    float2 w = twiddle_4096[m_times_4096_over_N & 4095];
+    if (DIR) w.y = -w.y;
+    return w;
+}
+
+// Synchronisation between the threads that share one FFT: nothing but a compiler fence when the
+// FFT lives in one wave (DS operations of a wave are executed in issue order), a workgroup
+// barrier otherwise.
+template <bool MULTI_WAVE>
+__device__ __forceinline__ void fft_sync() {
+    if (MULTI_WAVE) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small in-register DFTs (R = 2, 4, 8, 16), decimation in time on compile-time indices.
+// in[k*STRIDE], k < R  ->  out[q], q < R (natural order).  DIR = 0: e^{-2 pi i/R}, 1: e^{+}.
+// ------------------------------------------------------------------------------------------------
+template <int IDX16, int DIR>
+__device__ __forceinline__ float2 mul_w16(float2 a) {
+    // multiplies by W_16^IDX16 (IDX16 in [0,8)); conjugate for DIR = 1
+    constexpr float c1 = 0.92387953251128673848f, s1 = 0.38268343236508978178f, h = 0.70710678118654752440f;
+    if constexpr (IDX16 == 0) return a;
+    else if constexpr (IDX16 == 4) return DIR ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+    else if constexpr (IDX16 == 2) return DIR ? make_float2(h * (a.x - a.y), h * (a.x + a.y)) : make_float2(h * (a.x + a.y), h * (a.y - a.x));
+    else if constexpr (IDX16 == 6) return DIR ? make_float2(-h * (a.x + a.y), h * (a.x - a.y)) : make_float2(h * (a.y - a.x), -h * (a.x + a.y));
+    else {
+        constexpr float wr = (IDX16 == 1) ? c1 : (IDX16 == 3) ? s1 : (IDX16 == 5) ? -s1 : -c1;
+        constexpr float wi_f = (IDX16 == 1) ? -s1 : (IDX16 == 3) ? -c1 : (IDX16 == 5) ? -c1 : -s1;
+        constexpr float wi = DIR ? -wi_f : wi_f;
+        return make_float2(a.x * wr - a.y * wi, a.x * wi + a.y * wr);
+    }
+}
+
+template <int R, int STRIDE, int DIR>
+struct SmallDft {
+    __device__ static __forceinline__ void run(const float2* in, float2* out) {
+        float2 e[R / 2], o[R / 2];
+        SmallDft<R / 2, 2 * STRIDE, DIR>::run(in, e);
+        SmallDft<R / 2, 2 * STRIDE, DIR>::run(in + STRIDE, o);
+        combine<0>(e, o, out);
+    }
+    template <int K>
+    __device__ static __forceinline__ void combine(const float2* e, const float2* o, float2* out) {
+        if constexpr (K < R / 2) {
+            float2 t = mul_w16<K*(16 / R), DIR>(o[K]);
+            out[K] = cadd(e[K], t);
+            out[K + R / 2] = csub(e[K], t);
+            combine<K + 1>(e, o, out);
+        }
+    }
+};
+template <int STRIDE, int DIR>
+struct SmallDft<1, STRIDE, DIR> {
+    __device__ static __forceinline__ void run(const float2* in, float2* out) { out[0] = in[0]; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Twiddles a thread keeps in registers.  u = thread index inside its FFT (0 .. T-1).
+// ------------------------------------------------------------------------------------------------
+template <int N, int DIR>
+struct Twiddles {
+    using G = Geometry<N>;
+    float2 w1[16];                         // [b*R1 + q1] = W_N^{(u + T*b) * q1}
+    float2 wm[G::RM > 1 ? G::RM : 1];      // [q2] = W_{T1}^{t2 * q2}
+    __device__ __forceinline__ void init(int u, int t2) {
+#pragma unroll
+        for (int b = 0; b < G::B1; ++b)
+#pragma unroll
+            for (int q1 = 1; q1 < G::R1; ++q1) w1[b * G::R1 + q1] = twiddle<DIR>((u + G::T * b) * q1 * (4096 / N));
+        if constexpr (G::RM > 1) {
+#pragma unroll
+            for (int q2 = 1; q2 < G::RM; ++q2) wm[q2] = twiddle<DIR>(t2 * q2 * (4096 / G::T1));
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// The engine.  One instance per thread; tid = threadIdx.x in a 256-thread workgroup.
+// ------------------------------------------------------------------------------------------------
+template <int N, int DIR, int REORDER>
+struct Engine {
+    using G = Geometry<N>;
+    static constexpr int T = G::T, R1 = G::R1, RM = G::RM, T1 = G::T1, B1 = G::B1, BM = G::BM;
+    static constexpr int S1 = G::S1, S2 = G::S2, SF = G::SF;
+    static constexpr int E_BITS = ilog2c(N), T_BITS = ilog2c(T), R1_BITS = ilog2c(R1), B1_BITS = ilog2c(B1);
+
+    int u;        // thread inside the FFT
+    int fft;      // FFT inside the workgroup
+    int t2, a;    // middle / last pass roles: v = t2 + 16*a
+    Twiddles<N, DIR> tw;
+
+    __device__ __forceinline__ void init(int tid) {
+        u = tid % T;
+        fft = tid / T;
+        t2 = u & 15;
+        a = u >> 4;
+        tw.init(u, t2);
+    }
+
+    // element index (inside one FFT, natural order) of register slot (b, r1) for pass 1
+    __device__ __forceinline__ int src_index(int b, int r1) const {
+        if (REORDER) return u + T * b + T1 * r1;
+        // DFT(in[bitrev(n)]): n = t1 + T1*r1 with t1 = u + T*b  ->  bitrev(n) = rev(t1)*R1 + rev(r1),
+        // rev(t1) = rev_T(u)*B1 + rev_B1(b)
+        int ru = (T_BITS > 0) ? (int)(__brev((unsigned)u) >> (32 - (T_BITS > 0 ? T_BITS : 1))) : 0;
+        int rb = (B1_BITS > 0) ? (int)(__brev((unsigned)b) >> (32 - (B1_BITS > 0 ? B1_BITS : 1))) : 0;
+        int rr = (R1_BITS > 0) ? (int)(__brev((unsigned)r1) >> (32 - (R1_BITS > 0 ? R1_BITS : 1))) : 0;
+        return (ru * B1 + rb) * R1 + rr;
+    }
+
+    // ---- inputs ------------------------------------------------------------------------------
+    __device__ __forceinline__ void load_global(float2 (&r)[16], const float2* __restrict__ g, bool active) const {
+#pragma unroll
+        for (int b = 0; b < B1; ++b)
+#pragma unroll
+            for (int r1 = 0; r1 < R1; ++r1) r[b * R1 + r1] = active ? g[src_index(b, r1)] : make_float2(0.f, 0.f);
+    }
+    __device__ __forceinline__ void load_lds(float2 (&r)[16], const float2* sf) const {
+#pragma unroll
+        for (int b = 0; b < B1; ++b)
+#pragma unroll
+            for (int r1 = 0; r1 < R1; ++r1) r[b * R1 + r1] = sf[src_index(b, r1)];
+    }
+
+    // ---- pass 1: B1 radix-R1 butterflies, then W_N^{t1*q1} -------------------------------------
+    __device__ __forceinline__ void pass1(float2 (&r)[16]) const {
+#pragma unroll
+        for (int b = 0; b < B1; ++b) {
+            float2 y[R1];
+            SmallDft<R1, 1, DIR>::run(&r[b * R1], y);
+            r[b * R1] = y[0];
+#pragma unroll
+            for (int q1 = 1; q1 < R1; ++q1) r[b * R1 + q1] = cmul(y[q1], tw.w1[b * R1 + q1]);
+        }
+    }
+
+    // ---- exchange after pass 1 -----------------------------------------------------------------
+    __device__ __forceinline__ void exchange1_write(const float2 (&r)[16], float2* sf) const {
+        if constexpr (RM > 1) {
+            // q1-major rows of S1: element (t1, q1) at q1*S1 + t1   (B1 == 1, t1 = u)
+#pragma unroll
+            for (int q1 = 0; q1 < 16; ++q1) sf[q1 * S1 + u] = r[q1];
+        } else {
+            // two-pass sizes go straight to the last layout: element (t1, q1) at q1*17 + t1
+#pragma unroll
+            for (int b = 0; b < B1; ++b)
+#pragma unroll
+                for (int q1 = 0; q1 < R1; ++q1) sf[q1 * 17 + u + T * b] = r[b * R1 + q1];
+        }
+    }
+
+    // ---- middle pass (N >= 512): BM radix-RM butterflies over r2, then W_{T1}^{t2*q2} -----------
+    __device__ __forceinline__ void middle(float2 (&r)[16], float2* sf) const {
+        if constexpr (RM > 1) {
+#pragma unroll
+            for (int c = 0; c < BM; ++c)
+#pragma unroll
+                for (int r2 = 0; r2 < RM; ++r2) r[c * RM + r2] = sf[(a * BM + c) * S1 + t2 + 16 * r2];
+            fft_sync<G::kMultiWave>();
+#pragma unroll
+            for (int c = 0; c < BM; ++c) {
+                float2 y[RM];
+                SmallDft<RM, 1, DIR>::run(&r[c * RM], y);
+                r[c * RM] = y[0];
+#pragma unroll
+                for (int q2 = 1; q2 < RM; ++q2) r[c * RM + q2] = cmul(y[q2], tw.wm[q2]);
+            }
+            // element (t2, klow = q1 + 16*q2) at t2*S2 + klow
+#pragma unroll
+            for (int c = 0; c < BM; ++c)
+#pragma unroll
+                for (int q2 = 0; q2 < RM; ++q2) sf[t2 * S2 + (a * BM + c) + 16 * q2] = r[c * RM + q2];
+            fft_sync<G::kMultiWave>();
+        }
+    }
+
+    // ---- last pass: one radix-16 butterfly per thread; r[q3] = X[u + T*q3] -----------------------
+    __device__ __forceinline__ void last(float2 (&r)[16], const float2* sf) const {
+        float2 x[16];
+        if constexpr (RM > 1) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) x[t] = sf[t * S2 + u];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) x[t] = sf[u * 17 + t];
+        }
+        SmallDft<16, 1, DIR>::run(x, r);
+    }
+
+    // ---- outputs -------------------------------------------------------------------------------
+    __device__ __forceinline__ void store_global(const float2 (&r)[16], float2* __restrict__ g, bool active) const {
+        if (active) {
+#pragma unroll
+            for (int q3 = 0; q3 < 16; ++q3) g[u + T * q3] = r[q3];
+        }
+    }
+    __device__ __forceinline__ void store_lds(const float2 (&r)[16], float2* sf) const {
+#pragma unroll
+        for (int q3 = 0; q3 < 16; ++q3) sf[u + T * q3] = r[q3];
+    }
+
+    // registers (pass-1 layout) -> registers (output layout) through the FFT's LDS region.
+    // Precondition: every earlier LDS access of this FFT's region has been ordered by fft_sync.
+    __device__ __forceinline__ void transform(float2 (&r)[16], float2* sf) const {
+        pass1(r);
+        exchange1_write(r, sf);
+        fft_sync<G::kMultiWave>();
+        middle(r, sf);
+        last(r, sf);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Device-function surface (reference names).  In place on the workgroup's LDS array; see the
+// layout contract at the top of this file.
+// ------------------------------------------------------------------------------------------------
+template <int N, int DIR, int REORDER>
+__device__ __forceinline__ void fft_lds_inplace(float2* s, const Engine<N, DIR, REORDER>& eng) {
+    using G = Geometry<N>;
+    float2* sf = s + eng.fft * G::SF;
+    float2 r[16];
+    eng.load_lds(r, sf);
+    fft_sync<G::kMultiWave>();          // all inputs are in registers before the region is reused
+    eng.transform(r, sf);
+    fft_sync<G::kMultiWave>();          // all exchange reads done before the results overwrite them
+    eng.store_lds(r, sf);
+}
+
+template <class const_params>
+__device__ void do_SMFFT_CT_DIT(float2* s_input) {
+    Engine<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder> eng;
+    eng.init(threadIdx.x);
+    fft_lds_inplace(s_input, eng);
+}
+
+}  // namespace smfft
+
+using smfft::do_SMFFT_CT_DIT;

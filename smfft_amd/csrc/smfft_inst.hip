@@ -1,0 +1,62 @@
+// smfft_inst.hip -- instantiates every kernel of ONE transform length; compiled once per length
+// with -DSMFFT_N=<32..4096> (see Makefile).
+#include "smfft_kernels.hpp"
+#include "smfft_launch.hpp"
+
+#ifndef SMFFT_N
+#error "compile with -DSMFFT_N=<transform length>"
+#endif
+
+#define SMFFT_PASTE3_(a, b, c) a##b##c
+#define SMFFT_PASTE3(a, b, c) SMFFT_PASTE3_(a, b, c)
+#define CT_CLASS(suffix) SMFFT_PASTE3(FFT_, SMFFT_N, suffix)
+
+namespace smfft {
+
+template <>
+int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, int grid_cap, hipStream_t stream) {
+    if (count <= 0) return 0;
+    dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
+    if (path == 0) {
+        if (!inverse && reorder)  SMFFT_DIT_external<CT_CLASS(_forward)><<<grid, block, 0, stream>>>(d_input, d_output, count);
+        if (!inverse && !reorder) SMFFT_DIT_external<CT_CLASS(_forward_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count);
+        if (inverse && reorder)   SMFFT_DIT_external<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count);
+        if (inverse && !reorder)  SMFFT_DIT_external<CT_CLASS(_inverse_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count);
+    } else {
+        if (!inverse && reorder)  SMFFT_DIT_multiple<CT_CLASS(_forward)><<<grid, block, 0, stream>>>(d_input, d_output, count);
+        if (!inverse && !reorder) SMFFT_DIT_multiple<CT_CLASS(_forward_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count);
+        if (inverse && reorder)   SMFFT_DIT_multiple<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count);
+        if (inverse && !reorder)  SMFFT_DIT_multiple<CT_CLASS(_inverse_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count);
+    }
+    return (int)hipGetLastError();
+}
+
+#if SMFFT_N >= 256
+#define ST_CLASS SMFFT_PASTE3(FFT_, SMFFT_N, )
+template <>
+int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int path, int grid_cap, hipStream_t stream) {
+    if (count <= 0) return 0;
+    dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
+    if (path == 0) FFT_GPU_external<ST_CLASS><<<grid, block, 0, stream>>>(d_input, d_output, count);
+    else           FFT_GPU_multiple<ST_CLASS><<<grid, block, 0, stream>>>(d_input, d_output, count);
+    return (int)hipGetLastError();
+}
+#endif
+
+#if SMFFT_N >= 256 && SMFFT_N <= 2048
+template <>
+int launch_rc<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int path, int grid_cap, hipStream_t stream) {
+    if (count <= 0) return 0;
+    dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
+    if (path == 0) {
+        if (!inverse) FFT_GPU_R2C_C2R_external<ST_CLASS, FFT_forward><<<grid, block, 0, stream>>>(d_input, d_output, count);
+        else          FFT_GPU_R2C_C2R_external<ST_CLASS, FFT_inverse><<<grid, block, 0, stream>>>(d_input, d_output, count);
+    } else {
+        if (!inverse) FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_forward><<<grid, block, 0, stream>>>(d_input, d_output, count);
+        else          FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_inverse><<<grid, block, 0, stream>>>(d_input, d_output, count);
+    }
+    return (int)hipGetLastError();
+}
+#endif
+
+}  // namespace smfft

@@ -1,0 +1,253 @@
+// smfft_kernels.hpp -- the benchmark kernels around the engine (reference names kept).
+//
+//   SMFFT_DIT_external<P>             CT/FFT-GPU-32bit.cu:534-551   global -> FFT -> global  (HBM bound)
+//   SMFFT_DIT_multiple<P>             CT/FFT-GPU-32bit.cu:553-572   NREUSES FFTs in LDS per load/store
+//   FFT_GPU_external/multiple<P>      ST/FFT-GPU-32bit-Stockham.cu:243-278
+//   FFT_GPU_R2C_C2R_external/multiple<P,D>  RC/FFT-GPU-32bit-Stockham.cu:349-384
+//
+// Every kernel uses 256-thread workgroups that own a tile of 4096 float2 (= 4096/N FFTs) and
+// P::fft_sm_required = 4352 float2 of LDS (34 KiB -> 4 workgroups = 16 waves per CU).  The
+// external kernels never stage through LDS on the way in or out: pass 1 loads straight from
+// global memory into registers (each wave instruction reads 512 contiguous bytes for N >= 1024)
+// and the last pass stores straight from registers, so the only LDS traffic is the exchanges.
+// Grids are grid-strided over tiles so a capped ("persistent") grid keeps twiddles in registers.
+#pragma once
+#include "smfft_engine.hpp"
+#include "SM_FFT_stockham_parameters.hpp"
+
+#ifndef NREUSES
+#define NREUSES 100
+#endif
+
+namespace smfft {
+
+// ------------------------------------------------------------------------------------------------
+// C2C, external: out[f] = FFT(in[f]) for f < nFFTs.
+// ------------------------------------------------------------------------------------------------
+template <int N, int DIR, int REORDER>
+__device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nFFTs, float2* s) {
+    using G = Geometry<N>;
+    Engine<N, DIR, REORDER> eng;
+    eng.init(threadIdx.x);
+    float2* sf = s + eng.fft * G::SF;
+    const int ntiles = (nFFTs + G::kFftsPerBlock - 1) / G::kFftsPerBlock;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long f = (long)tile * G::kFftsPerBlock + eng.fft;
+        const bool active = f < nFFTs;
+        float2 r[16];
+        eng.load_global(r, d_input + f * N, active);
+        if (G::kMultiWave) __syncthreads();   // the previous tile's exchange reads are complete
+        eng.transform(r, sf);
+        eng.store_global(r, d_output + f * N, active);
+    }
+}
+
+// tile <-> LDS copies in the natural per-FFT-region layout (used by the `multiple` kernels and
+// by the R2C/C2R kernels): element e of the tile belongs to FFT e/N, position e%N.
+template <int N>
+__device__ __forceinline__ void tile_to_lds(const float2* __restrict__ g, float2* s, long first_fft, long limit_fft) {
+    using G = Geometry<N>;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int e = threadIdx.x + 256 * c;
+        const int j = e / N, n = e % N;
+        s[j * G::SF + n] = (first_fft + j < limit_fft) ? g[e] : make_float2(0.f, 0.f);
+    }
+}
+template <int N>
+__device__ __forceinline__ void lds_to_tile(float2* __restrict__ g, const float2* s, long first_fft, long limit_fft) {
+    using G = Geometry<N>;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int e = threadIdx.x + 256 * c;
+        const int j = e / N, n = e % N;
+        if (first_fft + j < limit_fft) g[e] = s[j * G::SF + n];
+    }
+}
+
+// C2C, multiple: the first nSlots FFTs are loaded once, transformed NREUSES times in LDS, stored once.
+template <int N, int DIR, int REORDER>
+__device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, float2* s) {
+    using G = Geometry<N>;
+    Engine<N, DIR, REORDER> eng;
+    eng.init(threadIdx.x);
+    const int ntiles = (nSlots + G::kFftsPerBlock - 1) / G::kFftsPerBlock;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long first = (long)tile * G::kFftsPerBlock;
+        __syncthreads();
+        tile_to_lds<N>(d_input + first * N, s, first, nSlots);
+        __syncthreads();
+        for (int f = 0; f < NREUSES; ++f) {
+            fft_lds_inplace(s, eng);
+            fft_sync<G::kMultiWave>();   // the reference omits this (latent race, CT:563-565)
+        }
+        __syncthreads();
+        lds_to_tile<N>(d_output + first * N, s, first, nSlots);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// R2C / C2R (real length 2L through a complex FFT of length L).  RC:269-344.
+// Hermitian split (forward, after the C2C) / merge (inverse, before the C2C) on the natural
+// layout in LDS; thread u of an FFT handles the 8 index pairs i = 1 + u + T*j, (i, L - i).
+// ------------------------------------------------------------------------------------------------
+template <int L, int DIR>
+__device__ __forceinline__ void hermitian_pass(float2* sf, int u) {
+    constexpr int T = L / 16;
+    constexpr float ohx = DIR ? -0.5f : 0.5f, ohy = DIR ? 0.5f : -0.5f;
+    if (DIR) {
+        if (u == 0) {
+            float2 z = sf[0];
+            sf[0] = make_float2(0.5f * (z.x + z.y), 0.5f * (z.x - z.y));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = 1 + u + T * j;
+        float2 A = sf[i], B = sf[L - i];
+        float2 H1 = make_float2(0.5f * (A.x + B.x), 0.5f * (A.y - B.y));
+        float2 H2 = make_float2(ohx * (A.y + B.y), ohy * (A.x - B.x));
+        float2 W = twiddle<DIR>(i * (4096 / (2 * L)));
+        float2 WH = cmul(H2, W);
+        sf[i] = make_float2(H1.x + WH.x, H1.y + WH.y);
+        sf[L - i] = make_float2(H1.x - WH.x, -H1.y + WH.y);   // for i == L/2 this value stays (RC:308)
+    }
+    if (!DIR) {
+        if (u == 0) {   // sf[0] is not touched by the pair loop (i >= 1, L - i >= L/2)
+            float2 z = sf[0];
+            sf[0] = make_float2(z.x + z.y, z.x - z.y);
+        }
+    }
+}
+
+// In place on LDS, natural layout, region per FFT (device-function form; RC:269-344).
+template <int L, int DIR>
+__device__ __forceinline__ void r2c_c2r_lds_inplace(float2* s, const Engine<L, DIR, 1>& eng) {
+    using G = Geometry<L>;
+    float2* sf = s + eng.fft * G::SF;
+    if (DIR == 0) {
+        fft_lds_inplace(s, eng);
+        fft_sync<G::kMultiWave>();
+        hermitian_pass<L, 0>(sf, eng.u);
+    } else {
+        hermitian_pass<L, 1>(sf, eng.u);
+        fft_sync<G::kMultiWave>();
+        fft_lds_inplace(s, eng);
+    }
+}
+
+template <int L, int DIR>
+__device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nFFTs, float2* s) {
+    using G = Geometry<L>;
+    Engine<L, DIR, 1> eng;
+    eng.init(threadIdx.x);
+    float2* sf = s + eng.fft * G::SF;
+    const int ntiles = (nFFTs + G::kFftsPerBlock - 1) / G::kFftsPerBlock;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long f = (long)tile * G::kFftsPerBlock + eng.fft;
+        const bool active = f < nFFTs;
+        float2 r[16];
+        if (DIR == 0) {
+            eng.load_global(r, d_input + f * L, active);
+            if (G::kMultiWave) __syncthreads();
+            eng.transform(r, sf);
+            fft_sync<G::kMultiWave>();
+            eng.store_lds(r, sf);
+            fft_sync<G::kMultiWave>();
+            hermitian_pass<L, 0>(sf, eng.u);
+            fft_sync<G::kMultiWave>();
+            eng.load_lds(r, sf);               // natural order: r[c] = sf[u + T*c]
+            eng.store_global(r, d_output + f * L, active);
+        } else {
+            eng.load_global(r, d_input + f * L, active);
+            if (G::kMultiWave) __syncthreads();
+            eng.store_lds(r, sf);
+            fft_sync<G::kMultiWave>();
+            hermitian_pass<L, 1>(sf, eng.u);
+            fft_sync<G::kMultiWave>();
+            eng.load_lds(r, sf);
+            fft_sync<G::kMultiWave>();
+            eng.transform(r, sf);
+            eng.store_global(r, d_output + f * L, active);
+        }
+    }
+}
+
+template <int L, int DIR>
+__device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, float2* s) {
+    using G = Geometry<L>;
+    Engine<L, DIR, 1> eng;
+    eng.init(threadIdx.x);
+    const int ntiles = (nSlots + G::kFftsPerBlock - 1) / G::kFftsPerBlock;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long first = (long)tile * G::kFftsPerBlock;
+        __syncthreads();
+        tile_to_lds<L>(d_input + first * L, s, first, nSlots);
+        __syncthreads();
+        for (int f = 0; f < NREUSES; ++f) {
+            r2c_c2r_lds_inplace<L, DIR>(s, eng);
+            fft_sync<G::kMultiWave>();
+        }
+        __syncthreads();
+        lds_to_tile<L>(d_output + first * L, s, first, nSlots);
+    }
+}
+
+}  // namespace smfft
+
+// ------------------------------------------------------------------------------------------------
+// Kernels and device functions under the reference's names.
+// ------------------------------------------------------------------------------------------------
+template <class const_params>
+__global__ void __launch_bounds__(256) SMFFT_DIT_external(const float2* d_input, float2* d_output, int nFFTs) {
+    __shared__ float2 s_input[const_params::fft_sm_required];
+    smfft::c2c_external_body<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nFFTs, s_input);
+}
+
+template <class const_params>
+__global__ void __launch_bounds__(256) SMFFT_DIT_multiple(const float2* d_input, float2* d_output, int nSlots) {
+    __shared__ float2 s_input[const_params::fft_sm_required];
+    smfft::c2c_multiple_body<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nSlots, s_input);
+}
+
+// Stockham C2C program: un-normalised INVERSE (+i) transform, natural order (ST:76, :429).
+template <class const_params>
+__device__ void do_FFT_Stockham_mk6(float2* s_input) {
+    smfft::Engine<const_params::fft_length, 1, 1> eng;
+    eng.init(threadIdx.x);
+    smfft::fft_lds_inplace(s_input, eng);
+}
+template <class const_params>
+__global__ void __launch_bounds__(256) FFT_GPU_external(const float2* d_input, float2* d_output, int nFFTs) {
+    __shared__ float2 s_input[4352];
+    smfft::c2c_external_body<const_params::fft_length, 1, 1>(d_input, d_output, nFFTs, s_input);
+}
+template <class const_params>
+__global__ void __launch_bounds__(256) FFT_GPU_multiple(const float2* d_input, float2* d_output, int nSlots) {
+    __shared__ float2 s_input[4352];
+    smfft::c2c_multiple_body<const_params::fft_length, 1, 1>(d_input, d_output, nSlots, s_input);
+}
+
+// R2C/C2R program.
+template <class const_params, class const_direction>
+__device__ void do_FFT_Stockham_C2C(float2* s_input) {
+    smfft::Engine<const_params::fft_length, const_direction::fft_direction, 1> eng;
+    eng.init(threadIdx.x);
+    smfft::fft_lds_inplace(s_input, eng);
+}
+template <class const_params, class const_direction>
+__device__ void do_FFT_Stockham_R2C_C2R(float2* s_input) {
+    smfft::Engine<const_params::fft_length, const_direction::fft_direction, 1> eng;
+    eng.init(threadIdx.x);
+    smfft::r2c_c2r_lds_inplace<const_params::fft_length, const_direction::fft_direction>(s_input, eng);
+}
+template <class const_params, class const_direction>
+__global__ void __launch_bounds__(256) FFT_GPU_R2C_C2R_external(const float2* d_input, float2* d_output, int nFFTs) {
+    __shared__ float2 s_input[4352];
+    smfft::r2c_c2r_external_body<const_params::fft_length, const_direction::fft_direction>(d_input, d_output, nFFTs, s_input);
+}
+template <class const_params, class const_direction>
+__global__ void __launch_bounds__(256) FFT_GPU_R2C_C2R_multiple(const float2* d_input, float2* d_output, int nSlots) {
+    __shared__ float2 s_input[4352];
+    smfft::r2c_c2r_multiple_body<const_params::fft_length, const_direction::fft_direction>(d_input, d_output, nSlots, s_input);
+}
