@@ -26,7 +26,7 @@ static execute_t p_exec;
 static destroy_t p_destroy;
 static char backend[64] = "none";
 
-/* returns 1 if an FFTW3-API provider was found */
+/* returns 1 if an FFTW3-API provider was found; may be called again to change the thread count */
 int fftw_baseline_init(int threads) {
     const char* cands[] = {"libfftw3f_omp.so.3", "libfftw3f_threads.so.3", "libfftw3f.so.3", "libmkl_rt.so",
                            "/opt/conda/lib/libmkl_rt.so", "libmkl_rt.so.1", "/opt/conda/lib/libmkl_rt.so.1"};
@@ -40,13 +40,18 @@ int fftw_baseline_init(int threads) {
             lib = h;
             snprintf(backend, sizeof backend, "%s", strstr(cands[i], "mkl") ? "mkl-fftw3-api" : "fftw3f");
             init_threads_t it = (init_threads_t)dlsym(h, "fftwf_init_threads");
-            plan_threads_t pt = (plan_threads_t)dlsym(h, "fftwf_plan_with_nthreads");
-            if (it && pt && threads > 0) { it(); pt(threads); }
-            void (*mkl_set)(int) = (void (*)(int))dlsym(h, "MKL_Set_Num_Threads");
-            if (mkl_set && threads > 0) mkl_set(threads);
+            if (it) it();
         } else {
             dlclose(h);
         }
+    }
+    if (lib && threads > 0) {
+        plan_threads_t pt = (plan_threads_t)dlsym(lib, "fftwf_plan_with_nthreads");
+        if (pt) pt(threads);
+        void (*mkl_set)(int) = (void (*)(int))dlsym(lib, "MKL_Set_Num_Threads");
+        if (mkl_set) mkl_set(threads);
+        void (*mkl_dyn)(int) = (void (*)(int))dlsym(lib, "MKL_Set_Dynamic");
+        if (mkl_dyn) mkl_dyn(0);
     }
     return lib != 0;
 }

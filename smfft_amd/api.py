@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 NREUSES = 100
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsmfft_amd.so")
+LIB_PATH = os.environ.get("SMFFT_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsmfft_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -40,6 +40,8 @@ _SIGS = {
     "smfft_gpu_c2r": (_i, [_vp, _vp, _i, _i, _i]),
     "smfft_set_grid_cap": (None, [_i]),
     "smfft_get_grid_cap": (_i, []),
+    "smfft_set_nreuses": (None, [_i]),
+    "smfft_get_nreuses": (_i, []),
     "smfft_device_count": (_i, []),
     "smfft_set_device": (_i, [_i]),
     "smfft_version": (ctypes.c_char_p, []),

@@ -18,7 +18,8 @@
 namespace {
 
 int g_device = 0;       // the reference's global `int device = 0` (CT:15)
-int g_grid_cap = 0;     // 0: one workgroup per 4096-element tile
+int g_grid_cap = 4096;  // workgroups per launch (grid-stride over tiles); <= 0: one per 4096-element tile
+int g_nreuses = SMFFT_NREUSES;  // applications per slot in the `multiple` kernels (tests lower it)
 bool g_env_read = false;
 
 void read_env() {
@@ -42,34 +43,34 @@ using smfft::launch_st;
 // returns -1 for an unsupported length (nothing launched), else the launch status
 int dispatch_ct(const float2* in, float2* out, int N, int count, int inverse, int reorder, int path, hipStream_t st) {
     switch (N) {
-        case 32:   return launch_ct<32>(in, out, count, inverse, reorder, path, g_grid_cap, st);
-        case 64:   return launch_ct<64>(in, out, count, inverse, reorder, path, g_grid_cap, st);
-        case 128:  return launch_ct<128>(in, out, count, inverse, reorder, path, g_grid_cap, st);
-        case 256:  return launch_ct<256>(in, out, count, inverse, reorder, path, g_grid_cap, st);
-        case 512:  return launch_ct<512>(in, out, count, inverse, reorder, path, g_grid_cap, st);
-        case 1024: return launch_ct<1024>(in, out, count, inverse, reorder, path, g_grid_cap, st);
-        case 2048: return launch_ct<2048>(in, out, count, inverse, reorder, path, g_grid_cap, st);
-        case 4096: return launch_ct<4096>(in, out, count, inverse, reorder, path, g_grid_cap, st);
+        case 32:   return launch_ct<32>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, st);
+        case 64:   return launch_ct<64>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, st);
+        case 128:  return launch_ct<128>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, st);
+        case 256:  return launch_ct<256>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, st);
+        case 512:  return launch_ct<512>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, st);
+        case 1024: return launch_ct<1024>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, st);
+        case 2048: return launch_ct<2048>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, st);
+        case 4096: return launch_ct<4096>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, st);
         default:   return -1;
     }
 }
 int dispatch_st(const float2* in, float2* out, int N, int count, int path, hipStream_t st) {
     switch (N) {
-        case 256:  return launch_st<256>(in, out, count, path, g_grid_cap, st);
-        case 512:  return launch_st<512>(in, out, count, path, g_grid_cap, st);
-        case 1024: return launch_st<1024>(in, out, count, path, g_grid_cap, st);
-        case 2048: return launch_st<2048>(in, out, count, path, g_grid_cap, st);
-        case 4096: return launch_st<4096>(in, out, count, path, g_grid_cap, st);
+        case 256:  return launch_st<256>(in, out, count, path, g_grid_cap, g_nreuses, st);
+        case 512:  return launch_st<512>(in, out, count, path, g_grid_cap, g_nreuses, st);
+        case 1024: return launch_st<1024>(in, out, count, path, g_grid_cap, g_nreuses, st);
+        case 2048: return launch_st<2048>(in, out, count, path, g_grid_cap, g_nreuses, st);
+        case 4096: return launch_st<4096>(in, out, count, path, g_grid_cap, g_nreuses, st);
         default:   return -1;
     }
 }
 // FFT_size is the REAL length; the kernels are instantiated on the complex length L = FFT_size/2 (RC:404-428)
 int dispatch_rc(const float2* in, float2* out, int FFT_size, int count, int inverse, int path, hipStream_t st) {
     switch (FFT_size) {
-        case 512:  return launch_rc<256>(in, out, count, inverse, path, g_grid_cap, st);
-        case 1024: return launch_rc<512>(in, out, count, inverse, path, g_grid_cap, st);
-        case 2048: return launch_rc<1024>(in, out, count, inverse, path, g_grid_cap, st);
-        case 4096: return launch_rc<2048>(in, out, count, inverse, path, g_grid_cap, st);
+        case 512:  return launch_rc<256>(in, out, count, inverse, path, g_grid_cap, g_nreuses, st);
+        case 1024: return launch_rc<512>(in, out, count, inverse, path, g_grid_cap, g_nreuses, st);
+        case 2048: return launch_rc<1024>(in, out, count, inverse, path, g_grid_cap, g_nreuses, st);
+        case 4096: return launch_rc<2048>(in, out, count, inverse, path, g_grid_cap, g_nreuses, st);
         default:   return -1;
     }
 }
@@ -312,6 +313,8 @@ int smfft_gpu_c2r(float* h_output, const void* h_input, int FFT_size, int nFFTs,
 
 // ---- tuning / introspection ------------------------------------------------------------------------
 void smfft_set_grid_cap(int max_workgroups) { read_env(); g_grid_cap = max_workgroups; }
+void smfft_set_nreuses(int n) { g_nreuses = n > 0 ? n : SMFFT_NREUSES; }
+int smfft_get_nreuses(void) { return g_nreuses; }
 int smfft_get_grid_cap(void) { read_env(); return g_grid_cap; }
 int smfft_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 int smfft_set_device(int device) { read_env(); g_device = device; return (int)hipSetDevice(device); }

@@ -62,6 +62,30 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 w) {
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
+// Global-memory accessors of the streaming kernels.  SMFFT_NT=1 marks them non-temporal (`nt`):
+// every input byte is read once and every output byte written once, so nothing is worth keeping
+// in L2/MALL (copy ceiling on MI355X at 4 GiB: 5.36 TB/s plain vs 5.61 TB/s nt, tools/microbench).
+#ifndef SMFFT_NT
+#define SMFFT_NT 1
+#endif
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 gload(const float2* p) {
+#if SMFFT_NT
+    v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(p));
+    return make_float2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void gstore(float2* p, float2 a) {
+#if SMFFT_NT
+    v2f v = {a.x, a.y};
+    __builtin_nontemporal_store(v, reinterpret_cast<v2f*>(p));
+#else
+    *p = a;
+#endif
+}
+
 // W_N^m (forward sign) or its conjugate (inverse), from the fp64-rounded table.
 template <int DIR>
 __device__ __forceinline__ float2 twiddle(int m_times_4096_over_N) {
@@ -170,29 +194,53 @@ struct Engine {
         tw.init(u, t2);
     }
 
-    // element index (inside one FFT, natural order) of register slot (b, r1) for pass 1
-    __device__ __forceinline__ int src_index(int b, int r1) const {
-        if (REORDER) return u + T * b + T1 * r1;
-        // DFT(in[bitrev(n)]): n = t1 + T1*r1 with t1 = u + T*b  ->  bitrev(n) = rev(t1)*R1 + rev(r1),
-        // rev(t1) = rev_T(u)*B1 + rev_B1(b)
-        int ru = (T_BITS > 0) ? (int)(__brev((unsigned)u) >> (32 - (T_BITS > 0 ? T_BITS : 1))) : 0;
-        int rb = (B1_BITS > 0) ? (int)(__brev((unsigned)b) >> (32 - (B1_BITS > 0 ? B1_BITS : 1))) : 0;
-        int rr = (R1_BITS > 0) ? (int)(__brev((unsigned)r1) >> (32 - (R1_BITS > 0 ? R1_BITS : 1))) : 0;
-        return (ru * B1 + rb) * R1 + rr;
-    }
-
-    // ---- inputs ------------------------------------------------------------------------------
+    // ---- inputs: natural order, r[c] = x[u + T*c] (consecutive threads -> consecutive elements) ----
     __device__ __forceinline__ void load_global(float2 (&r)[16], const float2* __restrict__ g, bool active) const {
 #pragma unroll
-        for (int b = 0; b < B1; ++b)
-#pragma unroll
-            for (int r1 = 0; r1 < R1; ++r1) r[b * R1 + r1] = active ? g[src_index(b, r1)] : make_float2(0.f, 0.f);
+        for (int c = 0; c < 16; ++c) r[c] = active ? gload(g + u + T * c) : make_float2(0.f, 0.f);
     }
     __device__ __forceinline__ void load_lds(float2 (&r)[16], const float2* sf) const {
 #pragma unroll
-        for (int b = 0; b < B1; ++b)
+        for (int c = 0; c < 16; ++c) r[c] = sf[u + T * c];
+    }
+
+    // ---- natural registers -> pass-1 slots r[b*R1 + r1] = x'[t1 + T1*r1], t1 = u + T*b ------------
+    // REORDER: x' = x, and t1 + T1*r1 = u + T*(b + B1*r1): a compile-time renaming of registers.
+    // No reorder: x'[n] = x[bitrev(n)].  bitrev(t1 + T1*r1) = 16*rev_T(u) + rev_B1(b)*R1 + rev_R1(r1):
+    // every thread needs 16 CONTIGUOUS elements, the transpose of what coalesced/conflict-free
+    // accesses deliver.  The transposition goes through the FFT's LDS region with one pad per 16
+    // elements (position p at p + p/16), which makes both the write (consecutive lanes ->
+    // consecutive p) and the read (lane -> its own row of 17) bank-conflict free.
+    // Precondition: the region is free (earlier accesses ordered by fft_sync).
+    __device__ __forceinline__ void to_pass1_layout(float2 (&r)[16], float2* sf) const {
+        if constexpr (REORDER) {
+            if constexpr (B1 > 1) {
+                float2 t[16];
 #pragma unroll
-            for (int r1 = 0; r1 < R1; ++r1) r[b * R1 + r1] = sf[src_index(b, r1)];
+                for (int c = 0; c < 16; ++c) t[c] = r[c];
+#pragma unroll
+                for (int b = 0; b < B1; ++b)
+#pragma unroll
+                    for (int r1 = 0; r1 < R1; ++r1) r[b * R1 + r1] = t[b + B1 * r1];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int p = u + T * c;
+                sf[p + (p >> 4)] = r[c];
+            }
+            fft_sync<G::kMultiWave>();
+            const int row = 17 * (int)(__brev((unsigned)u) >> (32 - T_BITS));
+#pragma unroll
+            for (int b = 0; b < B1; ++b)
+#pragma unroll
+                for (int r1 = 0; r1 < R1; ++r1) {
+                    const int rb = (B1_BITS > 0) ? (int)(__brev((unsigned)b) >> (32 - (B1_BITS > 0 ? B1_BITS : 1))) : 0;
+                    const int rr = (R1_BITS > 0) ? (int)(__brev((unsigned)r1) >> (32 - (R1_BITS > 0 ? R1_BITS : 1))) : 0;
+                    r[b * R1 + r1] = sf[row + rb * R1 + rr];
+                }
+            fft_sync<G::kMultiWave>();
+        }
     }
 
     // ---- pass 1: B1 radix-R1 butterflies, then W_N^{t1*q1} -------------------------------------
@@ -264,7 +312,7 @@ struct Engine {
     __device__ __forceinline__ void store_global(const float2 (&r)[16], float2* __restrict__ g, bool active) const {
         if (active) {
 #pragma unroll
-            for (int q3 = 0; q3 < 16; ++q3) g[u + T * q3] = r[q3];
+            for (int q3 = 0; q3 < 16; ++q3) gstore(g + u + T * q3, r[q3]);
         }
     }
     __device__ __forceinline__ void store_lds(const float2 (&r)[16], float2* sf) const {
@@ -272,9 +320,11 @@ struct Engine {
         for (int q3 = 0; q3 < 16; ++q3) sf[u + T * q3] = r[q3];
     }
 
-    // registers (pass-1 layout) -> registers (output layout) through the FFT's LDS region.
+    // registers (natural order, r[c] = x[u + T*c]) -> registers (r[q] = X[u + T*q]) through the
+    // FFT's LDS region.
     // Precondition: every earlier LDS access of this FFT's region has been ordered by fft_sync.
     __device__ __forceinline__ void transform(float2 (&r)[16], float2* sf) const {
+        to_pass1_layout(r, sf);
         pass1(r);
         exchange1_write(r, sf);
         fft_sync<G::kMultiWave>();

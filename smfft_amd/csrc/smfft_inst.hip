@@ -14,7 +14,7 @@
 namespace smfft {
 
 template <>
-int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, int grid_cap, hipStream_t stream) {
+int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, int grid_cap, int nreuses, hipStream_t stream) {
     if (count <= 0) return 0;
     dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
     if (path == 0) {
@@ -23,10 +23,10 @@ int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int i
         if (inverse && reorder)   SMFFT_DIT_external<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count);
         if (inverse && !reorder)  SMFFT_DIT_external<CT_CLASS(_inverse_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count);
     } else {
-        if (!inverse && reorder)  SMFFT_DIT_multiple<CT_CLASS(_forward)><<<grid, block, 0, stream>>>(d_input, d_output, count);
-        if (!inverse && !reorder) SMFFT_DIT_multiple<CT_CLASS(_forward_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count);
-        if (inverse && reorder)   SMFFT_DIT_multiple<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count);
-        if (inverse && !reorder)  SMFFT_DIT_multiple<CT_CLASS(_inverse_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count);
+        if (!inverse && reorder)  SMFFT_DIT_multiple<CT_CLASS(_forward)><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
+        if (!inverse && !reorder) SMFFT_DIT_multiple<CT_CLASS(_forward_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
+        if (inverse && reorder)   SMFFT_DIT_multiple<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
+        if (inverse && !reorder)  SMFFT_DIT_multiple<CT_CLASS(_inverse_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
     }
     return (int)hipGetLastError();
 }
@@ -34,26 +34,26 @@ int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int i
 #if SMFFT_N >= 256
 #define ST_CLASS SMFFT_PASTE3(FFT_, SMFFT_N, )
 template <>
-int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int path, int grid_cap, hipStream_t stream) {
+int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int path, int grid_cap, int nreuses, hipStream_t stream) {
     if (count <= 0) return 0;
     dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
     if (path == 0) FFT_GPU_external<ST_CLASS><<<grid, block, 0, stream>>>(d_input, d_output, count);
-    else           FFT_GPU_multiple<ST_CLASS><<<grid, block, 0, stream>>>(d_input, d_output, count);
+    else           FFT_GPU_multiple<ST_CLASS><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
     return (int)hipGetLastError();
 }
 #endif
 
 #if SMFFT_N >= 256 && SMFFT_N <= 2048
 template <>
-int launch_rc<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int path, int grid_cap, hipStream_t stream) {
+int launch_rc<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int path, int grid_cap, int nreuses, hipStream_t stream) {
     if (count <= 0) return 0;
     dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
     if (path == 0) {
         if (!inverse) FFT_GPU_R2C_C2R_external<ST_CLASS, FFT_forward><<<grid, block, 0, stream>>>(d_input, d_output, count);
         else          FFT_GPU_R2C_C2R_external<ST_CLASS, FFT_inverse><<<grid, block, 0, stream>>>(d_input, d_output, count);
     } else {
-        if (!inverse) FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_forward><<<grid, block, 0, stream>>>(d_input, d_output, count);
-        else          FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_inverse><<<grid, block, 0, stream>>>(d_input, d_output, count);
+        if (!inverse) FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_forward><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
+        else          FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_inverse><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
     }
     return (int)hipGetLastError();
 }

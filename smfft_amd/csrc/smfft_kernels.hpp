@@ -24,21 +24,66 @@ namespace smfft {
 // ------------------------------------------------------------------------------------------------
 // C2C, external: out[f] = FFT(in[f]) for f < nFFTs.
 // ------------------------------------------------------------------------------------------------
+// Wave-coalesced staging for N <= 128 (external kernels only).  With 16 elements per thread an FFT
+// of N <= 128 has 8 or fewer threads, so direct register I/O would touch N/16 * 8 = 16..64
+// contiguous bytes per FFT per instruction.  Instead each wave moves its own 1024-element chunk
+// (its 1024/N FFTs) with 512-byte-contiguous instructions through the FFTs' LDS regions.
+template <int N>
+__device__ __forceinline__ void wave_chunk_to_lds(const float2* __restrict__ gwave, float2* swave, long first_fft, long limit_fft) {
+    using G = Geometry<N>;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int e = lane + 64 * c;
+        const int j = e / N, n = e % N;
+        swave[j * G::SF + n] = (first_fft + j < limit_fft) ? gload(gwave + e) : make_float2(0.f, 0.f);
+    }
+}
+template <int N>
+__device__ __forceinline__ void lds_to_wave_chunk(float2* __restrict__ gwave, const float2* swave, long first_fft, long limit_fft) {
+    using G = Geometry<N>;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int e = lane + 64 * c;
+        const int j = e / N, n = e % N;
+        if (first_fft + j < limit_fft) gstore(gwave + e, swave[j * G::SF + n]);
+    }
+}
+
 template <int N, int DIR, int REORDER>
 __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nFFTs, float2* s) {
     using G = Geometry<N>;
+    constexpr bool kStaged = (N <= 128);
+    constexpr int kFftsPerWave = (N <= 1024) ? 1024 / N : 1;
     Engine<N, DIR, REORDER> eng;
     eng.init(threadIdx.x);
     float2* sf = s + eng.fft * G::SF;
+    const int wave = threadIdx.x >> 6;
+    float2* swave = s + wave * kFftsPerWave * G::SF;
     const int ntiles = (nFFTs + G::kFftsPerBlock - 1) / G::kFftsPerBlock;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long f = (long)tile * G::kFftsPerBlock + eng.fft;
         const bool active = f < nFFTs;
         float2 r[16];
-        eng.load_global(r, d_input + f * N, active);
-        if (G::kMultiWave) __syncthreads();   // the previous tile's exchange reads are complete
-        eng.transform(r, sf);
-        eng.store_global(r, d_output + f * N, active);
+        if constexpr (kStaged) {
+            const long fw = (long)tile * G::kFftsPerBlock + wave * kFftsPerWave;
+            wave_chunk_to_lds<N>(d_input + fw * N, swave, fw, nFFTs);
+            fft_sync<false>();
+            eng.load_lds(r, sf);
+            fft_sync<false>();
+            eng.transform(r, sf);
+            fft_sync<false>();
+            eng.store_lds(r, sf);
+            fft_sync<false>();
+            lds_to_wave_chunk<N>(d_output + fw * N, swave, fw, nFFTs);
+            fft_sync<false>();
+        } else {
+            eng.load_global(r, d_input + f * N, active);
+            if (G::kMultiWave) __syncthreads();   // the previous tile's exchange reads are complete
+            eng.transform(r, sf);
+            eng.store_global(r, d_output + f * N, active);
+        }
     }
 }
 
@@ -65,9 +110,10 @@ __device__ __forceinline__ void lds_to_tile(float2* __restrict__ g, const float2
     }
 }
 
-// C2C, multiple: the first nSlots FFTs are loaded once, transformed NREUSES times in LDS, stored once.
+// C2C, multiple: the first nSlots FFTs are loaded once, transformed nreuses (= NREUSES = 100 in the
+// benchmark; a kernel argument so the tests can run 1, 2 and 4 applications) times in LDS, stored once.
 template <int N, int DIR, int REORDER>
-__device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, float2* s) {
+__device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, float2* s) {
     using G = Geometry<N>;
     Engine<N, DIR, REORDER> eng;
     eng.init(threadIdx.x);
@@ -77,7 +123,7 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_i
         __syncthreads();
         tile_to_lds<N>(d_input + first * N, s, first, nSlots);
         __syncthreads();
-        for (int f = 0; f < NREUSES; ++f) {
+        for (int f = 0; f < nreuses; ++f) {
             fft_lds_inplace(s, eng);
             fft_sync<G::kMultiWave>();   // the reference omits this (latent race, CT:563-565)
         }
@@ -174,7 +220,7 @@ __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__
 }
 
 template <int L, int DIR>
-__device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, float2* s) {
+__device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, float2* s) {
     using G = Geometry<L>;
     Engine<L, DIR, 1> eng;
     eng.init(threadIdx.x);
@@ -184,7 +230,7 @@ __device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__
         __syncthreads();
         tile_to_lds<L>(d_input + first * L, s, first, nSlots);
         __syncthreads();
-        for (int f = 0; f < NREUSES; ++f) {
+        for (int f = 0; f < nreuses; ++f) {
             r2c_c2r_lds_inplace<L, DIR>(s, eng);
             fft_sync<G::kMultiWave>();
         }
@@ -205,9 +251,9 @@ __global__ void __launch_bounds__(256) SMFFT_DIT_external(const float2* d_input,
 }
 
 template <class const_params>
-__global__ void __launch_bounds__(256) SMFFT_DIT_multiple(const float2* d_input, float2* d_output, int nSlots) {
+__global__ void __launch_bounds__(256) SMFFT_DIT_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
     __shared__ float2 s_input[const_params::fft_sm_required];
-    smfft::c2c_multiple_body<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nSlots, s_input);
+    smfft::c2c_multiple_body<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nSlots, nreuses, s_input);
 }
 
 // Stockham C2C program: un-normalised INVERSE (+i) transform, natural order (ST:76, :429).
@@ -223,9 +269,9 @@ __global__ void __launch_bounds__(256) FFT_GPU_external(const float2* d_input, f
     smfft::c2c_external_body<const_params::fft_length, 1, 1>(d_input, d_output, nFFTs, s_input);
 }
 template <class const_params>
-__global__ void __launch_bounds__(256) FFT_GPU_multiple(const float2* d_input, float2* d_output, int nSlots) {
+__global__ void __launch_bounds__(256) FFT_GPU_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
     __shared__ float2 s_input[4352];
-    smfft::c2c_multiple_body<const_params::fft_length, 1, 1>(d_input, d_output, nSlots, s_input);
+    smfft::c2c_multiple_body<const_params::fft_length, 1, 1>(d_input, d_output, nSlots, nreuses, s_input);
 }
 
 // R2C/C2R program.
@@ -247,7 +293,7 @@ __global__ void __launch_bounds__(256) FFT_GPU_R2C_C2R_external(const float2* d_
     smfft::r2c_c2r_external_body<const_params::fft_length, const_direction::fft_direction>(d_input, d_output, nFFTs, s_input);
 }
 template <class const_params, class const_direction>
-__global__ void __launch_bounds__(256) FFT_GPU_R2C_C2R_multiple(const float2* d_input, float2* d_output, int nSlots) {
+__global__ void __launch_bounds__(256) FFT_GPU_R2C_C2R_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
     __shared__ float2 s_input[4352];
-    smfft::r2c_c2r_multiple_body<const_params::fft_length, const_direction::fft_direction>(d_input, d_output, nSlots, s_input);
+    smfft::r2c_c2r_multiple_body<const_params::fft_length, const_direction::fft_direction>(d_input, d_output, nSlots, nreuses, s_input);
 }

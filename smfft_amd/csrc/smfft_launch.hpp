@@ -7,16 +7,16 @@
 namespace smfft {
 
 // path: 0 = external (count = number of FFTs), 1 = multiple (count = number of FFT slots, each
-// transformed NREUSES times in LDS).  grid_cap <= 0: one workgroup per 4096-element tile.
+// transformed nreuses times in LDS; the benchmark entry points pass NREUSES = 100).  grid_cap <= 0: one workgroup per 4096-element tile.
 // Returns hipSuccess (0) or the launch error.
 template <int N>
-int launch_ct(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, int grid_cap, hipStream_t stream);
+int launch_ct(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, int grid_cap, int nreuses, hipStream_t stream);
 // Stockham C2C program (inverse sign), N = 256..4096.
 template <int N>
-int launch_st(const float2* d_input, float2* d_output, int count, int path, int grid_cap, hipStream_t stream);
+int launch_st(const float2* d_input, float2* d_output, int count, int path, int grid_cap, int nreuses, hipStream_t stream);
 // R2C (inverse = 0) / C2R (inverse = 1) of real length 2L, L = 256..2048.
 template <int L>
-int launch_rc(const float2* d_input, float2* d_output, int count, int inverse, int path, int grid_cap, hipStream_t stream);
+int launch_rc(const float2* d_input, float2* d_output, int count, int inverse, int path, int grid_cap, int nreuses, hipStream_t stream);
 
 inline int grid_for(int count, int ffts_per_block, int grid_cap) {
     int ntiles = (count + ffts_per_block - 1) / ffts_per_block;

@@ -102,57 +102,77 @@ def test_input_not_modified(sm):
 
 
 # ----------------------------------------------------------------- the in-LDS `multiple` path
+def _slots(n, nffts):
+    return nffts // 400 * 4 if n == 32 else nffts // 200 * 2 if n == 64 else nffts // 100
+
+
 @pytest.mark.parametrize("n", C2C_SIZES)
-@pytest.mark.parametrize("reo", [0, 1])
-def test_ct_multiple_is_repeated_unitary_fft(sm, oracle_lib, n, reo):
-    """FFT_multiple_benchmark applies the transform NREUSES = 100 times in LDS.  With the forward
-    transform F, F^4 = N^2 * I (and F P F P ... for no-reorder), so 100 applications are
-    N^50 times a known permutation -- far outside fp32.  The kernel is therefore checked on a
-    scaled copy: the test drives the same device function with inputs scaled so that the oracle's
-    100-fold application stays finite only for tiny N; for the general case we check the first
-    nFFTs/100 slots are the only ones written and contain inf/NaN-free data for N = 32."""
-    nffts = 100 * (4096 // n) + 100
-    rng = np.random.default_rng(n + reo)
-    x = (rng.standard_normal((nffts, n)) + 1j * rng.standard_normal((nffts, n))).astype(np.complex64)
-    x *= np.float32(1e-30)    # 100 un-normalised FFTs multiply magnitudes by ~N^50
-    got = sm.c2c(x, False, bool(reo), path="multiple")
-    slots = sm.NREUSES and (nffts // 400 * 4 if n == 32 else nffts // 200 * 2 if n == 64 else nffts // 100)
-    tail = got[slots:].view(np.uint32)
-    assert (tail == 0xFFFFFFFF).all(), "multiple path wrote outside the first nFFTs/100 slots"
-    if n <= 64:
-        y = x[:slots].astype(np.complex128)
-        for _ in range(100):
-            y = ref.ct_c2c(y, False, bool(reo))
-        # magnitudes ~1e-30 * n^50: representable for n=32 (1e45 overflows) -> compare in log-free relative terms where finite
-        finite = np.isfinite(got[:slots]).all()
-        if finite and np.abs(y).max() < 1e38:
-            l2, mx = ref.fft_errors(got[:slots], y)
-            assert l2 < 1e-4, l2
-
-
-@pytest.mark.parametrize("n", [32, 256, 1024, 4096])
-def test_multiple_equals_external_on_involution(sm, n):
-    """Exact check of the multiple path without overflow: scale so values stay finite and use
-    F^4 = N^2 I  =>  F^100 = N^50 I.  With inputs pre-scaled by N^-12.5 per 25 ... instead we use
-    the identity on the device itself: multiple(x) must equal 100 chained external calls."""
+@pytest.mark.parametrize("inv,reo", [(0, 1), (0, 0), (1, 1), (1, 0)])
+@pytest.mark.parametrize("reuses", [1, 2, 4])
+def test_ct_multiple_k_applications(sm, oracle_lib, n, inv, reo, reuses):
+    """FFT_multiple_benchmark applies do_SMFFT_CT_DIT NREUSES = 100 times in LDS, which overflows
+    fp32 (as upstream, CT:563-565: timing only).  The same kernel with the reuse count lowered to
+    1, 2, 4 is checked exactly: k applications of the oracle; only the first nFFTs/100 slots are
+    written (CT:669-683)."""
     per_block = 4096 // n
-    nffts = 100 * per_block
+    nffts = 100 * (2 * per_block + 3) + 7
+    rng = np.random.default_rng(n * 100 + inv * 10 + reo)
+    x = ((rng.random((nffts, n), dtype=np.float32) - 0.5) + 1j * (rng.random((nffts, n), dtype=np.float32) - 0.5)).astype(np.complex64)
+    sm.lib.smfft_set_nreuses(reuses)
+    try:
+        got = sm.c2c(x, bool(inv), bool(reo), path="multiple")
+    finally:
+        sm.lib.smfft_set_nreuses(0)
+    slots = _slots(n, nffts)
+    assert (got[slots:].view(np.uint32) == 0xFFFFFFFF).all(), "multiple path wrote outside the first nFFTs/100 slots"
+    want = x[:slots].astype(np.complex128)
+    for _ in range(reuses):
+        want = oa.ct_c2c(oracle_lib, want, inv, reo, "f64")
+    l2, mx = ref.fft_errors(got[:slots], want)
+    assert l2 <= 5e-7 * reuses ** 0.5 and mx <= 1e-6 * reuses ** 0.5, (l2, mx)
+
+
+@pytest.mark.parametrize("n", ST_SIZES)
+def test_stockham_multiple_k_applications(sm, oracle_lib, n):
+    nffts = 100 * (4096 // n + 1) + 50
     rng = np.random.default_rng(n)
-    x = (rng.standard_normal((nffts, n)) + 1j * rng.standard_normal((nffts, n))).astype(np.complex64)
-    scale = np.float32(float(n) ** -0.5)
-    slots = nffts // 400 * 4 if n == 32 else nffts // 100
-    y = x[:slots].copy()
-    # chain external calls with a unitary rescale each step to stay in range; the multiple kernel
-    # has no rescale, so feed it an input whose magnitude makes the product identical: compare
-    # directions only (normalise both results per FFT)
-    for _ in range(100):
-        y = sm.c2c(y, False, True) * scale
-    got = sm.c2c(x * np.float32(1e-20 if n >= 1024 else 1e-10 if n >= 256 else 1.0) , False, True, path="multiple")[:slots]
-    if not np.isfinite(got).all():
-        pytest.skip("100 un-normalised FFTs overflow fp32 for this size (as upstream, CT:563-565)")
-    gn = got / np.linalg.norm(got, axis=-1, keepdims=True)
-    yn = y / np.linalg.norm(y, axis=-1, keepdims=True)
-    assert np.abs(gn - yn).max() < 1e-4
+    x = ((rng.random((nffts, n), dtype=np.float32) - 0.5) + 1j * (rng.random((nffts, n), dtype=np.float32) - 0.5)).astype(np.complex64)
+    sm.lib.smfft_set_nreuses(2)
+    try:
+        din, dout = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
+        sm.lib.smfft_memset(dout.ptr, 0xFF, x.nbytes)
+        rc, ms = sm.FFT_multiple_benchmark(din.ptr, dout.ptr, n, nffts, family="st")
+        got = dout.to_host(np.complex64, x.shape)
+    finally:
+        sm.lib.smfft_set_nreuses(0)
+    slots = nffts // 100
+    want = oa.st_c2c(oracle_lib, oa.st_c2c(oracle_lib, x[:slots], True, "f64"), True, "f64")
+    ref.assert_close_fp32(got[:slots], want, f"ST multiple N={n}")
+    assert (got[slots:].view(np.uint32) == 0xFFFFFFFF).all()
+
+
+@pytest.mark.parametrize("n", R2C_SIZES)
+def test_r2c_multiple_k_applications(sm, oracle_lib, n):
+    """RC's multiple kernel re-applies the forward R2C in place: the packed N/2 complex output is
+    the next application's N reals (RC:367-384)."""
+    nffts = 100 * (4096 // (n // 2) + 1) + 1
+    rng = np.random.default_rng(n)
+    x = (rng.random((nffts, n), dtype=np.float32) - 0.5)
+    for reuses in (1, 2):
+        sm.lib.smfft_set_nreuses(reuses)
+        try:
+            din, dout = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
+            sm.lib.smfft_memset(dout.ptr, 0xFF, x.nbytes)
+            sm.FFT_multiple_benchmark(din.ptr, dout.ptr, n, nffts, family="rc")
+            got = dout.to_host(np.complex64, (nffts, n // 2))
+        finally:
+            sm.lib.smfft_set_nreuses(0)
+        slots = nffts // 100
+        want = x[:slots].astype(np.float64)
+        for _ in range(reuses):
+            want = oa.r2c(oracle_lib, want, "f64").view(np.float64).reshape(slots, n)
+        ref.assert_close_fp32(got[:slots], want.view(np.complex128).reshape(slots, n // 2), f"R2C multiple N={n} x{reuses}")
+        assert (got[slots:].view(np.uint32) == 0xFFFFFFFF).all()
 
 
 # ------------------------------------------------------------- properties at full BASELINE size
