@@ -48,27 +48,24 @@ def cpu_baseline(n, sample_ffts, threads):
         fb.fftw_baseline_backend.restype = ctypes.c_char_p
         fb.fftw_baseline_c2c.restype = ctypes.c_double
         fb.fftw_baseline_c2c.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
-        # MKL with one thread per hardware thread thrashes on this many small FFTs: try a few
-        # thread counts for ~2 s each and keep the best (cores = the count that won)
-        cands = sorted({c for c in (1, 8, 16, 32, 64, 128, threads // 2, threads) if 1 <= c <= threads})
-        best_all, best_thr, reps_all = 1e30, 0, 0
+        fb.fftw_baseline_c2c_sliced.restype = ctypes.c_double
+        fb.fftw_baseline_c2c_sliced.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        # one single-threaded plan per batch slice, slices run concurrently (oracle/fftw_baseline.c);
+        # a few thread counts are tried for a bounded time, `cores` = the count that won
+        cands = sorted({c for c in (1, 8, 32, 64, 128, threads // 2, threads) if 1 <= c <= threads})
+        best_all, best_thr = 1e30, 0
         t_start = time.time()
-        for thr in cands:
-            if not fb.fftw_baseline_init(thr) or time.time() - t_start > 25.0:
-                break
-            t0, reps, best = time.time(), 0, 1e30
-            while reps < 2 or (time.time() - t0 < 2.0 and reps < 50):
-                t = fb.fftw_baseline_c2c(x.ctypes.data_as(fp), out.ctypes.data_as(fp), n, sample_ffts, 0, 1)
-                if t <= 0:
+        if fb.fftw_baseline_init(1):
+            for thr in cands:
+                if time.time() - t_start > 25.0:
                     break
-                best = min(best, t)
-                reps += 1
-            if best < best_all:
-                best_all, best_thr, reps_all = best, thr, reps
+                t = fb.fftw_baseline_c2c_sliced(x.ctypes.data_as(fp), out.ctypes.data_as(fp), n, sample_ffts, 0, 5, thr)
+                if 0 < t < best_all:
+                    best_all, best_thr = t, thr
         if best_all < 1e29:
             res = {"value": sample_ffts / best_all, "unit": "FFT/s", "cores": best_thr, "kind": "port",
-                   "impl": fb.fftw_baseline_backend().decode() + " fftwf_plan_many_dft (FFTW_ESTIMATE), out of place; best thread count of " + str(cands),
-                   "sample": f"N={n} C2C forward, {sample_ffts} FFTs ({x.nbytes >> 20} MiB in), best of {reps_all} executes"}
+                   "impl": fb.fftw_baseline_backend().decode() + " fftwf_plan_many_dft (FFTW_ESTIMATE) per batch slice, out of place, slices on pthreads; thread counts tried " + str(cands),
+                   "sample": f"N={n} C2C forward, {sample_ffts} FFTs ({x.nbytes >> 20} MiB in), best of 5 rounds"}
     except OSError:
         pass
     if res is None:
@@ -84,6 +81,21 @@ def cpu_baseline(n, sample_ffts, threads):
                "sample": f"N={n} C2C forward, {sample_ffts} FFTs, best of 3"}
     res["GB/s"] = res["value"] * 2 * n * 8 / 1e9
     return res
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/*_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x2 per the
+    gfx950 correction, calibrated on the same access shape).  None if no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"]["void SMFFT_DIT_external<FFT_1024_forward>"]
+        return k["hbm_bytes_per_launch"]
+    except (KeyError, ValueError):
+        return None
 
 
 def main():
@@ -154,10 +166,8 @@ def main():
     err = (torch.linalg.vector_norm(ys - torch.fft.fft(xs, dim=-1)) / torch.linalg.vector_norm(torch.fft.fft(xs, dim=-1))).item()
     assert err < 5e-7, f"timed output failed the spot check: relL2={err}"
 
-    t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_max, kernel_ms_max = t[0].item(), t[1].item()
+    from smfft_amd.sharding import reduce_stats
+    wall_max, kernel_ms_max, _ = reduce_stats(dist, dev, wall, kernel_ms)
 
     # in-LDS `multiple` path on the same buffers (config 3's N=1024 point), informational
     mult = {}
@@ -193,14 +203,14 @@ def main():
                        "fft_size": n, "nffts_per_gpu": nffts, "parallelism": f"batch-split x{world}"},
             "hbm_GBps_per_gpu": alg_bytes / (ms_per_step * 1e-3) / 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel": "SMFFT_DIT_external<FFT_1024_forward>", "kernel_ms": kernel_ms_max,
+                         "traffic": measured_traffic(), "kernel": "SMFFT_DIT_external<FFT_1024_forward>", "kernel_ms": kernel_ms_max,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "multiple_path": mult,
             "spot_check_relL2": err,
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = os.cpu_count() or 1
-            out["cpu_baseline"] = cpu_baseline(n, 65536, threads)
+            out["cpu_baseline"] = cpu_baseline(n, 131072, threads)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -29,7 +29,7 @@ extern "C" {
 
 /* FFT_init (CT:576-581).  The CUDA cache/bank configuration calls have no gfx950 meaning; this
  * selects the device (SMFFT_DEVICE or the one already current) and reads the tuning environment
- * (SMFFT_GRID_CAP: maximum workgroups per launch, default 4096; 0 = one per 4096-element tile). */
+ * (SMFFT_GRID_CAP: maximum workgroups per launch, default 12288; 0 = one per 4096-element tile). */
 void smfft_init(void);
 
 /* ---- Cooley-Tukey C2C family, N = 32 .. 4096 ------------------------------------------------ */
@@ -76,7 +76,7 @@ int smfft_gpu_r2c(void* h_output, const float* h_input, int FFT_size, int nFFTs,
 int smfft_gpu_c2r(float* h_output, const void* h_input, int FFT_size, int nFFTs, int nRuns);
 
 /* ---- tuning / introspection ------------------------------------------------------------------- */
-void smfft_set_grid_cap(int max_workgroups); /* default 4096 (persistent, grid-strided); 0 = one workgroup per tile */
+void smfft_set_grid_cap(int max_workgroups); /* default 12288 (persistent, grid-strided); 0 = one workgroup per tile */
 int smfft_get_grid_cap(void);
 /* Applications of the transform per slot in the `multiple` kernels.  The benchmark value is
  * SMFFT_NREUSES (100, CT:10); the knob exists so the in-LDS device functions can be verified with

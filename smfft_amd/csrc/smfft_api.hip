@@ -18,7 +18,8 @@
 namespace {
 
 int g_device = 0;       // the reference's global `int device = 0` (CT:15)
-int g_grid_cap = 4096;  // workgroups per launch (grid-stride over tiles); <= 0: one per 4096-element tile
+int g_grid_cap = 12288; // workgroups per launch (grid-stride over tiles; 12288 = 12 or 16 rounds of the 4 or 3
+                        // resident workgroups per CU; measured sweet spot); <= 0: one per tile
 int g_nreuses = SMFFT_NREUSES;  // applications per slot in the `multiple` kernels (tests lower it)
 bool g_env_read = false;
 

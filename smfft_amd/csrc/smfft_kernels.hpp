@@ -18,6 +18,10 @@
 #ifndef NREUSES
 #define NREUSES 100
 #endif
+// external kernels stage through LDS with wave-coalesced global access up to this length
+#ifndef SMFFT_STAGED_MAX_N
+#define SMFFT_STAGED_MAX_N 128
+#endif
 
 namespace smfft {
 
@@ -54,7 +58,7 @@ __device__ __forceinline__ void lds_to_wave_chunk(float2* __restrict__ gwave, co
 template <int N, int DIR, int REORDER>
 __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nFFTs, float2* s) {
     using G = Geometry<N>;
-    constexpr bool kStaged = (N <= 128);
+    constexpr bool kStaged = (N <= SMFFT_STAGED_MAX_N);
     constexpr int kFftsPerWave = (N <= 1024) ? 1024 / N : 1;
     Engine<N, DIR, REORDER> eng;
     eng.init(threadIdx.x);

@@ -1,0 +1,37 @@
+"""Batch sharding across the GPUs of one node.
+
+Every FFT of a batch is independent (one workgroup tile per 4096 elements, no inter-tile
+communication), so the multi-GPU path is an embarrassingly parallel contiguous batch split:
+rank g of G owns FFTs [first, first + count) and runs the identical kernel on its slab; there is
+no data-path collective.  The only communication is the reduction of per-rank timings (MAX) and
+error counts (SUM), which bench.py does with torch.distributed (RCCL on GPUs, gloo in the CPU tests).
+"""
+
+
+def shard_range(nffts: int, rank: int, world: int):
+    """Contiguous, balanced split: returns (first_fft, count) of `rank`'s slab.  The first
+    nffts % world ranks get one extra FFT; slabs tile [0, nffts) exactly, in rank order."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world: {rank}/{world}")
+    if nffts < 0:
+        raise ValueError("nffts must be >= 0")
+    base, extra = divmod(nffts, world)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def slab_bytes(fft_size: int, count: int, bytes_per_element: int = 8) -> int:
+    return fft_size * count * bytes_per_element
+
+
+def reduce_stats(dist, device, wall_s: float, kernel_ms: float, errors: int = 0):
+    """MAX over ranks of (wall, kernel) times and SUM of error counts.  `dist` is
+    torch.distributed (initialised) or None for a single process."""
+    import torch
+
+    t = torch.tensor([wall_s, kernel_ms], dtype=torch.float64, device=device)
+    e = torch.tensor([errors], dtype=torch.int64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(e, op=dist.ReduceOp.SUM)
+    return t[0].item(), t[1].item(), int(e.item())

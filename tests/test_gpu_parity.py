@@ -229,3 +229,28 @@ def test_config4_r2c_c2r_roundtrip(sm, oracle_lib):
         l2, mx = ref.fft_errors(got / (n / 2), src.astype(np.float64))
         assert l2 < 1e-6 and mx < 2e-6, (off, l2, mx)
     print(f"config4 R2C {ms:.3f} ms, C2R {ms2:.3f} ms")
+
+
+# ------------------------------------------------------------------- the C harness programs (L4)
+@pytest.mark.parametrize("prog,args,expect", [
+    ("FFT_CooleyTukey_C2C.exe", ["1024", "2000", "2", "0", "1"], 1),
+    ("FFT_CooleyTukey_C2C.exe", ["32", "1001", "2", "1", "1"], 1),
+    ("FFT_CooleyTukey_C2C.exe", ["256", "1000", "1", "0", "0"], 0),
+    ("FFT_Stockham_C2C.exe", ["2048", "1500", "2"], 1),
+    ("FFT_Stockham_R2C_C2R.exe", ["2048", "1200", "2"], 2),
+])
+def test_harness_programs(sm, prog, args, expect):
+    """The harness (g++-compiled host code with the reference's prototypes, CLI and printed lines)
+    against libsmfft_amd.so, checked by the vendor library (hipFFT) exactly as upstream checks
+    against cuFFT with max_error = 1e-4."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "..", "harness", prog)
+    if not os.path.exists(exe):
+        pytest.skip("harness not built")
+    p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600, env=dict(os.environ, SMFFT_SEED="7"))
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.count("PASSED") == expect and "FAILED" not in p.stdout, p.stdout
+    if expect == 0:
+        assert "There is no verification of the results if FFT are not reordered." in p.stdout
+    assert "SH FFT normal" in p.stdout or "smFFT R2C time" in p.stdout

@@ -1,0 +1,55 @@
+"""world_size-2 test of the N>1 path on CPU (gloo): contiguous batch split, identical work per
+rank, no data-path collective, MAX-reduced timings / SUM-reduced error counts.
+The per-rank transform is played by the CPU oracle here (no GPU in this container); on GPUs
+bench.py runs the same logic with the HIP kernel and RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, nffts, n, outdir):
+    sys.path.insert(0, ROOT)
+    import ctypes
+
+    from smfft_amd.sharding import reduce_stats, shard_range
+    from tests import oracle_api as oa
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.oracle_ct_c2c_f64.argtypes = [dp, dp, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int]
+    rng = np.random.default_rng(99)                       # same batch on every rank
+    x = rng.standard_normal((nffts, n)) + 1j * rng.standard_normal((nffts, n))
+    first, count = shard_range(nffts, rank, world)
+    y = oa.ct_c2c(lib, x[first:first + count], 0, 1, "f64")
+    np.save(os.path.join(outdir, f"shard{rank}.npy"), y)
+    wall, kernel, errs = reduce_stats(dist, torch.device("cpu"), wall_s=1.0 + rank, kernel_ms=10.0 - rank, errors=rank + 1)
+    assert wall == float(world) and kernel == 10.0 and errs == world * (world + 1) // 2
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_batch_split(tmp_path):
+    world, nffts, n = 2, 11, 256
+    mp.spawn(_worker, args=(world, _free_port(), nffts, n, str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f"shard{r}.npy") for r in range(world)])
+    rng = np.random.default_rng(99)
+    x = rng.standard_normal((nffts, n)) + 1j * rng.standard_normal((nffts, n))
+    np.testing.assert_allclose(got, np.fft.fft(x, axis=-1), atol=1e-9)
