@@ -51,6 +51,9 @@ struct Geometry {
     static constexpr int S2 = T + 1;                      // row stride of the last layout (t-major)
     static constexpr int SF = 17 * (N / 16);              // LDS region of one FFT (float2)
     static constexpr bool kMultiWave = (T > 64);
+    // N = 512 / 1024: exchange 1 is a transpose between the lane's row bits (lane >> 4) and the top
+    // register-index bits, done in registers with v_permlane16_swap / v_permlane32_swap: no LDS.
+    static constexpr bool kRegExchange1 = (RM == 2 || RM == 4);
     static constexpr int kFftsPerBlock = 4096 / N;
 };
 
@@ -183,6 +186,7 @@ struct Engine {
 
     int u;        // thread inside the FFT
     int fft;      // FFT inside the workgroup
+    int t1;       // pass-1 role (which butterfly t1 + T*b this thread computes)
     int t2, a;    // middle / last pass roles: v = t2 + 16*a
     Twiddles<N, DIR> tw;
 
@@ -191,13 +195,26 @@ struct Engine {
         fft = tid / T;
         t2 = u & 15;
         a = u >> 4;
-        tw.init(u, t2);
+        // REORDER: role = lane.  No reorder: the thread with role t1 reads row rev_T(t1) of the
+        // padded transposition image (to_pass1_layout); with role = lane the 32 lanes of a DS read
+        // group would hit only 32 / 2^(log2(T)-5) different banks (T = 64/128/256: 2/4/8-way).
+        // XOR-ing the top log2(T)-5 role bits with the reversed low lane bits makes the rows of a
+        // read group distinct mod 32, while the low 4 role bits stay the lane's (exchange-1 writes
+        // remain conflict free).
+        t1 = u;
+        if constexpr (!REORDER && T_BITS > 5 && !G::kRegExchange1) {
+            constexpr int m = T_BITS - 5;
+            t1 = u ^ ((int)(__brev((unsigned)(u & ((1 << m) - 1))) >> (32 - m)) << 5);
+        }
+        tw.init(t1, t2);
     }
 
     // ---- inputs: natural order, r[c] = x[u + T*c] (consecutive threads -> consecutive elements) ----
-    __device__ __forceinline__ void load_global(float2 (&r)[16], const float2* __restrict__ g, bool active) const {
+    // (threads of an out-of-range FFT are pointed at FFT 0 by the caller instead of being predicated
+    // per element: 16 unconditional back-to-back loads; their result is never stored)
+    __device__ __forceinline__ void load_global(float2 (&r)[16], const float2* __restrict__ g) const {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) r[c] = active ? gload(g + u + T * c) : make_float2(0.f, 0.f);
+        for (int c = 0; c < 16; ++c) r[c] = gload(g + u + T * c);
     }
     __device__ __forceinline__ void load_lds(float2 (&r)[16], const float2* sf) const {
 #pragma unroll
@@ -230,7 +247,7 @@ struct Engine {
                 sf[p + (p >> 4)] = r[c];
             }
             fft_sync<G::kMultiWave>();
-            const int row = 17 * (int)(__brev((unsigned)u) >> (32 - T_BITS));
+            const int row = 17 * (int)(__brev((unsigned)t1) >> (32 - T_BITS));
 #pragma unroll
             for (int b = 0; b < B1; ++b)
 #pragma unroll
@@ -256,28 +273,72 @@ struct Engine {
     }
 
     // ---- exchange after pass 1 -----------------------------------------------------------------
+    // One-bit transposes between a lane bit and a register-index bit.  v_permlane16_swap(A, B) swaps
+    // the odd 16-lane rows of A with the even rows of B, v_permlane32_swap(A, B) the upper 32 lanes
+    // of A with the lower 32 of B: exactly "element (lane bit 1, reg bit 0) <-> (lane bit 0, reg bit 1)".
+    template <int LANE_BIT>
+    __device__ static __forceinline__ void swap_bit(float2& A, float2& B) {
+        typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+        uint2v x, y;
+        if constexpr (LANE_BIT == 4) {
+            x = __builtin_amdgcn_permlane16_swap(__float_as_uint(A.x), __float_as_uint(B.x), false, false);
+            y = __builtin_amdgcn_permlane16_swap(__float_as_uint(A.y), __float_as_uint(B.y), false, false);
+        } else {
+            x = __builtin_amdgcn_permlane32_swap(__float_as_uint(A.x), __float_as_uint(B.x), false, false);
+            y = __builtin_amdgcn_permlane32_swap(__float_as_uint(A.y), __float_as_uint(B.y), false, false);
+        }
+        A = make_float2(__uint_as_float(x[0]), __uint_as_float(y[0]));
+        B = make_float2(__uint_as_float(x[1]), __uint_as_float(y[1]));
+    }
+
+    // N = 512 / 1024.  After pass 1 lane (t2, row r2) holds element (t1 = t2 + 16*r2, q1) in r[q1];
+    // the middle pass wants lane (t2, row a) to hold (t2 + 16*r2, q1 = a*BM + c) in r[c*RM + r2]:
+    // transpose the row bits with the top log2(RM) bits of q1, then rename registers.
+    __device__ __forceinline__ void exchange1_registers(float2 (&r)[16]) const {
+        if constexpr (RM == 4) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if ((q & 4) == 0) swap_bit<4>(r[q], r[q + 4]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) swap_bit<5>(r[q], r[q + 8]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) swap_bit<4>(r[q], r[q + 8]);
+        }
+        // now r[BM*r2 + c] = (t2 + 16*r2, a*BM + c)  ->  r[c*RM + r2]
+        float2 t[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = r[i];
+#pragma unroll
+        for (int c = 0; c < BM; ++c)
+#pragma unroll
+            for (int r2 = 0; r2 < RM; ++r2) r[c * RM + r2] = t[BM * r2 + c];
+    }
+
     __device__ __forceinline__ void exchange1_write(const float2 (&r)[16], float2* sf) const {
         if constexpr (RM > 1) {
-            // q1-major rows of S1: element (t1, q1) at q1*S1 + t1   (B1 == 1, t1 = u)
+            // q1-major rows of S1: element (t1, q1) at q1*S1 + t1   (B1 == 1)
 #pragma unroll
-            for (int q1 = 0; q1 < 16; ++q1) sf[q1 * S1 + u] = r[q1];
+            for (int q1 = 0; q1 < 16; ++q1) sf[q1 * S1 + t1] = r[q1];
         } else {
             // two-pass sizes go straight to the last layout: element (t1, q1) at q1*17 + t1
 #pragma unroll
             for (int b = 0; b < B1; ++b)
 #pragma unroll
-                for (int q1 = 0; q1 < R1; ++q1) sf[q1 * 17 + u + T * b] = r[b * R1 + q1];
+                for (int q1 = 0; q1 < R1; ++q1) sf[q1 * 17 + t1 + T * b] = r[b * R1 + q1];
         }
     }
 
     // ---- middle pass (N >= 512): BM radix-RM butterflies over r2, then W_{T1}^{t2*q2} -----------
     __device__ __forceinline__ void middle(float2 (&r)[16], float2* sf) const {
         if constexpr (RM > 1) {
+            if constexpr (!G::kRegExchange1) {
 #pragma unroll
-            for (int c = 0; c < BM; ++c)
+                for (int c = 0; c < BM; ++c)
 #pragma unroll
-                for (int r2 = 0; r2 < RM; ++r2) r[c * RM + r2] = sf[(a * BM + c) * S1 + t2 + 16 * r2];
-            fft_sync<G::kMultiWave>();
+                    for (int r2 = 0; r2 < RM; ++r2) r[c * RM + r2] = sf[(a * BM + c) * S1 + t2 + 16 * r2];
+                fft_sync<G::kMultiWave>();
+            }
 #pragma unroll
             for (int c = 0; c < BM; ++c) {
                 float2 y[RM];
@@ -326,8 +387,12 @@ struct Engine {
     __device__ __forceinline__ void transform(float2 (&r)[16], float2* sf) const {
         to_pass1_layout(r, sf);
         pass1(r);
-        exchange1_write(r, sf);
-        fft_sync<G::kMultiWave>();
+        if constexpr (G::kRegExchange1) {
+            exchange1_registers(r);
+        } else {
+            exchange1_write(r, sf);
+            fft_sync<G::kMultiWave>();
+        }
         middle(r, sf);
         last(r, sf);
     }

@@ -18,6 +18,15 @@
 #ifndef NREUSES
 #define NREUSES 100
 #endif
+// minimum waves per SIMD requested for the in-LDS `multiple` kernels (0 = let the compiler decide)
+#ifndef SMFFT_MULT_WAVES
+#define SMFFT_MULT_WAVES 0
+#endif
+#if SMFFT_MULT_WAVES > 0
+#define SMFFT_MULT_BOUNDS __launch_bounds__(256, SMFFT_MULT_WAVES)
+#else
+#define SMFFT_MULT_BOUNDS __launch_bounds__(256)
+#endif
 // external kernels stage through LDS with wave-coalesced global access up to this length
 #ifndef SMFFT_STAGED_MAX_N
 #define SMFFT_STAGED_MAX_N 128
@@ -32,26 +41,52 @@ namespace smfft {
 // of N <= 128 has 8 or fewer threads, so direct register I/O would touch N/16 * 8 = 16..64
 // contiguous bytes per FFT per instruction.  Instead each wave moves its own 1024-element chunk
 // (its 1024/N FFTs) with 512-byte-contiguous instructions through the FFTs' LDS regions.
+// `full` (wave-uniform) = every FFT of the chunk is inside the batch: the loads are then issued
+// back to back with no per-element predicate.  (A per-element "load or zero" select makes hipcc
+// branch around every load and wait vmcnt(0) after each one: 16 serialised HBM round trips.)
 template <int N>
-__device__ __forceinline__ void wave_chunk_to_lds(const float2* __restrict__ gwave, float2* swave, long first_fft, long limit_fft) {
+__device__ __forceinline__ void wave_chunk_to_lds(const float2* __restrict__ gwave, const float2* __restrict__ gsafe, float2* swave, long first_fft, long limit_fft) {
     using G = Geometry<N>;
     const int lane = threadIdx.x & 63;
+    float2 v[16];
+    if (first_fft + 1024 / N <= limit_fft) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = gload(gwave + lane + 64 * c);
+    } else {
+        // ragged tail: out-of-range lanes read a safe address and the value is replaced by zero
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int e = lane + 64 * c;
+            const bool ok = first_fft + e / N < limit_fft;
+            float2 t = gload(ok ? gwave + e : gsafe);
+            v[c] = ok ? t : make_float2(0.f, 0.f);
+        }
+    }
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         const int e = lane + 64 * c;
-        const int j = e / N, n = e % N;
-        swave[j * G::SF + n] = (first_fft + j < limit_fft) ? gload(gwave + e) : make_float2(0.f, 0.f);
+        swave[(e / N) * G::SF + (e % N)] = v[c];
     }
 }
 template <int N>
 __device__ __forceinline__ void lds_to_wave_chunk(float2* __restrict__ gwave, const float2* swave, long first_fft, long limit_fft) {
     using G = Geometry<N>;
     const int lane = threadIdx.x & 63;
+    float2 v[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         const int e = lane + 64 * c;
-        const int j = e / N, n = e % N;
-        if (first_fft + j < limit_fft) gstore(gwave + e, swave[j * G::SF + n]);
+        v[c] = swave[(e / N) * G::SF + (e % N)];
+    }
+    if (first_fft + 1024 / N <= limit_fft) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) gstore(gwave + lane + 64 * c, v[c]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int e = lane + 64 * c;
+            if (first_fft + e / N < limit_fft) gstore(gwave + e, v[c]);
+        }
     }
 }
 
@@ -72,7 +107,7 @@ __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_i
         float2 r[16];
         if constexpr (kStaged) {
             const long fw = (long)tile * G::kFftsPerBlock + wave * kFftsPerWave;
-            wave_chunk_to_lds<N>(d_input + fw * N, swave, fw, nFFTs);
+            wave_chunk_to_lds<N>(d_input + fw * N, d_input, swave, fw, nFFTs);
             fft_sync<false>();
             eng.load_lds(r, sf);
             fft_sync<false>();
@@ -83,7 +118,7 @@ __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_i
             lds_to_wave_chunk<N>(d_output + fw * N, swave, fw, nFFTs);
             fft_sync<false>();
         } else {
-            eng.load_global(r, d_input + f * N, active);
+            eng.load_global(r, d_input + (active ? f : 0) * N);
             if (G::kMultiWave) __syncthreads();   // the previous tile's exchange reads are complete
             eng.transform(r, sf);
             eng.store_global(r, d_output + f * N, active);
@@ -198,7 +233,7 @@ __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__
         const bool active = f < nFFTs;
         float2 r[16];
         if (DIR == 0) {
-            eng.load_global(r, d_input + f * L, active);
+            eng.load_global(r, d_input + (active ? f : 0) * L);
             if (G::kMultiWave) __syncthreads();
             eng.transform(r, sf);
             fft_sync<G::kMultiWave>();
@@ -209,7 +244,7 @@ __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__
             eng.load_lds(r, sf);               // natural order: r[c] = sf[u + T*c]
             eng.store_global(r, d_output + f * L, active);
         } else {
-            eng.load_global(r, d_input + f * L, active);
+            eng.load_global(r, d_input + (active ? f : 0) * L);
             if (G::kMultiWave) __syncthreads();
             eng.store_lds(r, sf);
             fft_sync<G::kMultiWave>();
@@ -255,7 +290,7 @@ __global__ void __launch_bounds__(256) SMFFT_DIT_external(const float2* d_input,
 }
 
 template <class const_params>
-__global__ void __launch_bounds__(256) SMFFT_DIT_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
+__global__ void SMFFT_MULT_BOUNDS SMFFT_DIT_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
     __shared__ float2 s_input[const_params::fft_sm_required];
     smfft::c2c_multiple_body<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nSlots, nreuses, s_input);
 }
@@ -273,7 +308,7 @@ __global__ void __launch_bounds__(256) FFT_GPU_external(const float2* d_input, f
     smfft::c2c_external_body<const_params::fft_length, 1, 1>(d_input, d_output, nFFTs, s_input);
 }
 template <class const_params>
-__global__ void __launch_bounds__(256) FFT_GPU_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
+__global__ void SMFFT_MULT_BOUNDS FFT_GPU_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
     __shared__ float2 s_input[4352];
     smfft::c2c_multiple_body<const_params::fft_length, 1, 1>(d_input, d_output, nSlots, nreuses, s_input);
 }
@@ -297,7 +332,7 @@ __global__ void __launch_bounds__(256) FFT_GPU_R2C_C2R_external(const float2* d_
     smfft::r2c_c2r_external_body<const_params::fft_length, const_direction::fft_direction>(d_input, d_output, nFFTs, s_input);
 }
 template <class const_params, class const_direction>
-__global__ void __launch_bounds__(256) FFT_GPU_R2C_C2R_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
+__global__ void SMFFT_MULT_BOUNDS FFT_GPU_R2C_C2R_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
     __shared__ float2 s_input[4352];
     smfft::r2c_c2r_multiple_body<const_params::fft_length, const_direction::fft_direction>(d_input, d_output, nSlots, nreuses, s_input);
 }

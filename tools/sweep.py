@@ -45,7 +45,7 @@ for n in [int(s) for s in args.sizes.split(",")]:
                 ts.sort()
                 med, mn = ts[len(ts) // 2], ts[0]
                 if path == "external":
-                    gb = (2 * nbytes if args.family != "rc" else nbytes) / 1e9
+                    gb = 2 * nbytes / 1e9
                     print(f"{args.family} N={n:5d} {path:8s} {var} cap={cap:6d}: median {med:.4f} ms ({gb/med*1e3:7.1f} GB/s)  min {mn:.4f} ms ({gb/mn*1e3:7.1f} GB/s)", flush=True)
                 else:
                     cnt = (nffts // 100) * 100
