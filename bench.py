@@ -169,6 +169,17 @@ def main():
     from smfft_amd.sharding import reduce_stats
     wall_max, kernel_ms_max, _ = reduce_stats(dist, dev, wall, kernel_ms)
 
+    # same-run copy ceiling: the kernel's own access shape without the FFT (outside the timed region)
+    for _ in range(3):
+        sm.lib.smfft_copy_launch(d_in.data_ptr(), d_out.data_ptr(), nffts * n, sh)
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0.record(stream)
+    for _ in range(20):
+        sm.lib.smfft_copy_launch(d_in.data_ptr(), d_out.data_ptr(), nffts * n, sh)
+    c1.record(stream)
+    torch.cuda.synchronize(dev)
+    copy_ms = c0.elapsed_time(c1) / 20
+
     # in-LDS `multiple` path on the same buffers (config 3's N=1024 point), informational
     mult = {}
     for reo in (0, 1):
@@ -204,7 +215,8 @@ def main():
             "hbm_GBps_per_gpu": alg_bytes / (ms_per_step * 1e-3) / 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": measured_traffic(), "kernel": "SMFFT_DIT_external<FFT_1024_forward>", "kernel_ms": kernel_ms_max,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "copy_ceiling": alg_bytes / (copy_ms * 1e-3) / 1e9, "frac_of_copy": copy_ms / kernel_ms_max},
             "multiple_path": mult,
             "spot_check_relL2": err,
         }

@@ -1,0 +1,56 @@
+// fft_convolution.hip -- the library use case of SMFFT (reference README.md:10-16: "the code is
+// expected to be called within a GPU kernel"): a user kernel that calls the device function.
+//
+// Batched circular convolution of length-1024 complex series with one filter whose spectrum H is
+// given:  y = IFFT( FFT(x) .* H ) / N.  One 256-thread workgroup owns 4 series (a 4096-element
+// tile); everything between the global load and the global store stays in LDS / registers:
+//     global -> LDS | do_SMFFT_CT_DIT<FFT_1024_forward> | .* H | do_SMFFT_CT_DIT<FFT_1024_inverse> | -> global
+// Build: hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-slp-vectorize -fPIC -shared \
+//        -I smfft_amd/csrc examples/fft_convolution.hip -o smfft_amd/libsmfft_examples.so
+#include <hip/hip_runtime.h>
+#include "smfft_engine.hpp"
+
+template <class Fwd, class Inv>
+__global__ void __launch_bounds__(256) convolve_kernel(const float2* __restrict__ x, const float2* __restrict__ H, float2* __restrict__ y, int nSeries) {
+    constexpr int N = Fwd::fft_size;
+    __shared__ float2 s[Fwd::fft_sm_required];
+    const long first = (long)blockIdx.x * Fwd::fft_per_block;
+    // natural order, series j of the workgroup at s[j*fft_region + n]
+    for (int e = threadIdx.x; e < 4096; e += 256) {
+        const int j = e / N, n = e % N;
+        s[j * Fwd::fft_region + n] = (first + j < nSeries) ? x[first * N + e] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    do_SMFFT_CT_DIT<Fwd>(s);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4096; e += 256) {
+        const int j = e / N, k = e % N;
+        const float2 a = s[j * Fwd::fft_region + k], h = H[k];
+        s[j * Fwd::fft_region + k] = make_float2(a.x * h.x - a.y * h.y, a.x * h.y + a.y * h.x);
+    }
+    __syncthreads();
+    do_SMFFT_CT_DIT<Inv>(s);
+    __syncthreads();
+    const float scale = 1.0f / N;
+    for (int e = threadIdx.x; e < 4096; e += 256) {
+        const int j = e / N, n = e % N;
+        if (first + j < nSeries) {
+            const float2 v = s[j * Fwd::fft_region + n];
+            y[first * N + e] = make_float2(v.x * scale, v.y * scale);
+        }
+    }
+}
+
+extern "C" int smfft_example_convolve_1024(const void* d_x, const void* d_H, void* d_y, int nSeries, void* stream) {
+    if (nSeries <= 0) return 0;
+    const int grid = (nSeries + FFT_1024_forward::fft_per_block - 1) / FFT_1024_forward::fft_per_block;
+    convolve_kernel<FFT_1024_forward, FFT_1024_inverse><<<grid, 256, 0, (hipStream_t)stream>>>((const float2*)d_x, (const float2*)d_H, (float2*)d_y, nSeries);
+    return (int)hipGetLastError();
+}
+
+extern "C" int smfft_example_convolve_256(const void* d_x, const void* d_H, void* d_y, int nSeries, void* stream) {
+    if (nSeries <= 0) return 0;
+    const int grid = (nSeries + FFT_256_forward::fft_per_block - 1) / FFT_256_forward::fft_per_block;
+    convolve_kernel<FFT_256_forward, FFT_256_inverse><<<grid, 256, 0, (hipStream_t)stream>>>((const float2*)d_x, (const float2*)d_H, (float2*)d_y, nSeries);
+    return (int)hipGetLastError();
+}

@@ -64,6 +64,10 @@ int smfft_rc_multiple_benchmark(const float* d_input, float* d_output, int FFT_s
 int smfft_launch(int family, int path, const void* d_input, void* d_output, int FFT_size, int nFFTs,
                  int inverse, int reorder, void* hip_stream);
 
+/* Calibration: streams n_float2 elements (a multiple of 4096) from d_input to d_output with exactly
+ * the external kernels' global access shape and grid, no FFT: the same-run copy ceiling. */
+int smfft_copy_launch(const void* d_input, void* d_output, long long n_float2, void* hip_stream);
+
 /* ---- L3 wrappers: host buffers in, host buffers out (alloc, H2D, nRuns launches, D2H, free) ---- */
 /* GPU_smFFT_4elements (CT:827-908). */
 int smfft_gpu_ct(const void* h_input, void* h_output, int FFT_size, int nFFTs, int inverse, int reorder,

@@ -151,6 +151,11 @@ int smfft_launch(int family, int path, const void* d_input, void* d_output, int 
     return -1;
 }
 
+int smfft_copy_launch(const void* d_input, void* d_output, long long n_float2, void* hip_stream) {
+    read_env();
+    return smfft::launch_stream_copy((const float2*)d_input, (float2*)d_output, (long)n_float2, g_grid_cap, (hipStream_t)hip_stream);
+}
+
 // ---- L3 wrappers ---------------------------------------------------------------------------------
 int smfft_gpu_ct(const void* h_input, void* h_output, int FFT_size, int nFFTs, int inverse, int reorder, int nRuns, double* single_ex_time, double* multi_ex_time) {
     select_device();

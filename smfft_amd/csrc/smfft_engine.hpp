@@ -241,13 +241,18 @@ struct Engine {
                     for (int r1 = 0; r1 < R1; ++r1) r[b * R1 + r1] = t[b + B1 * r1];
             }
         } else {
+            // pad shift: one pad per 16 elements, except N = 1024 (roles must equal lanes for the
+            // register exchange 1, so the rows a read group touches are the even or the odd ones):
+            // one pad per 32 elements makes those 32 rows distinct mod 32 as well.
+            constexpr int PS = (N == 1024) ? 5 : 4;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 const int p = u + T * c;
-                sf[p + (p >> 4)] = r[c];
+                sf[p + (p >> PS)] = r[c];
             }
             fft_sync<G::kMultiWave>();
-            const int row = 17 * (int)(__brev((unsigned)t1) >> (32 - T_BITS));
+            const int g16 = 16 * (int)(__brev((unsigned)t1) >> (32 - T_BITS));
+            const int row = g16 + (g16 >> PS);
 #pragma unroll
             for (int b = 0; b < B1; ++b)
 #pragma unroll

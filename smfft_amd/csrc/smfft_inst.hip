@@ -31,6 +31,16 @@ int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int i
     return (int)hipGetLastError();
 }
 
+#if SMFFT_N == 1024
+int launch_stream_copy(const float2* d_input, float2* d_output, long n_float2, int grid_cap, hipStream_t stream) {
+    long ntiles = n_float2 / 4096;
+    if (ntiles <= 0) return 0;
+    long g = (grid_cap > 0 && ntiles > grid_cap) ? grid_cap : ntiles;
+    SMFFT_stream_copy<0><<<dim3((unsigned)g), dim3(256), 0, stream>>>(d_input, d_output, ntiles);
+    return (int)hipGetLastError();
+}
+#endif
+
 #if SMFFT_N >= 256
 #define ST_CLASS SMFFT_PASTE3(FFT_, SMFFT_N, )
 template <>

@@ -281,6 +281,29 @@ __device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__
 }  // namespace smfft
 
 // ------------------------------------------------------------------------------------------------
+// Calibration kernel: the external kernels' exact global access shape (one wave per 8 KiB chunk,
+// 16 x 8 B/lane non-temporal loads at 512 B stride, 16 stores, same grid-stride over 4096-element
+// tiles) with no FFT in between.  bench.py times it next to the FFT so the HBM-bound kernels are
+// reported against a same-run, same-shape copy ceiling as well as against the 8 TB/s datasheet peak.
+// ------------------------------------------------------------------------------------------------
+template <int kUnused>
+__global__ void __launch_bounds__(256) SMFFT_stream_copy(const float2* __restrict__ d_input, float2* __restrict__ d_output, long ntiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (a contiguous run of tiles per workgroup instead of this grid stride measured the same:
+    //  5.6-5.9 TB/s either way, tools/copy_probe.py)
+    const long first = blockIdx.x, step = gridDim.x, last = ntiles;
+    for (long tile = first; tile < last; tile += step) {
+        const float2* g = d_input + tile * 4096 + wave * 1024 + lane;
+        float2* o = d_output + tile * 4096 + wave * 1024 + lane;
+        float2 r[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) r[c] = smfft::gload(g + 64 * c);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) smfft::gstore(o + 64 * c, r[c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Kernels and device functions under the reference's names.
 // ------------------------------------------------------------------------------------------------
 template <class const_params>

@@ -18,6 +18,9 @@ int launch_st(const float2* d_input, float2* d_output, int count, int path, int 
 template <int L>
 int launch_rc(const float2* d_input, float2* d_output, int count, int inverse, int path, int grid_cap, int nreuses, hipStream_t stream);
 
+// calibration copy of n_float2 elements (multiple of 4096) with the external kernels' access shape
+int launch_stream_copy(const float2* d_input, float2* d_output, long n_float2, int grid_cap, hipStream_t stream);
+
 inline int grid_for(int count, int ffts_per_block, int grid_cap) {
     int ntiles = (count + ffts_per_block - 1) / ffts_per_block;
     if (grid_cap > 0 && ntiles > grid_cap) return grid_cap;

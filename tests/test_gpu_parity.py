@@ -254,3 +254,31 @@ def test_harness_programs(sm, prog, args, expect):
     if expect == 0:
         assert "There is no verification of the results if FFT are not reordered." in p.stdout
     assert "SH FFT normal" in p.stdout or "smFFT R2C time" in p.stdout
+
+
+# ------------------------------------------- device functions called from a user kernel (examples/)
+@pytest.mark.parametrize("n,sym", [(1024, "smfft_example_convolve_1024"), (256, "smfft_example_convolve_256")])
+def test_example_convolution_kernel(sm, n, sym):
+    """examples/fft_convolution.hip: a user kernel chaining do_SMFFT_CT_DIT<forward> -> .* H ->
+    do_SMFFT_CT_DIT<inverse> in LDS (the library use case, reference README.md:10-16)."""
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(sm.LIB_PATH), "libsmfft_examples.so")
+    if not os.path.exists(path):
+        pytest.skip("examples not built")
+    ex = ctypes.CDLL(path)
+    fn = getattr(ex, sym)
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    rng = np.random.default_rng(n)
+    nser = 3 * (4096 // n) + 1
+    x = (rng.standard_normal((nser, n)) + 1j * rng.standard_normal((nser, n))).astype(np.complex64)
+    h = np.zeros(n, np.complex128)
+    h[:5] = [0.4, 0.3, 0.2, 0.1, -0.05j]
+    H = np.fft.fft(h).astype(np.complex64)
+    dx, dH, dy = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer.from_host(H), sm.DeviceBuffer(x.nbytes)
+    assert fn(dx.ptr, dH.ptr, dy.ptr, nser, None) == 0
+    sm.lib.smfft_synchronize()
+    got = dy.to_host(np.complex64, x.shape)
+    want = np.fft.ifft(np.fft.fft(x.astype(np.complex128), axis=-1) * H.astype(np.complex128), axis=-1)
+    l2, mx = ref.fft_errors(got, want)
+    assert l2 < 1e-6 and mx < 2e-6, (l2, mx)
