@@ -114,12 +114,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # test hooks (a 1-GPU box cannot host two RCCL ranks): SMFFT_BENCH_DEVICE pins every rank to one
+    # device, SMFFT_BENCH_BACKEND=gloo reduces the timings on the CPU instead of over RCCL
+    if "SMFFT_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["SMFFT_BENCH_DEVICE"])
+    backend = os.environ.get("SMFFT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     import smfft_amd as sm  # raises if libsmfft_amd.so is missing
 
@@ -167,7 +175,7 @@ def main():
     assert err < 5e-7, f"timed output failed the spot check: relL2={err}"
 
     from smfft_amd.sharding import reduce_stats
-    wall_max, kernel_ms_max, _ = reduce_stats(dist, dev, wall, kernel_ms)
+    wall_max, kernel_ms_max, _ = reduce_stats(dist, dev if backend == "nccl" else torch.device("cpu"), wall, kernel_ms)
 
     # same-run copy ceiling: the kernel's own access shape without the FFT (outside the timed region)
     for _ in range(3):

@@ -1,0 +1,73 @@
+"""Summarises gpurun_out/<tag>/ (written by tools/profile_round.sh) into the tracked profiles/ files.
+usage: python tools/collect_profiles.py r01"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join("gpurun_out", tag)
+os.makedirs("profiles", exist_ok=True)
+
+
+def counters(sub):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return agg
+
+
+# 1. kernel stats of the bench command
+for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, f"profiles/{tag}_bench_kernel_stats.csv")
+for name in ("bench.json", "bench_under_rocprof.json", "configs.json", "mult_saturation.txt"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), f"profiles/{tag}_{name}")
+
+# 2. HBM traffic
+out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separate pass, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline",
+       "units": "FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE reports 1/2 of a coalesced streaming read (MI355X_MICROARCH.md, HBM)",
+       "calibration": {"note": "tools/microbench/membw 268435456 under the same two passes: tile8 = the engine's access shape (8 B/lane, 512 B per wave instruction) moves 2097152 KiB each way"},
+       "kernels": {}}
+for sub, key in (("pmc_calib_fetch", "FETCH_SIZE"), ("pmc_calib_write", "WRITE_SIZE")):
+    for (k, c), v in counters(sub).items():
+        if k in ("tile8", "tile16", "copy16_nt") and c == key:
+            out["calibration"].setdefault(k, {})[key + "_KiB_mean"] = sum(v) / len(v)
+for sub, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    for (k, c), v in counters(sub).items():
+        if "SMFFT" in k and c == key:
+            out["kernels"].setdefault(k, {})[key + "_KiB_mean"] = sum(v) / len(v)
+            out["kernels"][k][key + "_launches"] = len(v)
+k = "void SMFFT_DIT_external<FFT_1024_forward>"
+if k in out["kernels"] and len(out["kernels"][k]) >= 4:
+    e = out["kernels"][k]
+    e["hbm_bytes_per_launch"] = (2 * e["FETCH_SIZE_KiB_mean"] + e["WRITE_SIZE_KiB_mean"]) * 1024
+    e["algorithmic_bytes_per_launch"] = 2 * 1024 * 524288 * 8
+    e["traffic_over_algorithmic"] = e["hbm_bytes_per_launch"] / e["algorithmic_bytes_per_launch"]
+    json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
+    print("traffic/algorithmic =", e["traffic_over_algorithmic"])
+
+# 3. LDS counters of the sweep
+rows = {}
+total = 1 << 29
+for (k, c), v in counters("pmc_lds").items():
+    m = re.search(r"(SMFFT_DIT_\w+)<FFT_(\d+)_forward(_noreorder)?>", k)
+    if not m:
+        continue
+    path, n, nr = m.group(1), int(m.group(2)), bool(m.group(3))
+    nfft = total // n
+    if "multiple" in path:
+        nfft = (nfft // 400 * 400) if n == 32 else (nfft // 200 * 200) if n == 64 else (nfft // 100 * 100)
+    rows.setdefault(f"{path} N={n} {'noreorder' if nr else 'reorder'}", {})[c] = sum(v) / len(v) / nfft
+for name, r in rows.items():
+    if "SQ_LDS_IDX_ACTIVE" in r and r["SQ_LDS_IDX_ACTIVE"]:
+        r["bank_conflict_ratio"] = r.get("SQ_LDS_BANK_CONFLICT", 0.0) / r["SQ_LDS_IDX_ACTIVE"]
+json.dump({"command": "rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES -- python3 tools/sweep.py --sizes 32..4096 --paths multiple,external --variants f0,f1",
+           "unit": "counter value per FFT (README batch: 2^29/N FFTs; multiple path: floor(nFFTs/100)*100 FFT executions)",
+           "per_fft": dict(sorted(rows.items()))}, open(f"profiles/{tag}_pmc_lds.json", "w"), indent=1)
+print("wrote profiles/ for", tag, ":", sorted(os.listdir("profiles")))
