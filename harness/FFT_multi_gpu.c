@@ -1,0 +1,122 @@
+// FFT_multi_gpu.c -- config 5 of BASELINE.json at the C level: a batch of N-point C2C FFTs sharded
+// across the GPUs of one node.  Usage:
+//     FFT_multi_gpu.exe <FFT length> <FFTs per GPU> <nRuns> <inverse 0|1> <reorder 0|1> [nGPUs]
+//
+// The path shards embarrassingly: GPU g owns the contiguous slab
+// [g*B, (g+1)*B) of the batch, generates it on its own host thread, uploads it, and runs the
+// identical kernel through the same L2 call (FFT_external_benchmark) as the single-GPU harness;
+// there is NO data-path collective.  RCCL (over xGMI between GPUs) is used only for what
+// north_star calls the trivial part: one communicator per GPU (ncclCommInitAll) and an all-reduce
+// of the per-GPU statistics -- MAX of the kernel time, SUM of the error counts -- so every rank
+// ends with the job-level numbers.  One host thread per GPU (HIP's current device is per thread).
+#include "harness_common.h"
+#include <pthread.h>
+#include <rccl/rccl.h>
+
+int FFT_external_benchmark(float2 *d_input, float2 *d_output, int FFT_size, int nFFTs, bool inverse, bool reorder, double *FFT_time);
+void FFT_init();
+
+typedef struct {
+	int gpu, nGPUs, FFT_size, nFFTs, nRuns;
+	bool inverse, reorder;
+	ncclComm_t comm;
+	double kernel_ms;       // this GPU's mean launch time
+	double job_ms;          // MAX over GPUs (after the all-reduce)
+	double job_errors;      // SUM over GPUs
+	int status;
+} worker_t;
+
+static void *worker(void *arg) {
+	worker_t *w = (worker_t *) arg;
+	w->status = 1;
+	if (hipSetDevice(w->gpu) != hipSuccess) return NULL;
+	const size_t count = (size_t) w->FFT_size*w->nFFTs, bytes = count*sizeof(float2);
+	float2 *h_in = (float2 *) malloc(bytes), *h_out = (float2 *) malloc(bytes);
+	float2 *d_in = NULL, *d_out = NULL;
+	float *d_stats = NULL;
+	hipStream_t stream;
+	if (!h_in || !h_out || hipMalloc((void **) &d_in, bytes) != hipSuccess || hipMalloc((void **) &d_out, bytes) != hipSuccess
+	    || hipMalloc((void **) &d_stats, 2*sizeof(float)) != hipSuccess || hipStreamCreate(&stream) != hipSuccess) {
+		printf("GPU %d: allocation failed\n", w->gpu);
+		return NULL;
+	}
+	unsigned seed = 20200720u + 7919u*(unsigned) w->gpu;        // per-slab reproducible data, U[0,1) like FFT.c:141-142
+	for (size_t f = 0; f < count; f++) {
+		h_in[f].y = rand_r(&seed)/(float) RAND_MAX;
+		h_in[f].x = rand_r(&seed)/(float) RAND_MAX;
+	}
+	if (hipMemcpy(d_in, h_in, bytes, hipMemcpyHostToDevice) != hipSuccess) return NULL;
+	FFT_init();
+	double total = 0;
+	FFT_external_benchmark(d_in, d_out, w->FFT_size, w->nFFTs, w->inverse, w->reorder, &total);   // warm-up
+	total = 0;
+	for (int r = 0; r < w->nRuns; r++) FFT_external_benchmark(d_in, d_out, w->FFT_size, w->nFFTs, w->inverse, w->reorder, &total);
+	w->kernel_ms = total/w->nRuns;
+	if (hipMemcpy(h_out, d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess) return NULL;
+
+	// slab self-check without a second library: Parseval, sum|X|^2 = N * sum|x|^2 per FFT (first 64 FFTs)
+	double errors = 0;
+	const int nCheck = w->nFFTs < 64 ? w->nFFTs : 64;
+	for (int f = 0; f < nCheck; f++) {
+		double ein = 0, eout = 0;
+		for (int i = 0; i < w->FFT_size; i++) {
+			float2 a = h_in[(size_t) f*w->FFT_size + i], b = h_out[(size_t) f*w->FFT_size + i];
+			ein += (double) a.x*a.x + (double) a.y*a.y;
+			eout += (double) b.x*b.x + (double) b.y*b.y;
+		}
+		if (fabs(eout/(w->FFT_size*ein) - 1.0) > 1e-5) errors += 1;
+	}
+
+	// the only communication: job-level statistics over RCCL
+	float h_stats[2] = {(float) w->kernel_ms, (float) errors};
+	(void) hipMemcpy(d_stats, h_stats, sizeof(h_stats), hipMemcpyHostToDevice);
+	ncclAllReduce(d_stats, d_stats, 1, ncclFloat, ncclMax, w->comm, stream);
+	ncclAllReduce(d_stats + 1, d_stats + 1, 1, ncclFloat, ncclSum, w->comm, stream);
+	(void) hipStreamSynchronize(stream);
+	(void) hipMemcpy(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost);
+	w->job_ms = h_stats[0];
+	w->job_errors = h_stats[1];
+
+	(void) hipFree(d_in); (void) hipFree(d_out); (void) hipFree(d_stats); (void) hipStreamDestroy(stream);
+	free(h_in); free(h_out);
+	w->status = 0;
+	return NULL;
+}
+
+int main(int argc, char *argv[]) {
+	if (argc != 6 && argc != 7) {
+		printf("Argument error!\n 1) FFT length\n 2) number of FFTs per GPU\n 3) the number of kernel executions\n 4) do inverse FFT 1=yes 0=no\n 5) reorder 1=yes 0=no\n 6) [number of GPUs, default all]\n");
+		printf("For example: FFT_multi_gpu.exe 1024 524288 20 0 1\n");
+		return 1;
+	}
+	int FFT_size = (int) strtol(argv[1], NULL, 10), nFFTs = (int) strtol(argv[2], NULL, 10), nRuns = (int) strtol(argv[3], NULL, 10);
+	bool inverse = strtol(argv[4], NULL, 10) == 1, reorder = strtol(argv[5], NULL, 10) == 1;
+	int devCount = 0;
+	if (hipGetDeviceCount(&devCount) != hipSuccess || devCount < 1) { printf("No HIP device.\n"); return 1; }
+	int nGPUs = (argc == 7) ? (int) strtol(argv[6], NULL, 10) : devCount;
+	if (nGPUs < 1 || nGPUs > devCount) nGPUs = devCount;
+
+	ncclComm_t *comms = (ncclComm_t *) malloc(nGPUs*sizeof(ncclComm_t));
+	int *devs = (int *) malloc(nGPUs*sizeof(int));
+	for (int g = 0; g < nGPUs; g++) devs[g] = g;
+	if (ncclCommInitAll(comms, nGPUs, devs) != ncclSuccess) { printf("ncclCommInitAll failed\n"); return 1; }
+
+	worker_t *w = (worker_t *) calloc(nGPUs, sizeof(worker_t));
+	pthread_t *th = (pthread_t *) malloc(nGPUs*sizeof(pthread_t));
+	for (int g = 0; g < nGPUs; g++) {
+		w[g].gpu = g; w[g].nGPUs = nGPUs; w[g].FFT_size = FFT_size; w[g].nFFTs = nFFTs; w[g].nRuns = nRuns;
+		w[g].inverse = inverse; w[g].reorder = reorder; w[g].comm = comms[g];
+		pthread_create(&th[g], NULL, worker, &w[g]);
+	}
+	int failed = 0;
+	for (int g = 0; g < nGPUs; g++) { pthread_join(th[g], NULL); failed += w[g].status; }
+	for (int g = 0; g < nGPUs; g++) ncclCommDestroy(comms[g]);
+	if (failed) { printf("  %d GPU worker(s) failed\n", failed); return 1; }
+
+	const double bytes_per_gpu = 2.0*FFT_size*(double) nFFTs*sizeof(float2);
+	for (int g = 0; g < nGPUs; g++) printf("  GPU %d: SH FFT normal = %0.3f ms (%0.1f GB/s)\n", g, w[g].kernel_ms, bytes_per_gpu/w[g].kernel_ms/1e6);
+	printf("  %d GPU(s), %d FFTs of %d each: job time = %0.3f ms; %0.4g FFT/s; %0.1f GB/s aggregate\n", nGPUs, nFFTs, FFT_size, w[0].job_ms,
+	       (double) nFFTs*nGPUs/(w[0].job_ms*1e-3), nGPUs*bytes_per_gpu/w[0].job_ms/1e6);
+	print_verdict((int) w[0].job_errors);
+	return 0;
+}

@@ -238,6 +238,7 @@ def test_config4_r2c_c2r_roundtrip(sm, oracle_lib):
     ("FFT_CooleyTukey_C2C.exe", ["256", "1000", "1", "0", "0"], 0),
     ("FFT_Stockham_C2C.exe", ["2048", "1500", "2"], 1),
     ("FFT_Stockham_R2C_C2R.exe", ["2048", "1200", "2"], 2),
+    ("FFT_multi_gpu.exe", ["1024", "4100", "3", "0", "1"], 1),
 ])
 def test_harness_programs(sm, prog, args, expect):
     """The harness (g++-compiled host code with the reference's prototypes, CLI and printed lines)
@@ -254,6 +255,8 @@ def test_harness_programs(sm, prog, args, expect):
     if expect == 0:
         assert "There is no verification of the results if FFT are not reordered." in p.stdout
     assert "SH FFT normal" in p.stdout or "smFFT R2C time" in p.stdout
+    if prog == "FFT_multi_gpu.exe":
+        assert "GPU(s), 4100 FFTs of 1024 each: job time" in p.stdout
 
 
 # ------------------------------------------- device functions called from a user kernel (examples/)
