@@ -176,12 +176,15 @@ int smfft_gpu_ct(const void* h_input, void* h_output, int FFT_size, int nFFTs, i
     checkHipErrors(hipMalloc((void**)&d_output, bytes));
 
     double time_FFT_external = 0, time_FFT_multiple = 0;
+    // The reference re-uploads h_input before every one of the 2*nRuns launches (CT:868,884), outside
+    // the timed region.  The kernels never modify d_input, so one upload is equivalent and saves
+    // (2*nRuns - 1) pageable 4 GiB copies at the README batch.
+    checkHipErrors(hipMemcpy(d_input, h_input, bytes, hipMemcpyHostToDevice));
     if (MULTIPLE) {
         if (DEBUG) printf("  Running shared memory FFT (Cooley-Tukey) 100 times per GPU kernel (eliminates device memory)... ");
         smfft_init();
         double total = 0;
         for (int f = 0; f < nRuns; f++) {
-            checkHipErrors(hipMemcpy(d_input, h_input, bytes, hipMemcpyHostToDevice));
             smfft_ct_multiple_benchmark(d_input, d_output, FFT_size, nFFTs, inverse, reorder, &total);
         }
         time_FFT_multiple = total / nRuns;
@@ -194,7 +197,6 @@ int smfft_gpu_ct(const void* h_input, void* h_output, int FFT_size, int nFFTs, i
         smfft_init();
         double total = 0;
         for (int f = 0; f < nRuns; f++) {
-            checkHipErrors(hipMemcpy(d_input, h_input, bytes, hipMemcpyHostToDevice));
             smfft_ct_external_benchmark(d_input, d_output, FFT_size, nFFTs, inverse, reorder, &total);
         }
         time_FFT_external = total / nRuns;
@@ -224,11 +226,11 @@ int smfft_gpu_st(const void* h_input, void* h_output, int FFT_size, int nFFTs, i
     checkHipErrors(hipMalloc((void**)&d_input, bytes));
     checkHipErrors(hipMalloc((void**)&d_output, bytes));
     double time_FFT_external = 0, time_FFT_multiple = 0;
+    checkHipErrors(hipMemcpy(d_input, h_input, bytes, hipMemcpyHostToDevice));   // once (upstream: per run, ST:496,508)
     if (MULTIPLE) {
         smfft_init();
         double total = 0;
         for (int f = 0; f < nRuns; f++) {
-            checkHipErrors(hipMemcpy(d_input, h_input, bytes, hipMemcpyHostToDevice));
             smfft_st_multiple_benchmark(d_input, d_output, FFT_size, nFFTs, &total);
         }
         time_FFT_multiple = total / nRuns;
@@ -238,7 +240,6 @@ int smfft_gpu_st(const void* h_input, void* h_output, int FFT_size, int nFFTs, i
         smfft_init();
         double total = 0;
         for (int f = 0; f < nRuns; f++) {
-            checkHipErrors(hipMemcpy(d_input, h_input, bytes, hipMemcpyHostToDevice));
             smfft_st_external_benchmark(d_input, d_output, FFT_size, nFFTs, &total);
         }
         time_FFT_external = total / nRuns;

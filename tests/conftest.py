@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def built_product():
+    """The product library must exist before anything imports smfft_amd (it has no CPU fallback and
+    refuses to import without libsmfft_amd.so).  hipcc cross-compiles for gfx950 without a GPU."""
+    lib = os.path.join(ROOT, "smfft_amd", "libsmfft_amd.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "smfft_amd", "csrc"), "-j", "8"])
+    return lib
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     """The C restatement (oracle/liboracle.so), built on demand.  Checker only."""

@@ -11,11 +11,8 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
 @pytest.fixture(scope="module")
-def built():
-    lib = os.path.join(ROOT, "smfft_amd", "libsmfft_amd.so")
-    if not os.path.exists(lib):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "smfft_amd", "csrc"), "-j", "8"])
-    return lib
+def built(built_product):
+    return built_product
 
 
 def _declared_c_functions():

@@ -285,3 +285,51 @@ def test_example_convolution_kernel(sm, n, sym):
     want = np.fft.ifft(np.fft.fft(x.astype(np.complex128), axis=-1) * H.astype(np.complex128), axis=-1)
     l2, mx = ref.fft_errors(got, want)
     assert l2 < 1e-6 and mx < 2e-6, (l2, mx)
+
+
+# --------------------------------------------------------------------- API conventions (8(b))
+def test_time_accumulates_and_launch_on_stream(sm, oracle_lib):
+    """`*FFT_time += elapsed` (CT:598,660-662): two calls on one accumulator add up; the launch-only
+    entry runs on the stream it is given and produces the same bytes as the timed call."""
+    import ctypes
+    rng = np.random.default_rng(3)
+    x = (rng.random((40, 1024), dtype=np.float32) + 1j * rng.random((40, 1024), dtype=np.float32)).astype(np.complex64)
+    din, d1, d2 = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes), sm.DeviceBuffer(x.nbytes)
+    t = ctypes.c_double(0.0)
+    assert sm.lib.smfft_ct_external_benchmark(din.ptr, d1.ptr, 1024, 40, 0, 1, ctypes.byref(t)) == 0
+    first = t.value
+    assert first > 0
+    assert sm.lib.smfft_ct_external_benchmark(din.ptr, d1.ptr, 1024, 40, 0, 1, ctypes.byref(t)) == 0
+    assert t.value > first
+    sm.lib.smfft_memset(d2.ptr, 0, x.nbytes)
+    sm.launch("ct", "external", din.ptr, d2.ptr, 1024, 40, False, True, stream=0)
+    sm.lib.smfft_synchronize()
+    assert np.array_equal(d1.to_host(np.uint8, (x.nbytes,)), d2.to_host(np.uint8, (x.nbytes,)))
+    # wrappers: host in, host out (GPU_smFFT_4elements) incl. its N=32 divisibility rule (CT:835-836)
+    out = np.empty_like(x)
+    s_ms, m_ms = ctypes.c_double(0), ctypes.c_double(0)
+    rc = sm.lib.smfft_gpu_ct(x.ctypes.data, out.ctypes.data, 1024, 40, 0, 1, 2, ctypes.byref(s_ms), ctypes.byref(m_ms))
+    assert rc == 0 and s_ms.value > 0
+    ref.assert_close_fp32(out, oa.ct_c2c(oracle_lib, x, 0, 1, "f64"), "GPU_smFFT_4elements")
+    x32 = x.reshape(-1, 32)[:6]
+    assert sm.lib.smfft_gpu_ct(x32.ctypes.data, out.ctypes.data, 32, 6, 0, 1, 1, ctypes.byref(s_ms), ctypes.byref(m_ms)) == 1
+
+
+def test_in_place_and_grid_cap_invariance(sm, oracle_lib):
+    """Results do not depend on the launch geometry (grid cap) and an in-place call is safe
+    (every tile is read completely before it is written)."""
+    rng = np.random.default_rng(5)
+    for n in (64, 1024, 4096):
+        nffts = 9 * (4096 // n) + 2
+        x = (rng.random((nffts, n), dtype=np.float32) + 1j * rng.random((nffts, n), dtype=np.float32)).astype(np.complex64)
+        want = sm.c2c(x, False, True)
+        old = sm.lib.smfft_get_grid_cap()
+        try:
+            for cap in (1, 3, 0):
+                sm.lib.smfft_set_grid_cap(cap)
+                assert np.array_equal(sm.c2c(x, False, True).view(np.uint32), want.view(np.uint32)), (n, cap)
+        finally:
+            sm.lib.smfft_set_grid_cap(old)
+        buf = sm.DeviceBuffer.from_host(x)
+        rc, _ = sm.FFT_external_benchmark(buf.ptr, buf.ptr, n, nffts, False, True)
+        assert rc == 0 and np.array_equal(buf.to_host(np.complex64, x.shape).view(np.uint32), want.view(np.uint32))
