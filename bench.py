@@ -151,6 +151,13 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # device pre-warm (not part of the W warm-up steps of the contract): clocks / power state settle
+    prewarm_s = float(os.environ.get("SMFFT_BENCH_PREWARM_S", "1.0"))
+    t_pw = time.perf_counter()
+    while time.perf_counter() - t_pw < prewarm_s:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)

@@ -43,7 +43,8 @@ int smfft_ct_external_benchmark(const void* d_input, void* d_output, int FFT_siz
 int smfft_ct_multiple_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs,
                                 int inverse, int reorder, double* FFT_time);
 
-/* ---- Stockham C2C family (un-normalised INVERSE transform, ST:76), N = 256 .. 4096 ----------- */
+/* ---- Stockham C2C family (un-normalised INVERSE transform, ST:76), N = 32 .. 4096 ------------
+ * (upstream: 256 .. 4096; the smaller lengths are an extension) */
 /* FFT_external_benchmark / FFT_multiple_benchmark (ST:306-346, :348-384). */
 int smfft_st_external_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, double* FFT_time);
 int smfft_st_multiple_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, double* FFT_time);

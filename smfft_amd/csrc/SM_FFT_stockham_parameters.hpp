@@ -24,6 +24,11 @@ public:
 	static const int fft_threequarters = 3 * ((1 << EXP) / 4);
 };
 
+// FFT_32 ... FFT_128 do not exist upstream (its Stockham kernels start at 256, ST:316-338); the
+// engine here covers them, so the Stockham API accepts N = 32 ... 4096.
+class FFT_32   : public FFT_ConstParamsOf<5>  {};
+class FFT_64   : public FFT_ConstParamsOf<6>  {};
+class FFT_128  : public FFT_ConstParamsOf<7>  {};
 class FFT_256  : public FFT_ConstParamsOf<8>  {};
 class FFT_512  : public FFT_ConstParamsOf<9>  {};
 class FFT_1024 : public FFT_ConstParamsOf<10> {};

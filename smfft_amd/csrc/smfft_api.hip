@@ -57,6 +57,9 @@ int dispatch_ct(const float2* in, float2* out, int N, int count, int inverse, in
 }
 int dispatch_st(const float2* in, float2* out, int N, int count, int path, hipStream_t st) {
     switch (N) {
+        case 32:   return launch_st<32>(in, out, count, path, g_grid_cap, g_nreuses, st);
+        case 64:   return launch_st<64>(in, out, count, path, g_grid_cap, g_nreuses, st);
+        case 128:  return launch_st<128>(in, out, count, path, g_grid_cap, g_nreuses, st);
         case 256:  return launch_st<256>(in, out, count, path, g_grid_cap, g_nreuses, st);
         case 512:  return launch_st<512>(in, out, count, path, g_grid_cap, g_nreuses, st);
         case 1024: return launch_st<1024>(in, out, count, path, g_grid_cap, g_nreuses, st);

@@ -41,7 +41,6 @@ int launch_stream_copy(const float2* d_input, float2* d_output, long n_float2, i
 }
 #endif
 
-#if SMFFT_N >= 256
 #define ST_CLASS SMFFT_PASTE3(FFT_, SMFFT_N, )
 template <>
 int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int path, int grid_cap, int nreuses, hipStream_t stream) {
@@ -51,7 +50,6 @@ int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int p
     else           FFT_GPU_multiple<ST_CLASS><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
     return (int)hipGetLastError();
 }
-#endif
 
 #if SMFFT_N >= 256 && SMFFT_N <= 2048
 template <>

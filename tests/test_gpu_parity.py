@@ -13,7 +13,7 @@ from tests import oracle_api as oa
 pytestmark = pytest.mark.gpu
 
 C2C_SIZES = [32, 64, 128, 256, 512, 1024, 2048, 4096]
-ST_SIZES = [256, 512, 1024, 2048, 4096]
+ST_SIZES = [32, 64, 128, 256, 512, 1024, 2048, 4096]   # upstream: 256..4096; 32..128 are an extension
 R2C_SIZES = [512, 1024, 2048, 4096]
 
 
@@ -333,3 +333,24 @@ def test_in_place_and_grid_cap_invariance(sm, oracle_lib):
         buf = sm.DeviceBuffer.from_host(x)
         rc, _ = sm.FFT_external_benchmark(buf.ptr, buf.ptr, n, nffts, False, True)
         assert rc == 0 and np.array_equal(buf.to_host(np.complex64, x.shape).view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("n", R2C_SIZES)
+def test_c2r_multiple_extension(sm, oracle_lib, n):
+    """Upstream has no C2R `multiple` kernel (RC:435-467 is forward only); here the launch-only
+    entry runs it.  One application = the external C2R."""
+    nffts = 100 * (4096 // (n // 2)) + 100
+    rng = np.random.default_rng(n + 1)
+    xp = ((rng.random((nffts, n // 2), dtype=np.float32) - 0.5) + 1j * (rng.random((nffts, n // 2), dtype=np.float32) - 0.5)).astype(np.complex64)
+    din, dout = sm.DeviceBuffer.from_host(xp), sm.DeviceBuffer(xp.nbytes)
+    sm.lib.smfft_memset(dout.ptr, 0xFF, xp.nbytes)
+    sm.lib.smfft_set_nreuses(1)
+    try:
+        sm.launch("rc", "multiple", din.ptr, dout.ptr, n, nffts, inverse=True)
+        sm.lib.smfft_synchronize()
+    finally:
+        sm.lib.smfft_set_nreuses(0)
+    slots = nffts // 100
+    got = dout.to_host(np.float32, (nffts, n))
+    ref.assert_close_fp32(got[:slots], oa.c2r(oracle_lib, xp[:slots], "f64"), f"C2R multiple N={n}")
+    assert (got[slots:].view(np.uint32) == 0xFFFFFFFF).all()

@@ -34,7 +34,7 @@ def test_ct_zero_mean_golden(oracle_lib, golden, n):
     assert l2 < 1e-13 and mx < 1e-13
 
 
-@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("n", [32, 64, 128, 256, 512, 1024, 2048, 4096])
 @pytest.mark.parametrize("inv", [0, 1])
 def test_stockham_matches_golden(oracle_lib, golden, n, inv):
     x = golden[f"c2c_in_u01_{n}"]
