@@ -65,7 +65,8 @@ def cpu_baseline(n, sample_ffts, threads):
         if best_all < 1e29:
             res = {"value": sample_ffts / best_all, "unit": "FFT/s", "cores": best_thr, "kind": "port",
                    "impl": fb.fftw_baseline_backend().decode() + " fftwf_plan_many_dft (FFTW_ESTIMATE) per batch slice, out of place, slices on pthreads; thread counts tried " + str(cands),
-                   "sample": f"N={n} C2C forward, {sample_ffts} FFTs ({x.nbytes >> 20} MiB in), best of 5 rounds"}
+                   "sample": f"N={n} C2C forward, {sample_ffts} FFTs ({x.nbytes >> 20} MiB in), best of 5 rounds",
+                   "host_cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
     except OSError:
         pass
     if res is None:

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <time.h>
 
@@ -88,6 +89,12 @@ typedef struct { void* plan; pthread_barrier_t* bar; int reps; } slice_t;
 
 static void* slice_main(void* arg) {
     slice_t* s = (slice_t*)arg;
+    /* a caller whose main thread was pinned (OpenMP / torch affinity settings) would hand the same
+     * one-CPU mask to every worker: ask for every CPU, the kernel intersects with the cpuset */
+    cpu_set_t all;
+    CPU_ZERO(&all);
+    for (int c = 0; c < CPU_SETSIZE; ++c) CPU_SET(c, &all);
+    pthread_setaffinity_np(pthread_self(), sizeof all, &all);
     for (int r = 0; r < s->reps; ++r) {
         pthread_barrier_wait(s->bar);
         p_exec(s->plan);
