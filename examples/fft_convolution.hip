@@ -41,6 +41,50 @@ __global__ void __launch_bounds__(256) convolve_kernel(const float2* __restrict_
     }
 }
 
+// The same convolution on the register-level interface of the engine (smfft::Engine): the spectrum
+// never goes back to LDS in natural order -- thread u of an FFT holds X[u + T*q] after transform(),
+// multiplies it by H[u + T*q] in registers and feeds the inverse transform directly; global memory is
+// read and written straight from registers.  Per series: 2 LDS exchanges instead of 2 exchanges + 4
+// natural-order round trips.
+template <int N>
+__global__ void __launch_bounds__(256) convolve_kernel_registers(const float2* __restrict__ x, const float2* __restrict__ H, float2* __restrict__ y, int nSeries) {
+    using G = smfft::Geometry<N>;
+    __shared__ float2 s[4352];
+    smfft::Engine<N, 0, 1> fwd;
+    smfft::Engine<N, 1, 1> inv;
+    fwd.init(threadIdx.x);
+    inv.init(threadIdx.x);
+    float2* sf = s + fwd.fft * G::SF;
+    float2 h[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) h[q] = H[fwd.u + G::T * q];
+    const int ntiles = (nSeries + G::kFftsPerBlock - 1) / G::kFftsPerBlock;
+    const float scale = 1.0f / N;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long f = (long)tile * G::kFftsPerBlock + fwd.fft;
+        const bool active = f < nSeries;
+        float2 r[16];
+        fwd.load_global(r, x + (active ? f : 0) * N);
+        if (G::kMultiWave) __syncthreads();
+        fwd.transform(r, sf);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) r[q] = smfft::cmul(r[q], h[q]);
+        smfft::fft_sync<G::kMultiWave>();          // the forward transform's last LDS reads are done
+        inv.transform(r, sf);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) r[q] = make_float2(r[q].x * scale, r[q].y * scale);
+        inv.store_global(r, y + f * N, active);
+    }
+}
+
+extern "C" int smfft_example_convolve_1024_registers(const void* d_x, const void* d_H, void* d_y, int nSeries, void* stream) {
+    if (nSeries <= 0) return 0;
+    int grid = (nSeries + 3) / 4;
+    if (grid > 12288) grid = 12288;
+    convolve_kernel_registers<1024><<<grid, 256, 0, (hipStream_t)stream>>>((const float2*)d_x, (const float2*)d_H, (float2*)d_y, nSeries);
+    return (int)hipGetLastError();
+}
+
 extern "C" int smfft_example_convolve_1024(const void* d_x, const void* d_H, void* d_y, int nSeries, void* stream) {
     if (nSeries <= 0) return 0;
     const int grid = (nSeries + FFT_1024_forward::fft_per_block - 1) / FFT_1024_forward::fft_per_block;
