@@ -126,7 +126,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                dist.barrier()          # first collective: RCCL over xGMI is really up
+            except Exception as e:      # the timings can still be reduced on the CPU
+                print(f"[bench] RCCL unavailable ({type(e).__name__}: {e}); reducing timings over gloo", file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo"
+                dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend=backend)
 
@@ -234,6 +242,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "copy_ceiling": alg_bytes / (copy_ms * 1e-3) / 1e9, "frac_of_copy": copy_ms / kernel_ms_max},
             "multiple_path": mult,
+            "comm_backend": (backend if world > 1 else None),
             "spot_check_relL2": err,
         }
         if world == 1 and not args.no_cpu_baseline:
