@@ -97,6 +97,7 @@ void* smfft_malloc(unsigned long long bytes);
 int smfft_free(void* d_ptr);
 int smfft_memcpy_h2d(void* d_dst, const void* h_src, unsigned long long bytes);
 int smfft_memcpy_d2h(void* h_dst, const void* d_src, unsigned long long bytes);
+int smfft_memcpy_d2d(void* d_dst, const void* d_src, unsigned long long bytes);
 int smfft_memset(void* d_ptr, int value, unsigned long long bytes);
 int smfft_synchronize(void);
 

@@ -50,6 +50,7 @@ _SIGS = {
     "smfft_free": (_i, [_vp]),
     "smfft_memcpy_h2d": (_i, [_vp, _vp, _ull]),
     "smfft_memcpy_d2h": (_i, [_vp, _vp, _ull]),
+    "smfft_memcpy_d2d": (_i, [_vp, _vp, _ull]),
     "smfft_memset": (_i, [_vp, _i, _ull]),
     "smfft_synchronize": (_i, []),
 }

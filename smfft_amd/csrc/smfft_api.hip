@@ -334,6 +334,7 @@ void* smfft_malloc(unsigned long long bytes) { void* p = nullptr; return hipMall
 int smfft_free(void* d_ptr) { return (int)hipFree(d_ptr); }
 int smfft_memcpy_h2d(void* d_dst, const void* h_src, unsigned long long bytes) { return (int)hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice); }
 int smfft_memcpy_d2h(void* h_dst, const void* d_src, unsigned long long bytes) { return (int)hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost); }
+int smfft_memcpy_d2d(void* d_dst, const void* d_src, unsigned long long bytes) { return (int)hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice); }
 int smfft_memset(void* d_ptr, int value, unsigned long long bytes) { return (int)hipMemset(d_ptr, value, bytes); }
 int smfft_synchronize(void) { return (int)hipDeviceSynchronize(); }
 

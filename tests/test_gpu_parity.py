@@ -355,3 +355,36 @@ def test_c2r_multiple_extension(sm, oracle_lib, n):
     got = dout.to_host(np.float32, (nffts, n))
     ref.assert_close_fp32(got[:slots], oa.c2r(oracle_lib, xp[:slots], "f64"), f"C2R multiple N={n}")
     assert (got[slots:].view(np.uint32) == 0xFFFFFFFF).all()
+
+
+def test_beyond_32bit_element_index(sm, oracle_lib):
+    """More than 2^31 float2 elements in one call (N=1024, 2^21 + 5 FFTs, 16 GiB in + 16 GiB out):
+    the reference indexes elements with a 32-bit int (CT:538, max 2^29 at its README batch); the
+    kernels here use 64-bit offsets, so a batch sized for 288 GB of HBM works.  The tail FFTs, which
+    sit beyond element 2^31, are checked against the oracle."""
+    n, nffts = 1024, (1 << 21) + 5
+    nbytes = n * nffts * 8
+    try:
+        a, b = sm.DeviceBuffer(nbytes), sm.DeviceBuffer(nbytes)
+    except MemoryError:
+        pytest.skip("not enough device memory for the 2 x 16 GiB test")
+    rng = np.random.default_rng(31)
+    chunk = (rng.random((4096, n), dtype=np.float32) + 1j * rng.random((4096, n), dtype=np.float32)).astype(np.complex64)
+    sm.lib.smfft_memcpy_h2d(a.ptr, chunk.ctypes.data, chunk.nbytes)
+    filled = chunk.nbytes
+    while filled < nbytes:                       # doubling device-to-device fill
+        step = min(filled, nbytes - filled)
+        sm.lib.smfft_memcpy_d2d(a.ptr + filled, a.ptr, step)
+        filled += step
+    tail = (rng.random((5, n), dtype=np.float32) + 1j * rng.random((5, n), dtype=np.float32)).astype(np.complex64)
+    sm.lib.smfft_memcpy_h2d(a.ptr + (nffts - 5) * n * 8, tail.ctypes.data, tail.nbytes)
+    sm.lib.smfft_memset(b.ptr + (nffts - 8) * n * 8, 0xFF, 8 * n * 8)
+    rc, ms = sm.FFT_external_benchmark(a.ptr, b.ptr, n, nffts, False, True)
+    assert rc == 0
+    got = np.empty((5, n), np.complex64)
+    sm.lib.smfft_memcpy_d2h(got.ctypes.data, b.ptr + (nffts - 5) * n * 8, got.nbytes)
+    ref.assert_close_fp32(got, oa.ct_c2c(oracle_lib, tail, 0, 1, "f64"), "FFTs beyond element 2^31")
+    got0 = np.empty((4, n), np.complex64)
+    sm.lib.smfft_memcpy_d2h(got0.ctypes.data, b.ptr + ((1 << 21) - 4096) * n * 8, got0.nbytes)
+    ref.assert_close_fp32(got0, oa.ct_c2c(oracle_lib, chunk[:4], 0, 1, "f64"), "FFTs just below element 2^31")
+    print(f"2^21+5 FFTs of 1024: {ms:.3f} ms = {2 * nbytes / ms / 1e6:.0f} GB/s")
