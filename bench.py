@@ -153,42 +153,40 @@ def main():
     # CT:850-853).  Measured (tools/alloc_probe.py): writing into a 4 GiB block of torch's caching
     # allocator is 6-7 % slower than into a hipMalloc'ed one (1.53 vs 1.43 ms per launch).
     nbytes = nffts * n * 8
-    # Placement probe.  Where the driver puts a 4 GiB buffer physically changes the streaming rate
-    # by 6-8 % on this part (tools/alloc_probe.py: the same kernel writes one buffer at 6.03 TB/s
-    # and another at 5.56 TB/s, whichever allocator made them; mostly the OUTPUT side).  288 GB of
-    # HBM make it free to allocate a few candidates, time 8 launches into each and keep the best.
-    n_cand = max(2, int(os.environ.get("SMFFT_BENCH_CANDIDATES", "5")))
-    cands = [sm.DeviceBuffer(nbytes) for _ in range(n_cand)]
-    sm.lib.smfft_memcpy_d2d(cands[0].ptr, t_in.data_ptr(), nbytes)
+    # Buffer placement (profiles/r01_placement_map.txt): on MI355X a kernel that
+    # reads one buffer and writes another streams 6-8 % faster when the two addresses differ in bit 35
+    # (32 GiB interleave) than when they sit on the same side.  smfft_malloc_pair() -- the allocator the
+    # library's own L3 wrappers use -- carves both out of one arena, 32 GiB apart.  For transparency the
+    # same-side alternative (output 4 GiB after the input, inside the arena's spacer) is timed as well.
+    pa, pb = ctypes.c_void_p(), ctypes.c_void_p()
+    if sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(pa), ctypes.byref(pb)) != 0:
+        raise SystemExit("smfft_malloc_pair failed")
+
+    class _Raw:
+        def __init__(self, ptr):
+            self.ptr = ptr
+    b_in, b_out = _Raw(pa.value), _Raw(pb.value)
+    sm.lib.smfft_memcpy_d2d(b_in.ptr, t_in.data_ptr(), nbytes)
     xs = torch.view_as_complex(t_in[:4].contiguous()).to(torch.complex128)   # kept for the spot check
     del t_in
     torch.cuda.empty_cache()
 
-    def _probe(i_buf, o_buf):
+    def _probe(i_ptr, o_ptr):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s0 = torch.cuda.current_stream(dev)
         for _ in range(2):
-            sm.launch("ct", "external", i_buf.ptr, o_buf.ptr, n, nffts, stream=s0.cuda_stream)
+            sm.launch("ct", "external", i_ptr, o_ptr, n, nffts, stream=s0.cuda_stream)
         e0.record(s0)
         for _ in range(8):
-            sm.launch("ct", "external", i_buf.ptr, o_buf.ptr, n, nffts, stream=s0.cuda_stream)
+            sm.launch("ct", "external", i_ptr, o_ptr, n, nffts, stream=s0.cuda_stream)
         e1.record(s0)
         torch.cuda.synchronize(dev)
         return e0.elapsed_time(e1) / 8
 
-    out_ms = {k: _probe(cands[0], cands[k]) for k in range(1, n_cand)}
-    k_out = min(out_ms, key=out_ms.get)
-    in_ms = {0: out_ms[k_out]}
-    for k in range(1, n_cand):
-        if k != k_out:
-            sm.lib.smfft_memcpy_d2d(cands[k].ptr, cands[0].ptr, nbytes)
-            in_ms[k] = _probe(cands[k], cands[k_out])
-    k_in = min(in_ms, key=in_ms.get)
-    b_in, b_out = cands[k_in], cands[k_out]
-    placement = {"candidates": n_cand, "out_ms": [round(out_ms[k], 4) for k in sorted(out_ms)], "in_ms": [round(in_ms[k], 4) for k in sorted(in_ms)]}
-    for k, c in enumerate(cands):
-        if k not in (k_in, k_out):
-            c.free()
+    off_gib = (b_out.ptr - b_in.ptr) / float(1 << 30)
+    in_arena = 0 < off_gib <= 64 and float(off_gib).is_integer()
+    placement = {"output_offset_GiB": off_gib if in_arena else None, "paired_ms": round(_probe(b_in.ptr, b_out.ptr), 4),
+                 "adjacent_ms": round(_probe(b_in.ptr, b_in.ptr + nbytes), 4) if in_arena and 2 * nbytes <= (b_out.ptr - b_in.ptr) else None}
 
     class _Ptr:                      # tiny adaptor so the rest of the script reads like tensor code
         def __init__(self, buf):

@@ -47,6 +47,8 @@ _SIGS = {
     "smfft_set_device": (_i, [_i]),
     "smfft_version": (ctypes.c_char_p, []),
     "smfft_malloc": (_vp, [_ull]),
+    "smfft_malloc_pair": (_i, [_ull, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    "smfft_free_pair": (_i, [_vp]),
     "smfft_free": (_i, [_vp]),
     "smfft_memcpy_h2d": (_i, [_vp, _vp, _ull]),
     "smfft_memcpy_d2h": (_i, [_vp, _vp, _ull]),

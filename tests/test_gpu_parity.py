@@ -388,3 +388,20 @@ def test_beyond_32bit_element_index(sm, oracle_lib):
     sm.lib.smfft_memcpy_d2h(got0.ctypes.data, b.ptr + ((1 << 21) - 4096) * n * 8, got0.nbytes)
     ref.assert_close_fp32(got0, oa.ct_c2c(oracle_lib, chunk[:4], 0, 1, "f64"), "FFTs just below element 2^31")
     print(f"2^21+5 FFTs of 1024: {ms:.3f} ms = {2 * nbytes / ms / 1e6:.0f} GB/s")
+
+
+def test_malloc_pair(sm):
+    """smfft_malloc_pair: two usable buffers; 32 GiB apart in one arena when the device has room."""
+    import ctypes
+    a, b = ctypes.c_void_p(), ctypes.c_void_p()
+    nbytes = 256 << 20
+    assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
+    assert a.value and b.value and a.value != b.value
+    assert abs(b.value - a.value) >= nbytes
+    x = (np.random.default_rng(0).random((64, 1024, 2), dtype=np.float32)).view(np.complex64).reshape(64, 1024)
+    sm.lib.smfft_memcpy_h2d(a.value, x.ctypes.data, x.nbytes)
+    rc, _ = sm.FFT_external_benchmark(a.value, b.value, 1024, 64)
+    got = np.empty_like(x)
+    sm.lib.smfft_memcpy_d2h(got.ctypes.data, b.value, x.nbytes)
+    ref.assert_close_fp32(got, ref.ct_c2c(x, False, True), "paired buffers")
+    assert sm.lib.smfft_free_pair(a.value) == 0
