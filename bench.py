@@ -184,9 +184,10 @@ def main():
         return e0.elapsed_time(e1) / 8
 
     off_gib = (b_out.ptr - b_in.ptr) / float(1 << 30)
-    in_arena = 0 < off_gib <= 64 and float(off_gib).is_integer()
-    placement = {"output_offset_GiB": off_gib if in_arena else None, "paired_ms": round(_probe(b_in.ptr, b_out.ptr), 4),
-                 "adjacent_ms": round(_probe(b_in.ptr, b_in.ptr + nbytes), 4) if in_arena and 2 * nbytes <= (b_out.ptr - b_in.ptr) else None}
+    in_arena = abs(off_gib) <= 96 and float(off_gib).is_integer()
+    adjacent = b_in.ptr + nbytes if off_gib >= 2 * nbytes / float(1 << 30) else (b_in.ptr - nbytes if off_gib <= -2 * nbytes / float(1 << 30) else None)
+    placement = {"output_minus_input_GiB": off_gib if in_arena else None, "paired_ms": round(_probe(b_in.ptr, b_out.ptr), 4),
+                 "adjacent_ms": round(_probe(b_in.ptr, adjacent), 4) if in_arena and adjacent is not None and off_gib > 0 else None}
 
     class _Ptr:                      # tiny adaptor so the rest of the script reads like tensor code
         def __init__(self, buf):

@@ -100,54 +100,58 @@ int timed(F&& launch, double* FFT_time) {
 // 1.44 ms for the 4 GiB + 4 GiB N=1024 batch) than streams on opposite sides.  With 288 GB of HBM the
 // library can afford to carve both buffers out of ONE arena, exactly 32 GiB apart, so that byte x of
 // the input and byte x of the output always sit on opposite sides whatever the arena's base is.
-constexpr unsigned long long kSideStride = 1ull << 35;
 struct PairRec { void* a; void* b; void* arena; };
 PairRec g_pairs[64];
 
-// mean ms of a few stream-copy launches (the external kernels' access shape) of up to 1 GiB
+// mean ms of a few stream-copy launches (the external kernels' access shape) over the whole buffers:
+// a window shorter than the buffers can sit entirely on one side of a region boundary they cross
 float probe_copy_ms(const void* in, void* out, size_t bytes) {
-    const long n = (long)((bytes < (1ull << 30) ? bytes : (1ull << 30)) / 8 / 4096 * 4096);
+    const long n = (long)(bytes / 8 / 4096 * 4096);
     if (n <= 0) return 0.f;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 0.f;
-    for (int i = 0; i < 2; ++i) smfft::launch_stream_copy((const float2*)in, (float2*)out, n, 4096, 0);
+    for (int i = 0; i < 2; ++i) smfft::launch_stream_copy((const float2*)in, (float2*)out, n, 12288, 0);
     (void)hipEventRecord(e0, 0);
-    for (int i = 0; i < 6; ++i) smfft::launch_stream_copy((const float2*)in, (float2*)out, n, 4096, 0);
+    for (int i = 0; i < 5; ++i) smfft::launch_stream_copy((const float2*)in, (float2*)out, n, 12288, 0);
     (void)hipEventRecord(e1, 0);
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    return ms / 6;
+    return ms / 5;
 }
 
-// The virtual -> physical map of a big allocation is only piecewise linear, so the 32 GiB rule is
-// verified instead of trusted: the output is tried at several offsets inside the arena with a short
-// stream copy (about 3 ms per candidate) and the fastest placement wins.
+// Which offsets land on "opposite sides" differs from allocation to allocation (the fast region
+// started 24, 32 or 64 GiB after the input in different runs of tools/placement_map.py), so nothing
+// is assumed: (input, output) windows on an 8 GiB lattice inside one arena are each timed with a
+// short stream copy (about 3 ms per candidate pair) and the fastest pair wins.
 int alloc_pair(size_t bytes, void** d_a, void** d_b) {
     size_t free_mem = 0, total_mem = 0;
     *d_a = *d_b = nullptr;
     int slot = -1;
     for (int i = 0; i < 64; ++i) if (!g_pairs[i].a) { slot = i; break; }
     const bool want_arena = getenv("SMFFT_NO_PAIR_PLACEMENT") == nullptr;
-    if (want_arena && slot >= 0 && bytes > (64ull << 20) && bytes <= (16ull << 30) && hipMemGetInfo(&free_mem, &total_mem) == hipSuccess) {
-        // 64 GiB of spacer when the device is mostly empty (more candidates), else 32 GiB
-        const unsigned long long span = (free_mem > 3 * kSideStride) ? 2 * kSideStride : kSideStride;
+    if (want_arena && slot >= 0 && bytes >= (1ull << 30) && bytes <= (16ull << 30) && hipMemGetInfo(&free_mem, &total_mem) == hipSuccess) {
+        // up to 96 GiB of arena when the device is mostly empty (more candidate pairs), else 32 or 64
+        const unsigned long long g = 1ull << 30;
+        const unsigned long long span = (free_mem > 160 * g) ? 96 * g : (free_mem > 100 * g) ? 64 * g : 32 * g;
         void* arena = nullptr;
-        if (free_mem > span + bytes + (4ull << 30) && hipMalloc(&arena, span + bytes) == hipSuccess) {
-            const unsigned long long g = 1ull << 30;
-            const unsigned long long offs[] = {32 * g, 64 * g, 16 * g, 48 * g, 8 * g, 24 * g, 40 * g, 56 * g};
-            unsigned long long best_off = 0;
+        if (free_mem > span + bytes + 4 * g && hipMalloc(&arena, span + bytes) == hipSuccess) {
+            // candidate (input offset, output offset) pairs on an 8 GiB lattice; input at 0, 32 or 64 GiB
+            unsigned long long best_in = 0, best_out = 0;
             float best_ms = 1e30f;
-            for (unsigned long long off : offs) {
-                if (off < bytes || off > span) continue;
-                const float ms = probe_copy_ms(arena, (char*)arena + off, bytes);
-                if (ms > 0.f && ms < best_ms) { best_ms = ms; best_off = off; }
+            for (unsigned long long in_off = 0; in_off <= span; in_off += 32 * g) {
+                for (unsigned long long out_off = 0; out_off <= span; out_off += 8 * g) {
+                    const unsigned long long lo = in_off < out_off ? in_off : out_off, hi = in_off < out_off ? out_off : in_off;
+                    if (hi - lo < bytes) continue;                       // overlapping windows
+                    const float ms = probe_copy_ms((char*)arena + in_off, (char*)arena + out_off, bytes);
+                    if (ms > 0.f && ms < best_ms) { best_ms = ms; best_in = in_off; best_out = out_off; }
+                }
             }
-            if (best_off == 0) best_off = (kSideStride >= bytes && kSideStride <= span) ? kSideStride : span;
-            *d_a = arena;
-            *d_b = (char*)arena + best_off;
+            if (best_ms > 1e29f) { best_in = 0; best_out = span; }
+            *d_a = (char*)arena + best_in;
+            *d_b = (char*)arena + best_out;
             g_pairs[slot] = {*d_a, *d_b, arena};
             return 0;
         }

@@ -394,7 +394,7 @@ def test_malloc_pair(sm):
     """smfft_malloc_pair: two usable buffers; 32 GiB apart in one arena when the device has room."""
     import ctypes
     a, b = ctypes.c_void_p(), ctypes.c_void_p()
-    nbytes = 256 << 20
+    nbytes = 1 << 30                       # >= 1 GiB: the placement search is active
     assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
     assert a.value and b.value and a.value != b.value
     assert abs(b.value - a.value) >= nbytes
