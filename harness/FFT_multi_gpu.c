@@ -15,6 +15,9 @@
 
 int FFT_external_benchmark(float2 *d_input, float2 *d_output, int FFT_size, int nFFTs, bool inverse, bool reorder, double *FFT_time);
 void FFT_init();
+// the library's placement-aware allocator (include/smfft.h): input and output in different memory regions
+extern "C" int smfft_malloc_pair(unsigned long long bytes, void **d_read, void **d_written);
+extern "C" int smfft_free_pair(void *d_read);
 
 typedef struct {
 	int gpu, nGPUs, FFT_size, nFFTs, nRuns;
@@ -35,7 +38,7 @@ static void *worker(void *arg) {
 	float2 *d_in = NULL, *d_out = NULL;
 	float *d_stats = NULL;
 	hipStream_t stream;
-	if (!h_in || !h_out || hipMalloc((void **) &d_in, bytes) != hipSuccess || hipMalloc((void **) &d_out, bytes) != hipSuccess
+	if (!h_in || !h_out || smfft_malloc_pair(bytes, (void **) &d_in, (void **) &d_out) != 0
 	    || hipMalloc((void **) &d_stats, 2*sizeof(float)) != hipSuccess || hipStreamCreate(&stream) != hipSuccess) {
 		printf("GPU %d: allocation failed\n", w->gpu);
 		return NULL;
@@ -77,7 +80,7 @@ static void *worker(void *arg) {
 	w->job_ms = h_stats[0];
 	w->job_errors = h_stats[1];
 
-	(void) hipFree(d_in); (void) hipFree(d_out); (void) hipFree(d_stats); (void) hipStreamDestroy(stream);
+	(void) smfft_free_pair(d_in); (void) hipFree(d_stats); (void) hipStreamDestroy(stream);
 	free(h_in); free(h_out);
 	w->status = 0;
 	return NULL;
