@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "../../include/smfft.h"
 #include "../../include/smfft_reference_api.h"
@@ -102,6 +103,7 @@ int timed(F&& launch, double* FFT_time) {
 // the input and byte x of the output always sit on opposite sides whatever the arena's base is.
 struct PairRec { void* a; void* b; void* arena; };
 PairRec g_pairs[64];
+std::mutex g_pairs_mutex;   // the table is shared by the per-GPU host threads of a multi-GPU driver
 
 // mean ms of a few stream-copy launches (the external kernels' access shape) over the whole buffers:
 // a window shorter than the buffers can sit entirely on one side of a region boundary they cross
@@ -130,7 +132,10 @@ int alloc_pair(size_t bytes, void** d_a, void** d_b) {
     size_t free_mem = 0, total_mem = 0;
     *d_a = *d_b = nullptr;
     int slot = -1;
-    for (int i = 0; i < 64; ++i) if (!g_pairs[i].a) { slot = i; break; }
+    {
+        std::lock_guard<std::mutex> lock(g_pairs_mutex);
+        for (int i = 0; i < 64; ++i) if (!g_pairs[i].a) { slot = i; g_pairs[i].a = (void*)&g_pairs[i]; break; }   // reserved
+    }
     const bool want_arena = getenv("SMFFT_NO_PAIR_PLACEMENT") == nullptr;
     if (want_arena && slot >= 0 && bytes >= (1ull << 30) && bytes <= (16ull << 30) && hipMemGetInfo(&free_mem, &total_mem) == hipSuccess) {
         // up to 96 GiB of arena when the device is mostly empty (more candidate pairs), else 32 or 64
@@ -157,23 +162,27 @@ int alloc_pair(size_t bytes, void** d_a, void** d_b) {
         }
         (void)hipGetLastError();
     }
-    if (hipMalloc(d_a, bytes) != hipSuccess) return 1;
-    if (hipMalloc(d_b, bytes) != hipSuccess) { (void)hipFree(*d_a); *d_a = nullptr; return 1; }
+    if (hipMalloc(d_a, bytes) != hipSuccess) { if (slot >= 0) g_pairs[slot] = {nullptr, nullptr, nullptr}; return 1; }
+    if (hipMalloc(d_b, bytes) != hipSuccess) { (void)hipFree(*d_a); *d_a = nullptr; if (slot >= 0) g_pairs[slot] = {nullptr, nullptr, nullptr}; return 1; }
     if (slot >= 0) g_pairs[slot] = {*d_a, *d_b, nullptr};
     return 0;
 }
 
 int free_pair(void* d_a) {
-    for (int i = 0; i < 64; ++i) {
-        if (g_pairs[i].a == d_a && d_a) {
-            int rc = 0;
-            if (g_pairs[i].arena) rc = (int)hipFree(g_pairs[i].arena);
-            else { rc = (int)hipFree(g_pairs[i].a); rc |= (int)hipFree(g_pairs[i].b); }
-            g_pairs[i] = {nullptr, nullptr, nullptr};
-            return rc;
+    PairRec rec = {nullptr, nullptr, nullptr};
+    {
+        std::lock_guard<std::mutex> lock(g_pairs_mutex);
+        for (int i = 0; i < 64; ++i) {
+            if (g_pairs[i].a == d_a && d_a) {
+                rec = g_pairs[i];
+                g_pairs[i] = {nullptr, nullptr, nullptr};
+                break;
+            }
         }
     }
-    return (int)hipFree(d_a);
+    if (!rec.a) return (int)hipFree(d_a);
+    if (rec.arena) return (int)hipFree(rec.arena);
+    return (int)hipFree(rec.a) | (int)hipFree(rec.b);
 }
 
 int select_device() {
