@@ -405,3 +405,49 @@ def test_malloc_pair(sm):
     sm.lib.smfft_memcpy_d2h(got.ctypes.data, b.value, x.nbytes)
     ref.assert_close_fp32(got, ref.ct_c2c(x, False, True), "paired buffers")
     assert sm.lib.smfft_free_pair(a.value) == 0
+
+
+@pytest.mark.parametrize("n", [32, 1024, 4096])
+def test_config3_full_batch_multiple_path(sm, oracle_lib, n):
+    """Config 3 at the README batch (2^29/N FFTs, 4 GiB buffers), in-LDS `multiple` path:
+      * reorder, 4 applications: F^4 = N^2 * identity (size-independent property), every slot;
+      * no-reorder, 2 applications: sampled slots against the oracle;
+      * the full 100-application benchmark call runs and only reports a time (values overflow, as upstream)."""
+    total = 1 << 29
+    nffts = total // n
+    slots = _slots(n, nffts)
+    rng = np.random.default_rng(n)
+    rows = 4096 * 16 // n * 16            # 8 MiB of distinct data, tiled over the touched part of the buffer
+    chunk = ((rng.random((rows, n), dtype=np.float32) - 0.5) + 1j * (rng.random((rows, n), dtype=np.float32) - 0.5)).astype(np.complex64)
+    a, b = sm.DeviceBuffer(total * 8), sm.DeviceBuffer(total * 8)
+    touched = (slots + rows - 1) // rows * rows
+    sm.lib.smfft_memcpy_h2d(a.ptr, chunk.ctypes.data, chunk.nbytes)
+    filled = chunk.nbytes
+    while filled < touched * n * 8:
+        step = min(filled, touched * n * 8 - filled)
+        sm.lib.smfft_memcpy_d2d(a.ptr + filled, a.ptr, step)
+        filled += step
+    try:
+        sm.lib.smfft_set_nreuses(4)
+        rc, ms = sm.FFT_multiple_benchmark(a.ptr, b.ptr, n, nffts, False, True)
+        assert rc == 0
+        for first in (0, (slots // rows // 2) * rows, slots - rows if slots >= rows else 0):
+            cnt = min(rows, slots - first)
+            got = np.empty((cnt, n), np.complex64)
+            sm.lib.smfft_memcpy_d2h(got.ctypes.data, b.ptr + first * n * 8, got.nbytes)
+            src = chunk[(first + np.arange(cnt)) % rows]
+            l2, mx = ref.fft_errors(got / np.float32(n) ** 2, src.astype(np.complex128))
+            assert l2 < 1e-6 and mx < 2e-6, (n, first, l2, mx)
+        sm.lib.smfft_set_nreuses(2)
+        rc, ms = sm.FFT_multiple_benchmark(a.ptr, b.ptr, n, nffts, False, False)
+        got = np.empty((8, n), np.complex64)
+        sm.lib.smfft_memcpy_d2h(got.ctypes.data, b.ptr + (slots - 8) * n * 8, got.nbytes)
+        src = chunk[(slots - 8 + np.arange(8)) % rows]
+        want = oa.ct_c2c(oracle_lib, oa.ct_c2c(oracle_lib, src, 0, 0, "f64"), 0, 0, "f64")
+        ref.assert_close_fp32(got, want, f"config 3 no-reorder x2, N={n}")
+    finally:
+        sm.lib.smfft_set_nreuses(0)
+    rc, ms = sm.FFT_multiple_benchmark(a.ptr, b.ptr, n, nffts, False, False)
+    assert rc == 0 and ms > 0
+    done = (nffts // 400 * 400) if n == 32 else (nffts // 100 * 100)
+    print(f"config3 N={n}: {ms:.3f} ms, {done / ms * 1e3:.3e} FFT/s (no-reorder, 100 applications)")
