@@ -65,6 +65,15 @@ int smfft_rc_multiple_benchmark(const float* d_input, float* d_output, int FFT_s
 int smfft_launch(int family, int path, const void* d_input, void* d_output, int FFT_size, int nFFTs,
                  int inverse, int reorder, void* hip_stream);
 
+/* hipGraph form for launch-bound use (many small batches): captures `repeats` back-to-back launches
+ * of one transform into a graph -- with pingpong != 0 the two buffers swap roles every launch (d_b is
+ * the output of launch 0 and the input of launch 1, ...) -- and replays it with one host call per
+ * smfft_graph_launch.  Arguments as for smfft_launch.  Returns NULL on failure. */
+void* smfft_graph_create(int family, int path, void* d_a, void* d_b, int FFT_size, int nFFTs, int inverse, int reorder,
+                         int repeats, int pingpong);
+int smfft_graph_launch(void* graph, void* hip_stream);
+int smfft_graph_destroy(void* graph);
+
 /* Calibration: streams n_float2 elements (a multiple of 4096) from d_input to d_output with exactly
  * the external kernels' global access shape and grid, no FFT: the same-run copy ceiling. */
 int smfft_copy_launch(const void* d_input, void* d_output, long long n_float2, void* hip_stream);

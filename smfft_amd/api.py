@@ -34,6 +34,9 @@ _SIGS = {
     "smfft_rc_external_benchmark": (_i, [_vp, _vp, _i, _i, _i, _dp]),
     "smfft_rc_multiple_benchmark": (_i, [_vp, _vp, _i, _i, _dp]),
     "smfft_launch": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "smfft_graph_create": (_vp, [_i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    "smfft_graph_launch": (_i, [_vp, _vp]),
+    "smfft_graph_destroy": (_i, [_vp]),
     "smfft_copy_launch": (_i, [_vp, _vp, ctypes.c_longlong, _vp]),
     "smfft_gpu_ct": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _dp, _dp]),
     "smfft_gpu_st": (_i, [_vp, _vp, _i, _i, _i, _dp, _dp]),

@@ -451,3 +451,40 @@ def test_config3_full_batch_multiple_path(sm, oracle_lib, n):
     assert rc == 0 and ms > 0
     done = (nffts // 400 * 400) if n == 32 else (nffts // 100 * 100)
     print(f"config3 N={n}: {ms:.3f} ms, {done / ms * 1e3:.3e} FFT/s (no-reorder, 100 applications)")
+
+
+def test_graph_replay_matches_eager(sm, oracle_lib):
+    """smfft_graph_create / smfft_graph_launch: ping-ponged launches captured once into a hipGraph and
+    replayed with one host call.  Four forward transforms (F^4 = N^2 I) give an exact expectation;
+    the timing of a launch-bound case (64 launches of a 256-FFT batch per graph) is informational."""
+    import time
+    n, nffts = 1024, 4096
+    rng = np.random.default_rng(11)
+    x = ((rng.random((nffts, n), dtype=np.float32) - 0.5) + 1j * (rng.random((nffts, n), dtype=np.float32) - 0.5)).astype(np.complex64)
+    a, b = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
+    g = sm.lib.smfft_graph_create(0, 0, a.ptr, b.ptr, n, nffts, 0, 1, 4, 1)
+    assert g
+    assert sm.lib.smfft_graph_launch(g, None) == 0
+    sm.lib.smfft_synchronize()
+    got = a.to_host(np.complex64, x.shape)          # 4 ping-pong launches end in buffer a
+    l2, mx = ref.fft_errors(got / np.float32(n) ** 2, x.astype(np.complex128))
+    assert l2 < 1e-6 and mx < 2e-6, (l2, mx)
+    assert sm.lib.smfft_graph_destroy(g) == 0
+    small = 256
+    g = sm.lib.smfft_graph_create(0, 0, a.ptr, b.ptr, n, small, 0, 1, 64, 1)
+    assert g
+    sm.lib.smfft_graph_launch(g, None)
+    sm.lib.smfft_synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        sm.lib.smfft_graph_launch(g, None)
+    sm.lib.smfft_synchronize()
+    t_graph = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for r in range(20 * 64):
+        i, o = (a.ptr, b.ptr) if r % 2 == 0 else (b.ptr, a.ptr)
+        sm.launch("ct", "external", i, o, n, small, False, True)
+    sm.lib.smfft_synchronize()
+    t_eager = time.perf_counter() - t0
+    print(f"1280 launches of a {small}-FFT batch: eager {t_eager * 1e3:.2f} ms, 20 replays of a 64-launch graph {t_graph * 1e3:.2f} ms")
+    assert sm.lib.smfft_graph_destroy(g) == 0
