@@ -53,7 +53,10 @@ struct Geometry {
     static constexpr bool kMultiWave = (T > 64);
     // N = 512 / 1024: exchange 1 is a transpose between the lane's row bits (lane >> 4) and the top
     // register-index bits, done in registers with v_permlane16_swap / v_permlane32_swap: no LDS.
-    static constexpr bool kRegExchange1 = (RM == 2 || RM == 4);
+#ifndef SMFFT_NO_REG_X1
+#define SMFFT_NO_REG_X1 0
+#endif
+    static constexpr bool kRegExchange1 = !SMFFT_NO_REG_X1 && (RM == 2 || RM == 4);
     static constexpr int kFftsPerBlock = 4096 / N;
 };
 

@@ -90,10 +90,38 @@ __device__ __forceinline__ void lds_to_wave_chunk(float2* __restrict__ gwave, co
     }
 }
 
+// An empirical lever of the HBM-bound external kernels.  Passing the freshly loaded
+// tile once through LDS in natural order (every thread reads back exactly what it wrote) before the
+// transform makes the reorder kernels 3-8 % FASTER at every length except 1024 and 4096 (same buffers,
+// interleaved A/B, tools/ab_probe.py: N=32 5.64 -> 6.11 TB/s, 64: 5.63 -> 5.99, 128: 5.60 -> 5.95,
+// 256: 5.63 -> 5.91, 512: 5.67 -> 5.89, 2048: 5.73 -> 5.90; 1024: -0.5 %, 4096: +0.8 %), and it does the
+// same for a plain copy (SMFFT_stream_copy).  On the copy kernel a pure delay (s_sleep), holding all 16
+// loads before the first store, or the LDS allocation alone (occupancy) do NOT reproduce it, and a second
+// trip undoes it; the mechanism (how the load and store bursts of a CU's waves interleave on the way to
+// HBM) is not pinned down, so this is a per-length tuning switch like the grid cap, not a principle.
+#ifndef SMFFT_EXTRA_TRIP
+#define SMFFT_EXTRA_TRIP 1
+#endif
+template <int N>
+__device__ __forceinline__ void lds_round_trip(float2 (&r)[16], float2* sf, int u) {
+    using G = Geometry<N>;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) sf[u + G::T * c] = r[c];
+    fft_sync<G::kMultiWave>();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const v2f t = *reinterpret_cast<const volatile v2f*>(&sf[u + G::T * c]);
+        r[c] = make_float2(t.x, t.y);
+    }
+    fft_sync<G::kMultiWave>();
+}
+
 template <int N, int DIR, int REORDER>
 __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nFFTs, float2* s) {
     using G = Geometry<N>;
     constexpr bool kStaged = (N <= SMFFT_STAGED_MAX_N);
+    // see lds_round_trip: on for the reorder kernels of every length except 1024 and 4096
+    constexpr bool kExtraTrip = SMFFT_EXTRA_TRIP && REORDER && N != 1024 && N != 4096;
     constexpr int kFftsPerWave = (N <= 1024) ? 1024 / N : 1;
     Engine<N, DIR, REORDER> eng;
     eng.init(threadIdx.x);
@@ -111,6 +139,7 @@ __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_i
             fft_sync<false>();
             eng.load_lds(r, sf);
             fft_sync<false>();
+            if constexpr (kExtraTrip) lds_round_trip<N>(r, sf, eng.u);
             eng.transform(r, sf);
             fft_sync<false>();
             eng.store_lds(r, sf);
@@ -120,6 +149,7 @@ __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_i
         } else {
             eng.load_global(r, d_input + (active ? f : 0) * N);
             if (G::kMultiWave) __syncthreads();   // the previous tile's exchange reads are complete
+            if constexpr (kExtraTrip) lds_round_trip<N>(r, sf, eng.u);
             eng.transform(r, sf);
             eng.store_global(r, d_output + f * N, active);
         }
@@ -286,9 +316,10 @@ __device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__
 // tiles) with no FFT in between.  bench.py times it next to the FFT so the HBM-bound kernels are
 // reported against a same-run, same-shape copy ceiling as well as against the 8 TB/s datasheet peak.
 // ------------------------------------------------------------------------------------------------
-template <int kUnused>
+template <int kTrips>
 __global__ void __launch_bounds__(256) SMFFT_stream_copy(const float2* __restrict__ d_input, float2* __restrict__ d_output, long ntiles) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float2 s_trip[kTrips > 0 ? 4352 : 1];
     // (a contiguous run of tiles per workgroup instead of this grid stride measured the same:
     //  5.6-5.9 TB/s either way, tools/copy_probe.py)
     const long first = blockIdx.x, step = gridDim.x, last = ntiles;
@@ -298,6 +329,21 @@ __global__ void __launch_bounds__(256) SMFFT_stream_copy(const float2* __restric
         float2 r[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) r[c] = smfft::gload(g + 64 * c);
+        // kTrips = 1 is the default: ONE round trip of the wave's chunk through LDS between the loads and
+        // the stores makes this copy 7 % faster than the plain one (6.11 vs 5.73 TB/s, tools/copy_trip_probe.py;
+        // two trips: 5.64).  See lds_round_trip above.
+        for (int k = 0; k < kTrips; ++k) {
+            float2* sw = s_trip + wave * 1088;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) sw[lane + 64 * c] = r[c];
+            smfft::fft_sync<false>();
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const smfft::v2f t = *reinterpret_cast<const volatile smfft::v2f*>(&sw[lane + 64 * c]);
+                r[c] = make_float2(t.x, t.y);
+            }
+            smfft::fft_sync<false>();
+        }
 #pragma unroll
         for (int c = 0; c < 16; ++c) smfft::gstore(o + 64 * c, r[c]);
     }

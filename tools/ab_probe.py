@@ -17,14 +17,23 @@ def t(l, i, o, k=1):
     for _ in range(k):
         l.smfft_ct_external_benchmark(i, o, n, nffts, inv, reo, ctypes.byref(v))
     return v.value / k
-cands = [sm.DeviceBuffer(nbytes) for _ in range(5)]
+pa, pb = ctypes.c_void_p(), ctypes.c_void_p()
+assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(pa), ctypes.byref(pb)) == 0   # placement-probed pair
 chunk = np.random.default_rng(0).random(1 << 22, dtype=np.float32)
-for off in range(0, nbytes, chunk.nbytes):
-    sm.lib.smfft_memcpy_h2d(cands[0].ptr + off, chunk.ctypes.data, chunk.nbytes)
-for c in cands[1:]:
-    sm.lib.smfft_memcpy_d2d(c.ptr, cands[0].ptr, nbytes)
-best = min(((t(libs[0], a.ptr, b.ptr, 5), ia, ib) for ia, a in enumerate(cands) for ib, b in enumerate(cands) if ia != ib))
-a, b = cands[best[1]], cands[best[2]]
+sm.lib.smfft_memcpy_h2d(pa.value, chunk.ctypes.data, chunk.nbytes)
+filled = chunk.nbytes
+while filled < nbytes:
+    step = min(filled, nbytes - filled)
+    sm.lib.smfft_memcpy_d2d(pa.value + filled, pa.value, step)
+    filled += step
+
+
+class _B:
+    def __init__(self, p):
+        self.ptr = p
+
+
+a, b = _B(pa.value), _B(pb.value)
 res = [[], []]
 for rnd in range(15):
     for k, l in enumerate(libs):
