@@ -14,16 +14,22 @@ src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 
 
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: keep only the latest run's file."""
+    files = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return files[-1:]
+
+
 def counters(sub):
     agg = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(os.path.join(src, sub, "**", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
     return agg
 
 
 # 1. kernel stats of the bench command
-for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
+for f in newest(os.path.join(src, "stats", "**", "*kernel_stats.csv")):
     shutil.copy(f, f"profiles/{tag}_bench_kernel_stats.csv")
 for name in ("bench.json", "bench_under_rocprof.json", "configs.json", "mult_saturation.txt"):
     if os.path.exists(os.path.join(src, name)):
