@@ -49,6 +49,11 @@ int smfft_ct_multiple_benchmark(const void* d_input, void* d_output, int FFT_siz
 int smfft_st_external_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, double* FFT_time);
 int smfft_st_multiple_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, double* FFT_time);
 
+/* Forward-direction counterpart of the Stockham external call.  Upstream's Stockham C2C program only has
+ * the + sign (ST:76); SURVEY.md 8(f) item 3 lists the forward direction as a gap.  inverse != 0 is
+ * smfft_st_external_benchmark; inverse == 0 computes the un-normalised FORWARD transform, natural order. */
+int smfft_st_external_benchmark_dir(const void* d_input, void* d_output, int FFT_size, int nFFTs, int inverse, double* FFT_time);
+
 /* ---- R2C / C2R family, real FFT_size = 512 .. 4096 -------------------------------------------- */
 /* FFT_external_benchmark (RC:396-432).  inverse == 0: d_input = nFFTs*FFT_size reals,
  * d_output = nFFTs*FFT_size/2 float2 with element 0 = (X[0].re, X[N/2].re).  inverse != 0: the
@@ -88,6 +93,25 @@ int smfft_gpu_st(const void* h_input, void* h_output, int FFT_size, int nFFTs, i
 /* GPU_smFFT_R2C (RC:572-650) / GPU_smFFT_C2R (RC:652-688). */
 int smfft_gpu_r2c(void* h_output, const float* h_input, int FFT_size, int nFFTs, int nRuns);
 int smfft_gpu_c2r(float* h_output, const void* h_input, int FFT_size, int nFFTs, int nRuns);
+
+/* ---- host-resident batches (no upstream counterpart) ---------------------
+ * smfft_host_transform streams nFFTs transforms whose input AND output live in HOST memory through the
+ * current device: the batch is cut into slabs of slab_ffts FFTs (<= 0: 32 MiB worth, SMFFT_HOST_SLAB_MIB)
+ * and `lanes` (<= 0: 8 for pageable, 2 for pinned memory; SMFFT_HOST_LANES) host threads, each with its own HIP stream and two device slab
+ * pairs, run H2D -> FFT -> D2H for interleaved slabs, so both PCIe directions and the kernels overlap and
+ * the device never holds more than 2 * lanes slab pairs (the batch may exceed device memory).  Pinned
+ * buffers (smfft_host_malloc, or hipHostRegister'ed memory) are read and written by the DMA engines
+ * directly; pageable buffers go through per-lane pinned bounce buffers, copied by the lane threads in
+ * parallel.  family / FFT_size / inverse / reorder as for smfft_launch (family 2: real length; input and
+ * output are FFT_size * 4 bytes per FFT either way).  *elapsed_ms = wall-clock time of the whole call
+ * (end to end, PCIe included); the first call also builds the cached pipeline (smfft_host_pipeline_release
+ * frees it).  Returns 0, -1 for an unsupported (family, FFT_size), -4 when the pipeline cannot be allocated,
+ * or a hipError_t. */
+int smfft_host_transform(int family, const void* h_input, void* h_output, int FFT_size, long long nFFTs,
+                         int inverse, int reorder, long long slab_ffts, int lanes, double* elapsed_ms);
+void* smfft_host_malloc(unsigned long long bytes); /* pinned host memory (hipHostMalloc) */
+int smfft_host_free(void* h_ptr);
+void smfft_host_pipeline_release(void);
 
 /* ---- tuning / introspection ------------------------------------------------------------------- */
 void smfft_set_grid_cap(int max_workgroups); /* default 12288 (persistent, grid-strided); 0 = one workgroup per tile */

@@ -13,8 +13,10 @@ from .api import (  # noqa: F401
     NREUSES,
     c2c,
     c2r,
+    host_transform,
     launch,
     lib,
+    pinned_empty,
     r2c,
     stockham_c2c,
 )

@@ -30,7 +30,12 @@ _SIGS = {
     "smfft_ct_external_benchmark": (_i, [_vp, _vp, _i, _i, _i, _i, _dp]),
     "smfft_ct_multiple_benchmark": (_i, [_vp, _vp, _i, _i, _i, _i, _dp]),
     "smfft_st_external_benchmark": (_i, [_vp, _vp, _i, _i, _dp]),
+    "smfft_st_external_benchmark_dir": (_i, [_vp, _vp, _i, _i, _i, _dp]),
     "smfft_st_multiple_benchmark": (_i, [_vp, _vp, _i, _i, _dp]),
+    "smfft_host_transform": (_i, [_i, _vp, _vp, _i, ctypes.c_longlong, _i, _i, ctypes.c_longlong, _i, _dp]),
+    "smfft_host_malloc": (_vp, [ctypes.c_ulonglong]),
+    "smfft_host_free": (_i, [_vp]),
+    "smfft_host_pipeline_release": (None, []),
     "smfft_rc_external_benchmark": (_i, [_vp, _vp, _i, _i, _i, _dp]),
     "smfft_rc_multiple_benchmark": (_i, [_vp, _vp, _i, _i, _dp]),
     "smfft_launch": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -179,10 +184,16 @@ def c2c(x, inverse=False, reorder=True, path="external"):
     return _run(x, np.complex64, x.shape, lambda i, o: f(i, o, n, nffts, inverse, reorder, "ct"))
 
 
-def stockham_c2c(x):
+def stockham_c2c(x, inverse=True):
+    """Stockham program: un-normalised inverse (+i) transform as upstream (ST:76); inverse=False is the forward
+    extension (smfft_st_external_benchmark_dir)."""
     x = np.ascontiguousarray(x, dtype=np.complex64)
     nffts, n = x.shape
-    return _run(x, np.complex64, x.shape, lambda i, o: FFT_external_benchmark(i, o, n, nffts, family="st"))
+
+    def fn(i, o):
+        t = ctypes.c_double(0.0)
+        return lib.smfft_st_external_benchmark_dir(i, o, n, nffts, int(inverse), ctypes.byref(t)), t.value
+    return _run(x, np.complex64, x.shape, fn)
 
 
 def r2c(x):
@@ -195,3 +206,50 @@ def c2r(xp):
     xp = np.ascontiguousarray(xp, dtype=np.complex64)
     nffts, half = xp.shape
     return _run(xp, np.float32, (nffts, 2 * half), lambda i, o: FFT_external_benchmark(i, o, 2 * half, nffts, inverse=True, family="rc"))
+
+
+# ---- host-resident batches (smfft_host_transform) ----------------------------------------------------
+def pinned_empty(shape, dtype):
+    """NumPy array over pinned host memory from smfft_host_malloc (kept alive by the array's base object)."""
+    dtype = np.dtype(dtype)
+    nbytes = max(int(np.prod(shape)) * dtype.itemsize, 8)
+    ptr = lib.smfft_host_malloc(nbytes)
+    if not ptr:
+        raise MemoryError(f"smfft_host_malloc({nbytes}) failed")
+
+    class _Owner:
+        def __init__(self, p):
+            self.p = p
+
+        def __del__(self):
+            try:
+                lib.smfft_host_free(self.p)
+            except Exception:
+                pass
+    owner = _Owner(ptr)
+    buf = (ctypes.c_char * nbytes).from_address(ptr)
+    buf._owner = owner
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
+def host_transform(x, out=None, family="ct", inverse=False, reorder=True, slab_ffts=0, lanes=0):
+    """x: (nFFTs, N) host array (complex64; float32 for R2C) -> (result, elapsed_ms) streamed through the GPU in
+    slabs with H2D / FFT / D2H overlapped; x and out may be pageable or pinned (pinned_empty)."""
+    fam = _FAMILY[family]
+    nffts, width = x.shape
+    if fam == 2:
+        n = width if not inverse else 2 * width          # R2C: reals in; C2R: N/2 packed complex in
+        in_dtype, out_dtype = (np.float32, np.complex64) if not inverse else (np.complex64, np.float32)
+        out_shape = (nffts, n // 2) if not inverse else (nffts, n)
+    else:
+        n, in_dtype, out_dtype, out_shape = width, np.complex64, np.complex64, (nffts, width)
+    if x.dtype != in_dtype or not x.flags.c_contiguous:
+        x = np.ascontiguousarray(x, dtype=in_dtype)
+    if out is None:
+        out = np.empty(out_shape, dtype=out_dtype)
+    assert out.dtype == out_dtype and out.shape == out_shape and out.flags.c_contiguous
+    t = ctypes.c_double(0.0)
+    rc = lib.smfft_host_transform(fam, x.ctypes.data, out.ctypes.data, n, nffts, int(inverse), int(reorder), int(slab_ffts), int(lanes), ctypes.byref(t))
+    if rc != 0:
+        raise RuntimeError(f"smfft_host_transform({family}, N={n}) -> {rc}")
+    return out, t.value

@@ -221,6 +221,11 @@ int smfft_ct_multiple_benchmark(const void* d_input, void* d_output, int FFT_siz
 int smfft_st_external_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, double* FFT_time) {
     return timed([&] { return dispatch_st((const float2*)d_input, (float2*)d_output, FFT_size, nFFTs, 0, 0); }, FFT_time);
 }
+int smfft_st_external_benchmark_dir(const void* d_input, void* d_output, int FFT_size, int nFFTs, int inverse, double* FFT_time) {
+    if (inverse) return smfft_st_external_benchmark(d_input, d_output, FFT_size, nFFTs, FFT_time);
+    // the engine is the same autosort Stockham plan for both signs: forward natural order = Engine<N, 0, 1>
+    return timed([&] { return dispatch_ct((const float2*)d_input, (float2*)d_output, FFT_size, nFFTs, false, true, 0, 0); }, FFT_time);
+}
 int smfft_st_multiple_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, double* FFT_time) {
     return timed([&] { return dispatch_st((const float2*)d_input, (float2*)d_output, FFT_size, nFFTs / SMFFT_NREUSES, 1, 0); }, FFT_time);
 }

@@ -488,3 +488,59 @@ def test_graph_replay_matches_eager(sm, oracle_lib):
     t_eager = time.perf_counter() - t0
     print(f"1280 launches of a {small}-FFT batch: eager {t_eager * 1e3:.2f} ms, 20 replays of a 64-launch graph {t_graph * 1e3:.2f} ms")
     assert sm.lib.smfft_graph_destroy(g) == 0
+
+
+# ------------------------------------------------- Stockham forward extension
+@pytest.mark.parametrize("n", ST_SIZES)
+def test_stockham_forward_extension_golden(sm, golden, n):
+    got = sm.stockham_c2c(golden[f"c2c_in_u01_{n}"], inverse=False)
+    ref.assert_close_fp32(got, golden[f"ct_out_u01_{n}_inv0_reo1"], f"ST forward N={n}")
+
+
+# ------------------------------------ host-resident batches streamed in slabs
+@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("n,inv,reo", [(1024, 0, 1), (64, 1, 1), (4096, 0, 0)])
+def test_host_transform_matches_device_path_and_oracle(sm, oracle_lib, n, inv, reo, pinned):
+    """Ragged slabs (the batch is not a multiple of the slab, more slabs than lanes * slots so every ring slot is
+    reused): bit-identical to the one-launch device path, and within tolerance of the fp64 oracle."""
+    rng = np.random.default_rng(77 + n)
+    nffts = 7 * (4096 // n) * 3 + 5
+    x = (rng.random((nffts, n), dtype=np.float32) + 1j * rng.random((nffts, n), dtype=np.float32)).astype(np.complex64)
+    out = None
+    if pinned:
+        xp = sm.pinned_empty(x.shape, np.complex64)
+        xp[...] = x
+        x, out = xp, sm.pinned_empty(x.shape, np.complex64)
+    got, ms = sm.host_transform(x, out=out, family="ct", inverse=bool(inv), reorder=bool(reo), slab_ffts=(4096 // n) * 2 + 1, lanes=3)
+    assert ms > 0
+    np.testing.assert_array_equal(got, sm.c2c(np.array(x), bool(inv), bool(reo)))
+    ref.assert_close_fp32(got, oa.ct_c2c(oracle_lib, np.array(x), inv, reo, "f64"), f"host_transform N={n}")
+
+
+def test_host_transform_families_and_defaults(sm, golden):
+    """Stockham and R2C/C2R through the host pipeline with the default slab / lane count; empty batch; bad length."""
+    x = golden["c2c_in_u01_512"]
+    got, _ = sm.host_transform(x, family="st")
+    ref.assert_close_fp32(got, golden["ct_out_u01_512_inv1_reo1"], "host ST")
+    got, _ = sm.host_transform(golden["r2c_in_2048"], family="rc", inverse=False)
+    ref.assert_close_fp32(got, golden["r2c_out_2048"], "host R2C")
+    got, _ = sm.host_transform(golden["c2r_in_2048"], family="rc", inverse=True)
+    ref.assert_close_fp32(got, golden["c2r_out_2048"], "host C2R")
+    empty, ms = sm.host_transform(np.empty((0, 1024), np.complex64))
+    assert empty.shape == (0, 1024) and ms == 0
+    with pytest.raises(RuntimeError):
+        sm.host_transform(np.zeros((4, 48), np.complex64))
+    sm.lib.smfft_host_pipeline_release()
+
+
+def test_host_transform_larger_than_one_slab_ring_roundtrip(sm):
+    """256 MiB batch (every lane cycles its two slots several times): inverse(forward(x)) = N * x."""
+    n, nffts = 1024, 32768
+    rng = np.random.default_rng(5)
+    x = sm.pinned_empty((nffts, n), np.complex64)
+    x.real[...] = rng.random((nffts, n), dtype=np.float32)
+    x.imag[...] = rng.random((nffts, n), dtype=np.float32)
+    y, _ = sm.host_transform(x, out=sm.pinned_empty((nffts, n), np.complex64), slab_ffts=1024, lanes=4)
+    z, _ = sm.host_transform(y, inverse=True, slab_ffts=1000, lanes=8)     # pinned in, pageable out, ragged
+    err = np.abs(z / n - x).max()
+    assert err < 2e-6, err

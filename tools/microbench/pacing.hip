@@ -1,0 +1,112 @@
+// Pacing microbenchmark: what does a streaming copy of 4 GiB -> 4 GiB reach on gfx950 as a function of
+//   VEC   bytes per lane per instruction (8, 16)
+//   NLD   load instructions per wave tile (tile = 64 * VEC * NLD bytes)
+//   TRIP  0 none | 1 one LDS write + read-back of the tile | 2 one ds_bpermute (identity) per dword
+//         | 3 the LDS trip AFTER issuing the next tile's loads is not modelled here
+// and of the grid cap.  Motivation: one LDS round trip makes the plain copy 7 % faster.
+// Build: hipcc -O3 --offload-arch=gfx950 pacing.hip -o pacing ; run: ./pacing [out_offset_GiB]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int VEC> struct VecT;
+template <> struct VecT<8> { using type = v2f; };
+template <> struct VecT<16> { using type = v4f; };
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int VEC, int NLD, int TRIP, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) copyk(const char* __restrict__ in, char* __restrict__ out, long ntiles /* block tiles */) {
+    using V = typename VecT<VEC>::type;
+    constexpr int kWaveBytes = 64 * VEC * NLD;
+    constexpr int kWaveElems = 64 * NLD;
+    __shared__ V s[TRIP == 1 ? WAVES * (kWaveElems + 64 * 8 / VEC) : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const V* g = reinterpret_cast<const V*>(in + (tile * WAVES + wave) * kWaveBytes) + lane;
+        V* o = reinterpret_cast<V*>(out + (tile * WAVES + wave) * kWaveBytes) + lane;
+        V r[NLD];
+#pragma unroll
+        for (int c = 0; c < NLD; ++c) r[c] = __builtin_nontemporal_load(g + 64 * c);
+        if (TRIP == 1) {
+            V* sw = s + wave * (kWaveElems + 64 * 8 / VEC);
+#pragma unroll
+            for (int c = 0; c < NLD; ++c) sw[lane + 64 * c] = r[c];
+            wave_sync();
+#pragma unroll
+            for (int c = 0; c < NLD; ++c) r[c] = *reinterpret_cast<const volatile V*>(&sw[lane + 64 * c]);
+            wave_sync();
+        } else if (TRIP == 2) {
+#pragma unroll
+            for (int c = 0; c < NLD; ++c)
+#pragma unroll
+                for (int k = 0; k < VEC / 4; ++k)
+                    r[c][k] = __int_as_float(__builtin_amdgcn_ds_bpermute(lane * 4, __float_as_int(r[c][k])));
+        }
+#pragma unroll
+        for (int c = 0; c < NLD; ++c) __builtin_nontemporal_store(r[c], o + 64 * c);
+    }
+}
+
+struct Variant { const char* name; void (*launch)(const char*, char*, long, int); long block_bytes; };
+template <int VEC, int NLD, int TRIP, int WAVES>
+void launch(const char* in, char* out, long nbytes, int cap) {
+    long ntiles = nbytes / (64L * VEC * NLD * WAVES);
+    long g = (cap > 0 && ntiles > cap) ? cap : ntiles;
+    copyk<VEC, NLD, TRIP, WAVES><<<dim3((unsigned)g), dim3(64 * WAVES)>>>(in, out, ntiles);
+}
+#define V(VEC, NLD, TRIP, WAVES) {"vec" #VEC " nld" #NLD " trip" #TRIP " waves" #WAVES, launch<VEC, NLD, TRIP, WAVES>, 64L * VEC * NLD * WAVES}
+
+int main(int argc, char** argv) {
+    const long nbytes = 4L << 30;
+    const long out_off = (argc > 1 ? atol(argv[1]) : 40) << 30;
+    char* arena;
+    CK(hipMalloc(&arena, out_off + nbytes));
+    CK(hipMemset(arena, 1, nbytes));
+    const char* in = arena;
+    char* out = arena + out_off;
+    std::vector<Variant> vs = {
+        V(8, 16, 0, 4), V(8, 16, 1, 4), V(8, 16, 2, 4),
+        V(16, 8, 0, 4), V(16, 8, 1, 4), V(16, 16, 0, 4), V(16, 16, 1, 4),
+        V(8, 32, 0, 4), V(8, 32, 1, 4), V(8, 8, 0, 4), V(8, 8, 1, 4),
+        V(8, 16, 1, 2), V(8, 16, 1, 8), V(8, 16, 0, 8), V(16, 8, 1, 8), V(8, 16, 1, 1),
+    };
+    const int caps[] = {8192, 12288, 16384, 24576};
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<std::vector<float>> res(vs.size() * 4);
+    for (int round = 0; round < 5; ++round)
+        for (size_t v = 0; v < vs.size(); ++v)
+            for (int ci = 0; ci < 4; ++ci) {
+                // same number of workgroup-slots worth of bytes per cap: scale the cap by the block size
+                int cap = (int)(caps[ci] * (32768.0 / vs[v].block_bytes));
+                vs[v].launch(in, out, nbytes, cap);
+                CK(hipEventRecord(e0));
+                for (int k = 0; k < 5; ++k) vs[v].launch(in, out, nbytes, cap);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                res[v * 4 + ci].push_back(ms / 5);
+            }
+    printf("out offset %ld GiB; GB/s (median of 5 rounds x 5 launches) at caps (scaled to 32 KiB blocks) 8192 12288 16384 24576\n", out_off >> 30);
+    for (size_t v = 0; v < vs.size(); ++v) {
+        printf("%-28s", vs[v].name);
+        for (int ci = 0; ci < 4; ++ci) {
+            auto& r = res[v * 4 + ci];
+            std::sort(r.begin(), r.end());
+            printf("  %6.0f", 2.0 * nbytes / r[r.size() / 2] / 1e6);
+        }
+        printf("\n");
+    }
+    return 0;
+}
