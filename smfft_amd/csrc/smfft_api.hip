@@ -22,13 +22,15 @@ int g_device = 0;       // the reference's global `int device = 0` (CT:15)
 int g_grid_cap = 12288; // workgroups per launch (grid-stride over tiles; 12288 = 12 or 16 rounds of the 4 or 3
                         // resident workgroups per CU; measured sweet spot); <= 0: one per tile
 int g_nreuses = SMFFT_NREUSES;  // applications per slot in the `multiple` kernels (tests lower it)
-bool g_env_read = false;
+std::once_flag g_env_once;
 
+// launches may come from several host threads (per-GPU threads of a multi-GPU driver, the lanes of
+// smfft_host_transform): the environment is read exactly once
 void read_env() {
-    if (g_env_read) return;
-    g_env_read = true;
-    if (const char* e = getenv("SMFFT_GRID_CAP")) g_grid_cap = atoi(e);
-    if (const char* e = getenv("SMFFT_DEVICE")) g_device = atoi(e);
+    std::call_once(g_env_once, [] {
+        if (const char* e = getenv("SMFFT_GRID_CAP")) g_grid_cap = atoi(e);
+        if (const char* e = getenv("SMFFT_DEVICE")) g_device = atoi(e);
+    });
 }
 
 // count of FFT slots the `multiple` path touches (CT:669-683; ST:351; RC:438)
@@ -128,6 +130,12 @@ float probe_copy_ms(const void* in, void* out, size_t bytes) {
 // started 24, 32 or 64 GiB after the input in different runs of tools/placement_map.py), so nothing
 // is assumed: (input, output) windows on an 8 GiB lattice inside one arena are each timed with a
 // short stream copy (about 3 ms per candidate pair) and the fastest pair wins.
+void set_pair(int slot, PairRec rec) {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lock(g_pairs_mutex);
+    g_pairs[slot] = rec;
+}
+
 int alloc_pair(size_t bytes, void** d_a, void** d_b) {
     size_t free_mem = 0, total_mem = 0;
     *d_a = *d_b = nullptr;
@@ -157,14 +165,14 @@ int alloc_pair(size_t bytes, void** d_a, void** d_b) {
             if (best_ms > 1e29f) { best_in = 0; best_out = span; }
             *d_a = (char*)arena + best_in;
             *d_b = (char*)arena + best_out;
-            g_pairs[slot] = {*d_a, *d_b, arena};
+            set_pair(slot, {*d_a, *d_b, arena});
             return 0;
         }
         (void)hipGetLastError();
     }
-    if (hipMalloc(d_a, bytes) != hipSuccess) { if (slot >= 0) g_pairs[slot] = {nullptr, nullptr, nullptr}; return 1; }
-    if (hipMalloc(d_b, bytes) != hipSuccess) { (void)hipFree(*d_a); *d_a = nullptr; if (slot >= 0) g_pairs[slot] = {nullptr, nullptr, nullptr}; return 1; }
-    if (slot >= 0) g_pairs[slot] = {*d_a, *d_b, nullptr};
+    if (hipMalloc(d_a, bytes) != hipSuccess) { set_pair(slot, {nullptr, nullptr, nullptr}); return 1; }
+    if (hipMalloc(d_b, bytes) != hipSuccess) { (void)hipFree(*d_a); *d_a = nullptr; set_pair(slot, {nullptr, nullptr, nullptr}); return 1; }
+    set_pair(slot, {*d_a, *d_b, nullptr});
     return 0;
 }
 
