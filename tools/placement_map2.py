@@ -1,4 +1,5 @@
-"""Finer placement map: output offset in 1 GiB steps, 15 launches each (median), input at 0."""
+"""Full (input offset, output offset) map of the N=1024 external kernel's time inside one arena, 4 GiB lattice.
+usage: python tools/placement_map2.py [arena_GiB=192] [step_GiB=4]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -6,15 +7,28 @@ import smfft_amd as sm
 n, nffts = 1024, 524288
 nb = n * nffts * 8
 G = 1 << 30
-arena = sm.DeviceBuffer(80 * G)
-base = arena.ptr
-chunk = np.random.default_rng(0).random(1 << 22, dtype=np.float32)
-for off in range(0, nb, chunk.nbytes):
-    sm.lib.smfft_memcpy_h2d(base + off, chunk.ctypes.data, chunk.nbytes)
-def t(i, o):
-    sm.FFT_external_benchmark(i, o, n, nffts)
-    return sorted(sm.FFT_external_benchmark(i, o, n, nffts)[1] for _ in range(15))[7]
-for lo, hi in ((28, 48), (48, 68)):
-    print(" ".join(f"{g}:{t(base, base + g * G):.3f}" for g in range(lo, hi)))
-# sub-GiB: offsets 40 GiB + k*64 MiB
-print(" ".join(f"40G+{k*64}M:{t(base, base + 40 * G + k * (64 << 20)):.3f}" for k in range(0, 16, 2)))
+total = int(sys.argv[1]) if len(sys.argv) > 1 else 192
+step = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+arena = sm.DeviceBuffer(total * G)
+sm.lib.smfft_memset(arena.ptr, 0, total * G)     # content does not matter for the timing; avoid NaN paths anyway
+offs = list(range(0, total - 3, step))
+print(f"arena {arena.ptr:#x} {total} GiB; ms of one launch (min of 3) for input offset (rows) x output offset (columns), GiB")
+print("      " + " ".join(f"{o:5d}" for o in offs))
+best = []
+for i in offs:
+    row = []
+    for o in offs:
+        if abs(i - o) < 4:
+            row.append("    -")
+            continue
+        sm.FFT_external_benchmark(arena.ptr + i * G, arena.ptr + o * G, n, nffts)
+        ms = min(sm.FFT_external_benchmark(arena.ptr + i * G, arena.ptr + o * G, n, nffts)[1] for _ in range(3))
+        row.append(f"{ms:5.3f}")
+        best.append((ms, i, o))
+    print(f"{i:5d} " + " ".join(row), flush=True)
+best.sort()
+print("fastest:", [(round(m, 4), i, o) for m, i, o in best[:12]])
+print("slowest:", [(round(m, 4), i, o) for m, i, o in best[-5:]])
+import collections
+h = collections.Counter(round(m, 2) for m, _, _ in best)
+print("histogram (ms: pairs):", sorted(h.items()))
