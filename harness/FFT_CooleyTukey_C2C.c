@@ -43,10 +43,7 @@ int main(int argc, char* argv[]) {
 
 	if (DEBUG) printf("Initializing data with random numbers...\t");
 	harness_seed();
-	for (size_t f = 0; f < count; f++) {   // .y before .x, as FFT.c:141-142
-		h_input[f].y = rand()/(float) RAND_MAX;
-		h_input[f].x = rand()/(float) RAND_MAX;
-	}
+	harness_fill_uniform((float *) h_input, 2*count);   // U[0,1) re and im (FFT.c:141-142)
 	if (DEBUG) printf("done.\n");
 
 	double cuFFT_execution_time, smFFT_execution_time, smFFT_multiple_execution_time;

@@ -28,10 +28,7 @@ int main(int argc, char* argv[]) {
 	if (!h_input || !h_smFFT_output || !h_cuFFT_output) { printf("Host memory allocation failed.\n"); return 1; }
 
 	harness_seed();
-	for (size_t f = 0; f < count; f++) {
-		h_input[f].y = rand()/(float) RAND_MAX;
-		h_input[f].x = rand()/(float) RAND_MAX;
-	}
+	harness_fill_uniform((float *) h_input, 2*count);   // U[0,1) re and im (FFT.c:141-142)
 
 	double cuFFT_execution_time, smFFT_execution_time, smFFT_multiple_execution_time;
 	GPU_cuFFT(h_input, h_cuFFT_output, FFT_size, nFFTs, nRuns, &cuFFT_execution_time);

@@ -11,34 +11,38 @@ int GPU_smFFT_C2R(float *h_output, float2 *h_input, int FFT_size, int nFFTs, int
 
 // RC/FFT.c:126-159: element 0 of the packed smFFT output holds (DC, Nyquist)
 static int Compare_R2C_output(float2 *kFFT, float2 *vendor, int FFT_size, int nFFTs) {
-	int nErrors = 0, printed = 0;
+	std::atomic<int> nErrors(0), printed(0);
 	const int vs = (FFT_size >> 1) + 1, ks = (FFT_size >> 1);
-	for (int f = 0; f < nFFTs; f++) {
-		float2 v0 = make_float2(vendor[(size_t) f*vs].x, vendor[(size_t) (f + 1)*vs - 1].x);
-		for (int i = 0; i < ks; i++) {
-			float2 k = kFFT[(size_t) f*ks + i];
-			float2 v = (i == 0 ? v0 : vendor[(size_t) f*vs + i]);
-			float error = get_error(k, v);
-			if (error > max_error) {
-				if (printed++ < 20) printf("FFT: %d; element: %d; Error is [%f] value is [%f,%f] while it should be [%f,%f]\n", f, i, error, k.x, k.y, v.x, v.y);
-				nErrors++;
+	harness_parallel_chunks((size_t) nFFTs, [&](size_t fa, size_t fb, int) {
+		for (size_t f = fa; f < fb; f++) {
+			float2 v0 = make_float2(vendor[f*vs].x, vendor[(f + 1)*vs - 1].x);
+			for (int i = 0; i < ks; i++) {
+				float2 k = kFFT[f*ks + i];
+				float2 v = (i == 0 ? v0 : vendor[f*vs + i]);
+				float error = get_error(k, v);
+				if (error > max_error) {
+					if (printed++ < 20) printf("FFT: %zu; element: %d; Error is [%f] value is [%f,%f] while it should be [%f,%f]\n", f, i, error, k.x, k.y, v.x, v.y);
+					nErrors++;
+				}
 			}
 		}
-	}
+	});
 	return nErrors;
 }
 
 // RC/FFT.c:161-185: smFFT/(N/2) against vendor/N
 static int Compare_C2R_output(float *kFFT, float *vendor, int FFT_size, int nFFTs) {
-	int nErrors = 0, printed = 0;
-	for (size_t pos = 0; pos < (size_t) nFFTs*FFT_size; pos++) {
-		float k = kFFT[pos]/(FFT_size >> 1), v = vendor[pos]/FFT_size;
-		float error = get_error(k, v);
-		if (error > max_error) {
-			if (printed++ < 20) printf("element: %zu; Error is [%f] kFFT value is [%f] while it should be [%f]\n", pos, error, k, v);
-			nErrors++;
+	std::atomic<int> nErrors(0), printed(0);
+	harness_parallel_chunks((size_t) nFFTs*FFT_size, [&](size_t a, size_t b, int) {
+		for (size_t pos = a; pos < b; pos++) {
+			float k = kFFT[pos]/(FFT_size >> 1), v = vendor[pos]/FFT_size;
+			float error = get_error(k, v);
+			if (error > max_error) {
+				if (printed++ < 20) printf("element: %zu; Error is [%f] kFFT value is [%f] while it should be [%f]\n", pos, error, k, v);
+				nErrors++;
+			}
 		}
-	}
+	});
 	return nErrors;
 }
 
@@ -67,22 +71,28 @@ int main(int argc, char* argv[]) {
 	float  *h_cuFFT_output_inverse = (float *)  calloc((size_t) nFFTs*FFT_size, sizeof(float));
 
 	harness_seed();
-	for (size_t i = 0; i < (size_t) nFFTs*FFT_size; i++) h_input_R2C[i] = rand()/(float) RAND_MAX;
+	harness_fill_uniform(h_input_R2C, (size_t) nFFTs*FFT_size);
 	// C2R inputs (FFT.c:264-283): the vendor layout has N/2+1 bins with real DC and Nyquist; the
 	// smFFT layout packs the Nyquist value into element 0's imaginary part.
-	for (int f = 0; f < nFFTs; f++) {
-		float nyquist = rand()/(float) RAND_MAX;
-		float dc = rand()/(float) RAND_MAX;
-		h_input_C2R[(size_t) f*vs] = make_float2(dc, 0);
-		h_input_C2R_kFFT[(size_t) f*ks] = make_float2(dc, nyquist);
-		for (int s = 1; s < ks; s++) {
-			float re = rand()/(float) RAND_MAX;
-			float im = rand()/(float) RAND_MAX;
-			h_input_C2R[(size_t) f*vs + s] = make_float2(re, im);
-			h_input_C2R_kFFT[(size_t) f*ks + s] = make_float2(re, im);
+	const unsigned long long c2r_base = (unsigned long long) nFFTs*FFT_size;   // counter offset of this second data set
+	auto fill_c2r = [&](size_t fa, size_t fb, int) {
+		for (size_t f = fa; f < fb; f++) {
+			const unsigned long long i0 = c2r_base + (unsigned long long) f*FFT_size;
+			float nyquist = harness_next_uniform(i0);
+			float dc = harness_next_uniform(i0 + 1);
+			h_input_C2R[f*vs] = make_float2(dc, 0);
+			h_input_C2R_kFFT[f*ks] = make_float2(dc, nyquist);
+			for (int s = 1; s < ks; s++) {
+				float re = harness_next_uniform(i0 + 2*s);
+				float im = harness_next_uniform(i0 + 2*s + 1);
+				h_input_C2R[f*vs + s] = make_float2(re, im);
+				h_input_C2R_kFFT[f*ks + s] = make_float2(re, im);
+			}
+			h_input_C2R[f*vs + ks].x = nyquist;
 		}
-		h_input_C2R[(size_t) f*vs + ks].x = nyquist;
-	}
+	};
+	if (harness_libc_rand) fill_c2r(0, (size_t) nFFTs, 0);   // the serial libc stream keeps its order
+	else harness_parallel_chunks((size_t) nFFTs, fill_c2r);
 
 	GPU_cuFFT_R2C(h_cuFFT_output, h_input_R2C, FFT_size, nFFTs, nRuns);
 	GPU_smFFT_R2C(h_kFFT_output,  h_input_R2C, FFT_size, nFFTs, nRuns);
