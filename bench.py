@@ -99,6 +99,19 @@ def measured_traffic():
         return None
 
 
+def device_info(torch, dev):
+    """Which part ran the numbers (runs on different boxes of the pool differ by up to 6 %)."""
+    info = {}
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        for k in ("name", "gcnArchName", "total_memory", "multi_processor_count", "clock_rate", "memory_clock_rate", "memory_bus_width", "L2_cache_size"):
+            if hasattr(p, k):
+                info[k] = getattr(p, k)
+    except Exception as e:   # informational only
+        info["error"] = repr(e)
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -295,6 +308,7 @@ def main():
             "comm_backend": (backend if world > 1 else None),
             "buffer_placement_probe": placement,
             "spot_check_relL2": err,
+            "device": device_info(torch, dev),
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = os.cpu_count() or 1
