@@ -25,14 +25,21 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int VEC, int NLD, int TRIP, int WAVES>
+// MAP: 0 grid stride (block b: tiles b, b+G, ...: with G % 8 == 0 every XCD keeps one residue class mod 8)
+//      1 the residue class rotates with the iteration (every XCD visits all 8 classes)
+//      2 XCD x (= blockIdx % 8) owns the x-th contiguous eighth of the buffers
+template <int VEC, int NLD, int TRIP, int WAVES, int MAP = 0>
 __global__ void __launch_bounds__(64 * WAVES) copyk(const char* __restrict__ in, char* __restrict__ out, long ntiles /* block tiles */) {
     using V = typename VecT<VEC>::type;
     constexpr int kWaveBytes = 64 * VEC * NLD;
     constexpr int kWaveElems = 64 * NLD;
     __shared__ V s[TRIP == 1 ? WAVES * (kWaveElems + 64 * 8 / VEC) : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    long iter = 0;
+    for (long t0 = blockIdx.x; t0 < ntiles; t0 += gridDim.x, ++iter) {
+        long tile = t0;
+        if (MAP == 1) tile = (t0 & ~7L) | ((t0 + iter) & 7);
+        if (MAP == 2) tile = (long)(blockIdx.x & 7) * (ntiles / 8) + (blockIdx.x >> 3) + iter * (gridDim.x >> 3);
         const V* g = reinterpret_cast<const V*>(in + (tile * WAVES + wave) * kWaveBytes) + lane;
         V* o = reinterpret_cast<V*>(out + (tile * WAVES + wave) * kWaveBytes) + lane;
         V r[NLD];
@@ -59,13 +66,15 @@ __global__ void __launch_bounds__(64 * WAVES) copyk(const char* __restrict__ in,
 }
 
 struct Variant { const char* name; void (*launch)(const char*, char*, long, int); long block_bytes; };
-template <int VEC, int NLD, int TRIP, int WAVES>
+template <int VEC, int NLD, int TRIP, int WAVES, int MAP = 0>
 void launch(const char* in, char* out, long nbytes, int cap) {
     long ntiles = nbytes / (64L * VEC * NLD * WAVES);
     long g = (cap > 0 && ntiles > cap) ? cap : ntiles;
-    copyk<VEC, NLD, TRIP, WAVES><<<dim3((unsigned)g), dim3(64 * WAVES)>>>(in, out, ntiles);
+    g &= ~7L;   // MAP 1/2 need a multiple of 8 (ntiles is one)
+    copyk<VEC, NLD, TRIP, WAVES, MAP><<<dim3((unsigned)g), dim3(64 * WAVES)>>>(in, out, ntiles);
 }
 #define V(VEC, NLD, TRIP, WAVES) {"vec" #VEC " nld" #NLD " trip" #TRIP " waves" #WAVES, launch<VEC, NLD, TRIP, WAVES>, 64L * VEC * NLD * WAVES}
+#define VM(VEC, NLD, TRIP, WAVES, MAP) {"vec" #VEC " nld" #NLD " trip" #TRIP " waves" #WAVES " map" #MAP, launch<VEC, NLD, TRIP, WAVES, MAP>, 64L * VEC * NLD * WAVES}
 
 int main(int argc, char** argv) {
     const long nbytes = 4L << 30;
@@ -77,6 +86,7 @@ int main(int argc, char** argv) {
     char* out = arena + out_off;
     std::vector<Variant> vs = {
         V(8, 16, 0, 4), V(8, 16, 1, 4), V(8, 16, 2, 4),
+        VM(8, 16, 0, 4, 1), VM(8, 16, 1, 4, 1), VM(8, 16, 0, 4, 2), VM(8, 16, 1, 4, 2), VM(8, 8, 0, 4, 1), VM(8, 8, 0, 4, 2),
         V(16, 8, 0, 4), V(16, 8, 1, 4), V(16, 16, 0, 4), V(16, 16, 1, 4),
         V(8, 32, 0, 4), V(8, 32, 1, 4), V(8, 8, 0, 4), V(8, 8, 1, 4),
         V(8, 16, 1, 2), V(8, 16, 1, 8), V(8, 16, 0, 8), V(16, 8, 1, 8), V(8, 16, 1, 1),
