@@ -43,11 +43,9 @@ static void *worker(void *arg) {
 		printf("GPU %d: allocation failed\n", w->gpu);
 		return NULL;
 	}
-	unsigned seed = 20200720u + 7919u*(unsigned) w->gpu;        // per-slab reproducible data, U[0,1) like FFT.c:141-142
-	for (size_t f = 0; f < count; f++) {
-		h_in[f].y = rand_r(&seed)/(float) RAND_MAX;
-		h_in[f].x = rand_r(&seed)/(float) RAND_MAX;
-	}
+	// per-slab reproducible data, U[0,1) like FFT.c:141-142: element i of slab g is counter g*2*count + i of the
+	// harness's counter-based generator (seed fixed in main), so the batch does not depend on the number of GPUs
+	for (size_t i = 0; i < 2*count; i++) ((float *) h_in)[i] = harness_uniform((unsigned long long) w->gpu*2*count + i);
 	if (hipMemcpy(d_in, h_in, bytes, hipMemcpyHostToDevice) != hipSuccess) return NULL;
 	FFT_init();
 	double total = 0;
@@ -98,6 +96,7 @@ int main(int argc, char *argv[]) {
 	if (hipGetDeviceCount(&devCount) != hipSuccess || devCount < 1) { printf("No HIP device.\n"); return 1; }
 	int nGPUs = (argc == 7) ? (int) strtol(argv[6], NULL, 10) : devCount;
 	if (nGPUs < 1 || nGPUs > devCount) nGPUs = devCount;
+	harness_seed_value = getenv("SMFFT_SEED") ? strtoull(getenv("SMFFT_SEED"), NULL, 10) : 20200720ull;
 
 	ncclComm_t *comms = (ncclComm_t *) malloc(nGPUs*sizeof(ncclComm_t));
 	int *devs = (int *) malloc(nGPUs*sizeof(int));
