@@ -57,6 +57,14 @@ struct Geometry {
 #define SMFFT_NO_REG_X1 0
 #endif
     static constexpr bool kRegExchange1 = !SMFFT_NO_REG_X1 && (RM == 2 || RM == 4);
+    // N <= 64 (two passes, an FFT is 2 or 4 lanes of one quad): the exchange between the passes -- and
+    // the bit-reversal transposition of the no-reorder variants -- are transposes between the FFT's lane bits
+    // and as many register-index bits, done in registers with DPP row operations: no LDS at all inside the
+    // transform (measured on the in-LDS path: DESIGN.md section 5).
+#ifndef SMFFT_REG_TWOPASS_MAX_N
+#define SMFFT_REG_TWOPASS_MAX_N 64
+#endif
+    static constexpr bool kRegTwoPass = (RM == 1) && (N <= SMFFT_REG_TWOPASS_MAX_N);
     static constexpr int kFftsPerBlock = 4096 / N;
 };
 
@@ -215,6 +223,10 @@ struct Engine {
         // read group distinct mod 32, while the low 4 role bits stay the lane's (exchange-1 writes
         // remain conflict free).
         t1 = u;
+        if constexpr (!REORDER && G::kRegTwoPass) {
+            // register transposition: lane u ends up with row u of the bit-reversed image, i.e. role rev_T(u)
+            t1 = (int)(__brev((unsigned)u) >> (32 - T_BITS));
+        }
         if constexpr (!REORDER && T_BITS > 5 && !G::kRegExchange1) {
             constexpr int m = T_BITS - 5;
             t1 = u ^ ((int)(__brev((unsigned)(u & ((1 << m) - 1))) >> (32 - m)) << 5);
@@ -253,6 +265,24 @@ struct Engine {
 #pragma unroll
                     for (int r1 = 0; r1 < R1; ++r1) r[b * R1 + r1] = t[b + B1 * r1];
             }
+        } else if constexpr (G::kRegTwoPass) {
+            // r[c] = x[u + T*c] = x[16*rho + j] with rho = c >> B1_BITS and j = ((c & (B1-1)) << T_BITS) | u.
+            // Swapping lane bit i with register bit B1_BITS + i gives lane = rho, register c'' = x[16*lane + j],
+            // j = ((c'' & (B1-1)) << T_BITS) | (c'' >> B1_BITS); the thread's role is t1 = rev_T(lane) (init).
+#pragma unroll
+            for (int i = 0; i < T_BITS; ++i) swap_lane_bit_with_register_bit(r, i, B1_BITS + i);
+            float2 t[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) t[c] = r[c];
+#pragma unroll
+            for (int b = 0; b < B1; ++b)
+#pragma unroll
+                for (int r1 = 0; r1 < R1; ++r1) {
+                    const int rb = (B1_BITS > 0) ? (int)(__brev((unsigned)b) >> (32 - (B1_BITS > 0 ? B1_BITS : 1))) : 0;
+                    const int rr = (R1_BITS > 0) ? (int)(__brev((unsigned)r1) >> (32 - (R1_BITS > 0 ? R1_BITS : 1))) : 0;
+                    const int j = rb * R1 + rr;
+                    r[b * R1 + r1] = t[((j & (T - 1)) << B1_BITS) | (j >> T_BITS)];
+                }
         } else {
             // pad shift: one pad per 16 elements, except N = 1024 (roles must equal lanes for the
             // register exchange 1, so the rows a read group touches are the even or the odd ones):
@@ -337,6 +367,62 @@ struct Engine {
             for (int r2 = 0; r2 < RM; ++r2) r[c * RM + r2] = t[BM * r2 + c];
     }
 
+    // The same one-bit transpose for lane bits 0..3 (inside a 16-lane row) with DPP: lanes with the bit clear
+    // send B and receive the partner's A into B, lanes with it set send A and receive the partner's B into A.  Bits 2 and 3 select the
+    // receiving lanes with the DPP bank mask (a bank = 4 lanes of a row): two v_mov_b32_dpp per dword pair;
+    // bits 0 and 1 (partner inside the quad) need a lane predicate: select, quad_perm move, two selects.
+    template <int LANE_BIT>
+    __device__ static __forceinline__ void swap_bit_dpp_dword(float& A, float& B, bool hi) {
+        const int a = __float_as_int(A), b = __float_as_int(B);
+        int na, nb;
+        if constexpr (LANE_BIT == 2) {
+            na = __builtin_amdgcn_update_dpp(a, b, 0x114 /* row_shr:4 */, 0xF, 0xA, false);   // banks 1,3 <- B of lane-4
+            nb = __builtin_amdgcn_update_dpp(b, a, 0x104 /* row_shl:4 */, 0xF, 0x5, false);   // banks 0,2 <- A of lane+4
+        } else if constexpr (LANE_BIT == 3) {
+            na = __builtin_amdgcn_update_dpp(a, b, 0x128 /* row_ror:8 */, 0xF, 0xC, false);   // lanes 8..15 <- B of lane^8
+            nb = __builtin_amdgcn_update_dpp(b, a, 0x128, 0xF, 0x3, false);                    // lanes 0..7  <- A of lane^8
+        } else {
+            const int send = hi ? a : b;   // the partner keeps its own half and takes the other one from here
+            const int recv = __builtin_amdgcn_update_dpp(send, send, LANE_BIT == 0 ? 0xB1 /* quad_perm [1,0,3,2] */ : 0x4E /* [2,3,0,1] */, 0xF, 0xF, false);
+            na = hi ? recv : a;
+            nb = hi ? b : recv;
+        }
+        A = __int_as_float(na);
+        B = __int_as_float(nb);
+    }
+    // all 8 register pairs (c, c | 1 << reg_bit), c with that bit clear
+    __device__ __forceinline__ void swap_lane_bit_with_register_bit(float2 (&r)[16], int lane_bit, int reg_bit) const {
+        const bool hi = (u >> lane_bit) & 1;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if ((c >> reg_bit) & 1) continue;
+            float2& A = r[c];
+            float2& B = r[c | (1 << reg_bit)];
+            switch (lane_bit) {
+                case 0: swap_bit_dpp_dword<0>(A.x, B.x, hi); swap_bit_dpp_dword<0>(A.y, B.y, hi); break;
+                case 1: swap_bit_dpp_dword<1>(A.x, B.x, hi); swap_bit_dpp_dword<1>(A.y, B.y, hi); break;
+                case 2: swap_bit_dpp_dword<2>(A.x, B.x, hi); swap_bit_dpp_dword<2>(A.y, B.y, hi); break;
+                default: swap_bit_dpp_dword<3>(A.x, B.x, hi); swap_bit_dpp_dword<3>(A.y, B.y, hi); break;
+            }
+        }
+    }
+
+    // Two-pass sizes in registers.  After pass 1 lane u holds element (n1 = t1 + T*b, q1) in r[b*R1 + q1].
+    // Swapping lane bit i with register bit i (i < log2 T) leaves lane w with q1 = w and register
+    // b*R1 + v = the element of the lane v it came from, whose role was t1 = v (reorder) or rev_T(v):
+    // x[t + T*b] of the last pass = r[b*R1 + (t or rev_T(t))].
+    __device__ __forceinline__ void exchange_last_registers(float2 (&r)[16], float2 (&x)[16]) const {
+#pragma unroll
+        for (int i = 0; i < T_BITS; ++i) swap_lane_bit_with_register_bit(r, i, i);
+#pragma unroll
+        for (int b = 0; b < B1; ++b)
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int v = REORDER ? t : (int)(__brev((unsigned)t) >> (32 - T_BITS));
+                x[t + T * b] = r[b * R1 + v];
+            }
+    }
+
     __device__ __forceinline__ void exchange1_write(const float2 (&r)[16], float2* sf) const {
         if constexpr (RM > 1) {
             // q1-major rows of S1: element (t1, q1) at q1*S1 + t1   (B1 == 1)
@@ -409,6 +495,12 @@ struct Engine {
     __device__ __forceinline__ void transform(float2 (&r)[16], float2* sf) const {
         to_pass1_layout(r, sf);
         pass1(r);
+        if constexpr (G::kRegTwoPass) {
+            float2 x[16];
+            exchange_last_registers(r, x);
+            SmallDft<16, 1, DIR>::run(x, r);
+            return;
+        }
         if constexpr (G::kRegExchange1) {
             exchange1_registers(r);
         } else {

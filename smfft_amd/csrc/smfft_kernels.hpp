@@ -121,7 +121,8 @@ __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_i
     using G = Geometry<N>;
     constexpr bool kStaged = (N <= SMFFT_STAGED_MAX_N);
     // see lds_round_trip: on for the reorder kernels of every length except 1024 and 4096
-    constexpr bool kExtraTrip = SMFFT_EXTRA_TRIP && REORDER && N != 1024 && N != 4096;
+    // (the no-reorder kernels make such a trip anyway for their transposition, except where that is done in registers)
+    constexpr bool kExtraTrip = SMFFT_EXTRA_TRIP && (REORDER || G::kRegTwoPass) && N != 1024 && N != 4096;
     constexpr int kFftsPerWave = (N <= 1024) ? 1024 / N : 1;
     Engine<N, DIR, REORDER> eng;
     eng.init(threadIdx.x);

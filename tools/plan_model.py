@@ -14,7 +14,9 @@ SF = 17N/16 float2 per FFT):
            no reorder: write p -> p + p/16, each thread (role t1) reads row rev_T(t1) (16 contiguous)
   pass 1 : B1 butterflies of radix R1, then W_N^((t1 + T*b) * q1)
   exch 1 : RM in {2,4}: in registers (v_permlane16/32_swap; modelled as a free data movement);
-           RM in {8,16}: LDS q1-major rows of S1 = T1 + T1/16; RM = 1: q1-major rows of 17 (last layout)
+           RM in {8,16}: LDS q1-major rows of S1 = T1 + T1/16; RM = 1: q1-major rows of 17 (last layout),
+           except N <= 64: lane-bit <-> register-bit transposes with DPP (free data movement in this model;
+           the no-reorder transposition of those sizes likewise, with role t1 = rev_T(lane))
   middle : DFT_RM over r2, * W_T1^(t2*q2), write t2*S2 + (q1 + 16*q2), S2 = T + 1
   last   : thread w reads its 16 inputs, DFT_16 -> X[w + T*q3]; store natural.
 Usage: python tools/plan_model.py
@@ -29,7 +31,7 @@ def geom(N):
     T = N // 16
     T1 = N // R1
     return dict(N=N, R1=R1, RM=RM, T=T, T1=T1, B1=16 // R1, BM=16 // RM, S1=T1 + T1 // 16, S2=T + 1, SF=17 * T,
-                reg_x1=RM in (2, 4))
+                reg_x1=RM in (2, 4), reg_2p=(RM == 1 and N <= 64))
 
 
 def bitrev(v, bits):
@@ -72,6 +74,8 @@ def run(x, N, sign, reorder, conf):
     regs = np.zeros((nthreads, 16), dtype=np.complex128)
 
     def role_t1(u):
+        if (not reorder) and g["reg_2p"]:
+            return bitrev(u, tb)
         if (not reorder) and tb > 5 and not g["reg_x1"]:
             m = tb - 5
             return u ^ (bitrev(u & ((1 << m) - 1), m) << 5)
@@ -92,6 +96,16 @@ def run(x, N, sign, reorder, conf):
         for b in range(B1):
             for r1 in range(R1):
                 regs[:, b * R1 + r1] = t[:, b + B1 * r1]
+    elif g["reg_2p"]:
+        # register transposition: lane rho ends with x[16*rho + j]; slot (b, r1) <- j = rev(b)*R1 + rev(r1)
+        nat = regs.copy()
+        b1b, r1b = B1.bit_length() - 1, R1.bit_length() - 1
+        for th in range(nthreads):
+            f, rho = divmod(th, T)
+            for b in range(B1):
+                for r1 in range(R1):
+                    m = 16 * rho + bitrev(b, b1b) * R1 + bitrev(r1, r1b)
+                    regs[th, b * R1 + r1] = nat[f * T + m % T, m // T]
     else:
         for c in range(16):
             def fn(th, c=c):
@@ -157,6 +171,14 @@ def run(x, N, sign, reorder, conf):
             rec("x2_read", "r", fn)
             for th in range(nthreads):
                 regs[th, t] = lds[fn(th)]
+    elif g["reg_2p"]:
+        # lane w takes q1 = w from every lane v of its FFT: x[t1(v) + T*b]
+        src = regs.copy()
+        for th in range(nthreads):
+            f, w = divmod(th, T)
+            for b in range(B1):
+                for v in range(T):
+                    regs[th, role_t1(v) + T * b] = src[f * T + v, b * R1 + w]
     else:
         for b in range(B1):
             for q1 in range(R1):
