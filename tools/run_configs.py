@@ -23,32 +23,26 @@ TOTAL = 1 << 29                      # float2 elements = 4 GiB (README's "input 
 nbytes = TOTAL * 8
 rng = np.random.default_rng(0)
 chunk = rng.random(1 << 22, dtype=np.float32)
-# buffer placement probe (same as bench.py: where a 4 GiB buffer lands physically changes the
-# streaming rate by 6-8 %): a few candidates, keep the fastest (input, output) pair
-cands = [sm.DeviceBuffer(nbytes) for _ in range(5)]
-for off in range(0, nbytes, chunk.nbytes):
-    sm.lib.smfft_memcpy_h2d(cands[0].ptr + off, chunk.ctypes.data, chunk.nbytes)
+# buffer placement (same as bench.py and the L3 wrappers: where the two 4 GiB buffers land physically changes the
+# streaming rate by 6-8 %): the library's placement-probed pair allocator
+import ctypes  # noqa: E402
+
+
+class _Raw:
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+
+pa, pb = ctypes.c_void_p(), ctypes.c_void_p()
+assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(pa), ctypes.byref(pb)) == 0
+a, b = _Raw(pa.value), _Raw(pb.value)
+sm.lib.smfft_memcpy_h2d(a.ptr, chunk.ctypes.data, chunk.nbytes)
+filled = chunk.nbytes
+while filled < nbytes:
+    step = min(filled, nbytes - filled)
+    sm.lib.smfft_memcpy_d2d(a.ptr + filled, a.ptr, step)
+    filled += step
 sm.FFT_init()
-
-
-def _probe(i, o):
-    for _ in range(2):
-        sm.FFT_external_benchmark(i.ptr, o.ptr, 1024, TOTAL // 1024)
-    return sorted(sm.FFT_external_benchmark(i.ptr, o.ptr, 1024, TOTAL // 1024)[1] for _ in range(7))[3]
-
-
-out_ms = {k: _probe(cands[0], cands[k]) for k in range(1, 5)}
-k_out = min(out_ms, key=out_ms.get)
-in_ms = {0: out_ms[k_out]}
-for k in range(1, 5):
-    if k != k_out:
-        sm.lib.smfft_memcpy_d2d(cands[k].ptr, cands[0].ptr, nbytes)
-        in_ms[k] = _probe(cands[k], cands[k_out])
-k_in = min(in_ms, key=in_ms.get)
-a, b = cands[k_in], cands[k_out]
-for k, c in enumerate(cands):
-    if k not in (k_in, k_out):
-        c.free()
 
 
 def timed(fn):
@@ -59,7 +53,7 @@ def timed(fn):
 
 
 doc = {"grid_cap": sm.lib.smfft_get_grid_cap(), "rounds": args.rounds, "unit_time": "ms",
-       "buffer_placement_probe_ms": {"out": [round(v, 4) for v in out_ms.values()], "in": [round(v, 4) for v in in_ms.values()]}}
+       "buffers": "smfft_malloc_pair", "output_minus_input_GiB": (b.ptr - a.ptr) / 2**30}
 
 # ---- config 2: N=1024 C2C forward + inverse with reorder, 524288 FFTs, external path
 c2 = {}
