@@ -544,3 +544,36 @@ def test_host_transform_larger_than_one_slab_ring_roundtrip(sm):
     z, _ = sm.host_transform(y, inverse=True, slab_ffts=1000, lanes=8)     # pinned in, pageable out, ragged
     err = np.abs(z / n - x).max()
     assert err < 2e-6, err
+
+
+def test_randomised_geometry_sweep(sm, oracle_lib):
+    """Seeded random (family, length, batch, direction, order, grid cap) combinations, ragged batches and tiny grid
+    caps (long grid-stride loops with partial last tiles), each against the fp64 oracle."""
+    rng = np.random.default_rng(20261002)
+    old = sm.lib.smfft_get_grid_cap()
+    try:
+        for case in range(48):
+            fam = ("ct", "ct", "st", "rc")[int(rng.integers(0, 4))]
+            cap = int(rng.choice([0, 1, 2, 5, 13, 12288]))
+            sm.lib.smfft_set_grid_cap(cap)
+            if fam == "rc":
+                n = int(rng.choice(R2C_SIZES))
+                nffts = int(rng.integers(1, 6 * (8192 // n) + 3))
+                x = rng.random((nffts, n), dtype=np.float32) - 0.5
+                ref.assert_close_fp32(sm.r2c(x), oa.r2c(oracle_lib, x, "f64"), f"case {case}: R2C N={n} nFFTs={nffts} cap={cap}")
+                xp = (rng.random((nffts, n // 2), dtype=np.float32) + 1j * rng.random((nffts, n // 2), dtype=np.float32)).astype(np.complex64)
+                ref.assert_close_fp32(sm.c2r(xp), oa.c2r(oracle_lib, xp, "f64"), f"case {case}: C2R N={n} nFFTs={nffts} cap={cap}")
+                continue
+            n = int(rng.choice(C2C_SIZES))
+            nffts = int(rng.integers(1, 6 * (4096 // n) + 3))
+            x = ((rng.random((nffts, n), dtype=np.float32) - 0.5) + 1j * (rng.random((nffts, n), dtype=np.float32) - 0.5)).astype(np.complex64)
+            if fam == "st":
+                inv = bool(rng.integers(0, 2))
+                ref.assert_close_fp32(sm.stockham_c2c(x, inverse=inv), oa.ct_c2c(oracle_lib, x, int(inv), 1, "f64"),
+                                      f"case {case}: ST N={n} nFFTs={nffts} inv={inv} cap={cap}")
+            else:
+                inv, reo = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+                ref.assert_close_fp32(sm.c2c(x, bool(inv), bool(reo)), oa.ct_c2c(oracle_lib, x, inv, reo, "f64"),
+                                      f"case {case}: CT N={n} nFFTs={nffts} inv={inv} reo={reo} cap={cap}")
+    finally:
+        sm.lib.smfft_set_grid_cap(old)
