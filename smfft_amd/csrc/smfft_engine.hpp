@@ -57,7 +57,7 @@ struct Geometry {
 #define SMFFT_NO_REG_X1 0
 #endif
     static constexpr bool kRegExchange1 = !SMFFT_NO_REG_X1 && (RM == 2 || RM == 4);
-    // N <= 64 (two passes, an FFT is 2 or 4 lanes of one quad): the exchange between the passes -- and
+    // N <= 64 (two passes, an FFT is 2 or 4 lanes of one 16-lane row): the exchange between the passes -- and
     // the bit-reversal transposition of the no-reorder variants -- are transposes between the FFT's lane bits
     // and as many register-index bits, done in registers with DPP row operations: no LDS at all inside the
     // transform (measured on the in-LDS path: DESIGN.md section 5).
@@ -205,6 +205,12 @@ struct Engine {
     static constexpr int S1 = G::S1, S2 = G::S2, SF = G::SF;
     static constexpr int E_BITS = ilog2c(N), T_BITS = ilog2c(T), R1_BITS = ilog2c(R1), B1_BITS = ilog2c(B1);
 
+#ifndef SMFFT_ROW_TOP_LANES
+#define SMFFT_ROW_TOP_LANES 1
+#endif
+    // physical lane bit of thread bit i of a register-two-pass FFT
+    static constexpr int kLaneShift = (SMFFT_ROW_TOP_LANES && G::kRegTwoPass) ? 4 - T_BITS : 0;
+
     int u;        // thread inside the FFT
     int fft;      // FFT inside the workgroup
     int t1;       // pass-1 role (which butterfly t1 + T*b this thread computes)
@@ -214,6 +220,16 @@ struct Engine {
     __device__ __forceinline__ void init(int tid) {
         u = tid % T;
         fft = tid / T;
+#if SMFFT_ROW_TOP_LANES
+        if constexpr (G::kRegTwoPass) {
+            // the FFT's threads are the TOP log2(T) bits of the position inside a 16-lane row, so that the
+            // DPP transposes select their lanes with the bank mask (lane bits 2, 3) wherever possible;
+            // every LDS instruction still touches the same set of addresses per lane group
+            const int lane = tid & 63;
+            u = (lane >> kLaneShift) & (T - 1);
+            fft = (tid >> 6) * (64 / T) + (lane >> 4) * (16 / T) + (lane & ((1 << kLaneShift) - 1));
+        }
+#endif
         t2 = u & 15;
         a = u >> 4;
         // REORDER: role = lane.  No reorder: the thread with role t1 reads row rev_T(t1) of the
@@ -398,7 +414,7 @@ struct Engine {
             if ((c >> reg_bit) & 1) continue;
             float2& A = r[c];
             float2& B = r[c | (1 << reg_bit)];
-            switch (lane_bit) {
+            switch (lane_bit + kLaneShift) {
                 case 0: swap_bit_dpp_dword<0>(A.x, B.x, hi); swap_bit_dpp_dword<0>(A.y, B.y, hi); break;
                 case 1: swap_bit_dpp_dword<1>(A.x, B.x, hi); swap_bit_dpp_dword<1>(A.y, B.y, hi); break;
                 case 2: swap_bit_dpp_dword<2>(A.x, B.x, hi); swap_bit_dpp_dword<2>(A.y, B.y, hi); break;
