@@ -1,6 +1,6 @@
 // FFT_multi_gpu.c -- config 5 of BASELINE.json at the C level: a batch of N-point C2C FFTs sharded
 // across the GPUs of one node.  Usage:
-//     FFT_multi_gpu.exe <FFT length> <FFTs per GPU> <nRuns> <inverse 0|1> <reorder 0|1> [nGPUs]
+//     FFT_multi_gpu.exe <FFT length> <FFTs per GPU> <nRuns> <inverse 0|1> <reorder 0|1> [nGPUs] [exchange 0|1]
 //
 // The path shards embarrassingly: GPU g owns the contiguous slab
 // [g*B, (g+1)*B) of the batch, generates it on its own host thread, uploads it, and runs the
@@ -9,6 +9,12 @@
 // north_star calls the trivial part: one communicator per GPU (ncclCommInitAll) and an all-reduce
 // of the per-GPU statistics -- MAX of the kernel time, SUM of the error counts -- so every rank
 // ends with the job-level numbers.  One host thread per GPU (HIP's current device is per thread).
+//
+// exchange = 1 adds, OUTSIDE the timed transform and reported separately (a 4 GiB slab over one
+// xGMI link takes ~28 ms against 1.4 ms of compute), the two optional payload movements of a single-buffer
+// workflow: an ncclAllGather of the output slabs into one buffer on every GPU, and a scatter of that buffer's
+// slabs from GPU 0 back to their owners with a grouped ncclSend / ncclRecv; both are verified bit for bit
+// against the GPU's own output.
 #include "harness_common.h"
 #include <pthread.h>
 #include <rccl/rccl.h>
@@ -21,7 +27,8 @@ extern "C" int smfft_free_pair(void *d_read);
 
 typedef struct {
 	int gpu, nGPUs, FFT_size, nFFTs, nRuns;
-	bool inverse, reorder;
+	bool inverse, reorder, exchange;
+	double gather_ms, scatter_ms;   // MAX over GPUs (after the all-reduce); 0 without exchange
 	ncclComm_t comm;
 	double kernel_ms;       // this GPU's mean launch time
 	double job_ms;          // MAX over GPUs (after the all-reduce)
@@ -39,7 +46,7 @@ static void *worker(void *arg) {
 	float *d_stats = NULL;
 	hipStream_t stream;
 	if (!h_in || !h_out || smfft_malloc_pair(bytes, (void **) &d_in, (void **) &d_out) != 0
-	    || hipMalloc((void **) &d_stats, 2*sizeof(float)) != hipSuccess || hipStreamCreate(&stream) != hipSuccess) {
+	    || hipMalloc((void **) &d_stats, 4*sizeof(float)) != hipSuccess || hipStreamCreate(&stream) != hipSuccess) {
 		printf("GPU %d: allocation failed\n", w->gpu);
 		return NULL;
 	}
@@ -65,18 +72,66 @@ static void *worker(void *arg) {
 			ein += (double) a.x*a.x + (double) a.y*a.y;
 			eout += (double) b.x*b.x + (double) b.y*b.y;
 		}
-		if (fabs(eout/(w->FFT_size*ein) - 1.0) > 1e-5) errors += 1;
+		if (fabs(eout/(w->FFT_size*ein) - 1.0) > 1e-5) { printf("GPU %d: FFT %d fails the Parseval check\n", w->gpu, f); errors += 1; }
 	}
 
-	// the only communication: job-level statistics over RCCL
-	float h_stats[2] = {(float) w->kernel_ms, (float) errors};
+	// optional payload movement over xGMI, never inside the timed transform
+	float gather_ms = 0, scatter_ms = 0;
+	if (w->exchange) {
+		float2 *d_all = NULL, *d_back = NULL;
+		hipEvent_t e0, e1, e2;
+		if (hipMalloc((void **) &d_all, bytes*w->nGPUs) != hipSuccess || hipMalloc((void **) &d_back, bytes) != hipSuccess
+		    || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) {
+			printf("GPU %d: exchange buffers: allocation failed\n", w->gpu);
+			return NULL;
+		}
+		(void) hipMemsetAsync(d_back, 0, bytes, stream);
+		(void) hipEventRecord(e0, stream);
+		ncclAllGather(d_out, d_all, 2*count, ncclFloat, w->comm, stream);
+		(void) hipEventRecord(e1, stream);
+		// point-to-point pieces of at most 1 GiB: a single 2 GiB ncclSend/ncclRecv arrived without its tail on
+		// this RCCL (2^31-byte message), the all-gather has no such limit
+		const size_t piece = (size_t) 1 << 27;   // float2 elements = 1 GiB
+		for (size_t off = 0; off < count; off += piece) {
+			const size_t n = (count - off < piece ? count - off : piece);
+			ncclGroupStart();
+			if (w->gpu == 0) for (int r = 0; r < w->nGPUs; r++) ncclSend(d_all + (size_t) r*count + off, 2*n, ncclFloat, r, w->comm, stream);
+			ncclRecv(d_back + off, 2*n, ncclFloat, 0, w->comm, stream);
+			ncclGroupEnd();
+		}
+		(void) hipEventRecord(e2, stream);
+		(void) hipStreamSynchronize(stream);
+		(void) hipEventElapsedTime(&gather_ms, e0, e1);
+		(void) hipEventElapsedTime(&scatter_ms, e1, e2);
+		// own segment of the gathered buffer and the slab scattered back == own output, bit for bit (first and last MiB)
+		const size_t probe = bytes < (1u << 20) ? bytes : (1u << 20);
+		char *t = (char *) malloc(probe);
+		const char *srcs[2] = {(const char *) (d_all + (size_t) w->gpu*count), (const char *) d_back};
+		for (int k = 0; k < 2; k++) {
+			const size_t offs[2] = {0, bytes - probe};
+			for (int o = 0; o < 2; o++) {
+				if (hipMemcpy(t, srcs[k] + offs[o], probe, hipMemcpyDeviceToHost) != hipSuccess || memcmp(t, (const char *) h_out + offs[o], probe) != 0) {
+					printf("GPU %d: %s differs from the GPU's own output at byte offset %zu\n", w->gpu, k == 0 ? "all-gather segment" : "scattered slab", offs[o]);
+					errors += 1;
+				}
+			}
+		}
+		free(t);
+		(void) hipFree(d_all); (void) hipFree(d_back);
+		(void) hipEventDestroy(e0); (void) hipEventDestroy(e1); (void) hipEventDestroy(e2);
+	}
+
+	// the only communication of the timed path: job-level statistics over RCCL
+	float h_stats[4] = {(float) w->kernel_ms, gather_ms, scatter_ms, (float) errors};
 	(void) hipMemcpy(d_stats, h_stats, sizeof(h_stats), hipMemcpyHostToDevice);
-	ncclAllReduce(d_stats, d_stats, 1, ncclFloat, ncclMax, w->comm, stream);
-	ncclAllReduce(d_stats + 1, d_stats + 1, 1, ncclFloat, ncclSum, w->comm, stream);
+	ncclAllReduce(d_stats, d_stats, 3, ncclFloat, ncclMax, w->comm, stream);
+	ncclAllReduce(d_stats + 3, d_stats + 3, 1, ncclFloat, ncclSum, w->comm, stream);
 	(void) hipStreamSynchronize(stream);
 	(void) hipMemcpy(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost);
 	w->job_ms = h_stats[0];
-	w->job_errors = h_stats[1];
+	w->gather_ms = h_stats[1];
+	w->scatter_ms = h_stats[2];
+	w->job_errors = h_stats[3];
 
 	(void) smfft_free_pair(d_in); (void) hipFree(d_stats); (void) hipStreamDestroy(stream);
 	free(h_in); free(h_out);
@@ -85,8 +140,8 @@ static void *worker(void *arg) {
 }
 
 int main(int argc, char *argv[]) {
-	if (argc != 6 && argc != 7) {
-		printf("Argument error!\n 1) FFT length\n 2) number of FFTs per GPU\n 3) the number of kernel executions\n 4) do inverse FFT 1=yes 0=no\n 5) reorder 1=yes 0=no\n 6) [number of GPUs, default all]\n");
+	if (argc < 6 || argc > 8) {
+		printf("Argument error!\n 1) FFT length\n 2) number of FFTs per GPU\n 3) the number of kernel executions\n 4) do inverse FFT 1=yes 0=no\n 5) reorder 1=yes 0=no\n 6) [number of GPUs, default (or 0) all]\n 7) [exchange 1 = also time an all-gather of the outputs and a scatter from GPU 0]\n");
 		printf("For example: FFT_multi_gpu.exe 1024 524288 20 0 1\n");
 		return 1;
 	}
@@ -94,7 +149,8 @@ int main(int argc, char *argv[]) {
 	bool inverse = strtol(argv[4], NULL, 10) == 1, reorder = strtol(argv[5], NULL, 10) == 1;
 	int devCount = 0;
 	if (hipGetDeviceCount(&devCount) != hipSuccess || devCount < 1) { printf("No HIP device.\n"); return 1; }
-	int nGPUs = (argc == 7) ? (int) strtol(argv[6], NULL, 10) : devCount;
+	int nGPUs = (argc >= 7) ? (int) strtol(argv[6], NULL, 10) : devCount;
+	const bool exchange = (argc == 8) && strtol(argv[7], NULL, 10) == 1;
 	if (nGPUs < 1 || nGPUs > devCount) nGPUs = devCount;
 	harness_seed_value = getenv("SMFFT_SEED") ? strtoull(getenv("SMFFT_SEED"), NULL, 10) : 20200720ull;
 
@@ -107,7 +163,7 @@ int main(int argc, char *argv[]) {
 	pthread_t *th = (pthread_t *) malloc(nGPUs*sizeof(pthread_t));
 	for (int g = 0; g < nGPUs; g++) {
 		w[g].gpu = g; w[g].nGPUs = nGPUs; w[g].FFT_size = FFT_size; w[g].nFFTs = nFFTs; w[g].nRuns = nRuns;
-		w[g].inverse = inverse; w[g].reorder = reorder; w[g].comm = comms[g];
+		w[g].inverse = inverse; w[g].reorder = reorder; w[g].exchange = exchange; w[g].comm = comms[g];
 		pthread_create(&th[g], NULL, worker, &w[g]);
 	}
 	int failed = 0;
@@ -119,6 +175,11 @@ int main(int argc, char *argv[]) {
 	for (int g = 0; g < nGPUs; g++) printf("  GPU %d: SH FFT normal = %0.3f ms (%0.1f GB/s)\n", g, w[g].kernel_ms, bytes_per_gpu/w[g].kernel_ms/1e6);
 	printf("  %d GPU(s), %d FFTs of %d each: job time = %0.3f ms; %0.4g FFT/s; %0.1f GB/s aggregate\n", nGPUs, nFFTs, FFT_size, w[0].job_ms,
 	       (double) nFFTs*nGPUs/(w[0].job_ms*1e-3), nGPUs*bytes_per_gpu/w[0].job_ms/1e6);
+	if (exchange) {
+		const double slab_gb = bytes_per_gpu/2/1e9;
+		printf("  exchange (not part of the job time): all-gather of the %d output slabs = %0.3f ms (%0.1f GB/s received per GPU); scatter from GPU 0 = %0.3f ms (%0.1f GB/s sent by GPU 0)\n",
+		       nGPUs, w[0].gather_ms, (nGPUs - 1)*slab_gb/(w[0].gather_ms*1e-3 + 1e-12), w[0].scatter_ms, (nGPUs - 1)*slab_gb/(w[0].scatter_ms*1e-3 + 1e-12));
+	}
 	print_verdict((int) w[0].job_errors);
 	return 0;
 }

@@ -239,6 +239,7 @@ def test_config4_r2c_c2r_roundtrip(sm, oracle_lib):
     ("FFT_Stockham_C2C.exe", ["2048", "1500", "2"], 1),
     ("FFT_Stockham_R2C_C2R.exe", ["2048", "1200", "2"], 2),
     ("FFT_multi_gpu.exe", ["1024", "4100", "3", "0", "1"], 1),
+    ("FFT_multi_gpu.exe", ["1024", "4100", "3", "0", "1", "0", "1"], 1),   # + all-gather / scatter over RCCL
 ])
 def test_harness_programs(sm, prog, args, expect):
     """The harness (g++-compiled host code with the reference's prototypes, CLI and printed lines)
@@ -257,6 +258,7 @@ def test_harness_programs(sm, prog, args, expect):
     assert "SH FFT normal" in p.stdout or "smFFT R2C time" in p.stdout
     if prog == "FFT_multi_gpu.exe":
         assert "GPU(s), 4100 FFTs of 1024 each: job time" in p.stdout
+        assert ("exchange (not part of the job time)" in p.stdout) == (len(args) == 7)
 
 
 # ------------------------------------------- device functions called from a user kernel (examples/)
