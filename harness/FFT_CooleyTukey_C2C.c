@@ -6,32 +6,27 @@
 int GPU_smFFT_4elements(float2 *h_input, float2 *h_output, int FFT_size, int nFFTs, bool inverse, bool reorder, int nRuns, double *single_ex_time, double *multi_ex_time);
 int GPU_cuFFT(float2 *h_input, float2 *h_output, int FFT_size, int nFFTs, bool inverse, int nRuns, double *single_ex_time);
 
-int main(int argc, char* argv[]) {
-	if (argc != 6) {
-		printf("Argument error!\n");
-		printf(" 1) FFT length\n");
-		printf(" 2) number of FFTs\n");
-		printf(" 3) the number of kernel executions\n");
-		printf(" 4) do inverse FFT 1=yes 0=no\n");
-		printf(" 5) reorder elements to correct order 1=yes 0=no\n");
-		printf("For example: FFT.exe 1024 100000 20 0 1\n");
-		return 1;
-	}
-	int FFT_size = (int) strtol(argv[1], NULL, 10);
-	int nFFTs    = (int) strtol(argv[2], NULL, 10);
-	int nRuns    = (int) strtol(argv[3], NULL, 10);
-	bool inverse = strtol(argv[4], NULL, 10) == 1;
-	bool reorder = strtol(argv[5], NULL, 10) == 1;
+static const char *usage =   // the reference's text (CT/FFT.c:85-94)
+	"Argument error!\n"
+	" 1) FFT length\n"
+	" 2) number of FFTs\n"
+	" 3) the number of kernel executions\n"
+	" 4) do inverse FFT 1=yes 0=no\n"
+	" 5) reorder elements to correct order 1=yes 0=no\n"
+	"For example: FFT.exe 1024 100000 20 0 1\n";
 
-	// FFT.c:105-116 keeps the batch a multiple of the FFTs-per-block of the CUDA kernels
-	if (FFT_size == 32) {
-		printf("FFT length is 32 making sure that the number of FFTs is divisible by 4. ");
-		nFFTs = ((nFFTs + 3)/4)*4;
-		printf("New number of FFTs is %d.\n", nFFTs);
-	}
-	if (FFT_size == 64) {
-		printf("FFT length is 64 making sure that the number of FFTs is divisible by 2. ");
-		nFFTs = ((nFFTs + 1)/2)*2;
+int main(int argc, char **argv) {
+	long arg[5];
+	if (!harness_parse_ints(argc, argv, 5, arg, usage)) return 1;
+	const int FFT_size = (int) arg[0], nRuns = (int) arg[2];
+	int nFFTs = (int) arg[1];
+	const bool inverse = arg[3] == 1, reorder = arg[4] == 1;
+
+	// FFT.c:105-116 keeps the batch a multiple of the FFTs-per-block of the CUDA kernels (4 for N=32, 2 for N=64)
+	if (FFT_size == 32 || FFT_size == 64) {
+		const int per = 128/FFT_size;
+		printf("FFT length is %d making sure that the number of FFTs is divisible by %d. ", FFT_size, per);
+		nFFTs = (nFFTs + per - 1)/per*per;
 		printf("New number of FFTs is %d.\n", nFFTs);
 	}
 

@@ -6,18 +6,17 @@
 int GPU_cuFFT(float2 *h_input, float2 *h_output, int FFT_size, int nFFTs, int nRuns, double *single_ex_time);
 int GPU_FFT_C2C_Stockham(float2 *h_input, float2 *h_smFFT_output, int FFT_size, int nFFTs, int nRuns, double *single_ex_time, double *multi_ex_time);
 
-int main(int argc, char* argv[]) {
-	if (argc != 4) {
-		printf("Argument error!\n");
-		printf(" 1) FFT length\n");
-		printf(" 2) number of FFTs\n");
-		printf(" 3) the number of kernel executions\n");
-		printf("For example: FFT.exe 1024 100000 20\n");
-		return 1;
-	}
-	int FFT_size = (int) strtol(argv[1], NULL, 10);
-	int nFFTs    = (int) strtol(argv[2], NULL, 10);
-	int nRuns    = (int) strtol(argv[3], NULL, 10);
+static const char *usage =   // the reference's text (ST/FFT.c:85-92)
+	"Argument error!\n"
+	" 1) FFT length\n"
+	" 2) number of FFTs\n"
+	" 3) the number of kernel executions\n"
+	"For example: FFT.exe 1024 100000 20\n";
+
+int main(int argc, char **argv) {
+	long arg[3];
+	if (!harness_parse_ints(argc, argv, 3, arg, usage)) return 1;
+	const int FFT_size = (int) arg[0], nFFTs = (int) arg[1], nRuns = (int) arg[2];
 	size_t count = (size_t) nFFTs*FFT_size;
 	if (DEBUG) printf("FFT size: %d; Number of FFTs: %d; input size: %zu elements = %0.3f MB; output size: %zu elements = %0.3f\n", FFT_size, nFFTs, count, count*sizeof(float2)/(1024.0*1024.0), count, count*sizeof(float2)/(1024.0*1024.0));
 	if (FFT_size < 128) { printf("This FFT implementation works for N>=128.\n"); return 1; }

@@ -46,18 +46,17 @@ static int Compare_C2R_output(float *kFFT, float *vendor, int FFT_size, int nFFT
 	return nErrors;
 }
 
-int main(int argc, char* argv[]) {
-	if (argc != 4) {
-		printf("Argument error!\n");
-		printf(" 1) FFT length\n");
-		printf(" 2) number of FFTs\n");
-		printf(" 3) the number of kernel executions\n");
-		printf("For example: FFT.exe 1024 100000 20\n");
-		return 1;
-	}
-	int FFT_size = (int) strtol(argv[1], NULL, 10);
-	int nFFTs    = (int) strtol(argv[2], NULL, 10);
-	int nRuns    = (int) strtol(argv[3], NULL, 10);
+static const char *usage =   // the reference's text (RC/FFT.c:194-201)
+	"Argument error!\n"
+	" 1) FFT length\n"
+	" 2) number of FFTs\n"
+	" 3) the number of kernel executions\n"
+	"For example: FFT.exe 1024 100000 20\n";
+
+int main(int argc, char **argv) {
+	long arg[3];
+	if (!harness_parse_ints(argc, argv, 3, arg, usage)) return 1;
+	const int FFT_size = (int) arg[0], nFFTs = (int) arg[1], nRuns = (int) arg[2];
 	const int vs = (FFT_size >> 1) + 1, ks = (FFT_size >> 1);
 	if (DEBUG) printf("FFT size: %d; Number of FFTs: %d; input size = %0.3f MB; output size = %0.3f MB\n", FFT_size, nFFTs, (size_t) nFFTs*FFT_size*sizeof(float)/(1024.0*1024.0), (size_t) nFFTs*vs*sizeof(float2)/(1024.0*1024.0));
 	if (FFT_size < 128) { printf("This FFT works for N>=128.\n"); return 1; }

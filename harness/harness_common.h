@@ -125,6 +125,13 @@ static inline int Compare_data(float2 *vendor_result, float2 *smFFT_result, int 
 	return nErrors;
 }
 
+// positional integer arguments; prints `usage` and returns false unless exactly n are given
+static inline bool harness_parse_ints(int argc, char **argv, int n, long *out, const char *usage) {
+	if (argc != n + 1) { fputs(usage, stdout); return false; }
+	for (int i = 0; i < n; i++) out[i] = strtol(argv[i + 1], NULL, 10);
+	return true;
+}
+
 static inline void print_verdict(int nErrors) {   // CT/FFT.c:158-159
 	if (nErrors == 0) printf("  FFT test:\033[1;32mPASSED\033[0m\n");
 	else printf("  FFT test:\033[1;31mFAILED\033[0m\n");

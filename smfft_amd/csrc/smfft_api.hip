@@ -11,10 +11,8 @@
 
 #include "../../include/smfft.h"
 #include "../../include/smfft_reference_api.h"
-#include "debug.h"
+#include "smfft_host_util.hpp"
 #include "smfft_launch.hpp"
-#include "timer.h"
-#include "utils_hip.h"
 
 namespace {
 

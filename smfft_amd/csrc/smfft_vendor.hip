@@ -10,9 +10,7 @@
 #include <cstdio>
 
 #include "../../include/smfft_reference_api.h"
-#include "debug.h"
-#include "timer.h"
-#include "utils_hip.h"
+#include "smfft_host_util.hpp"
 
 static int vendor_c2c(float2* h_input, float2* h_output, int FFT_size, int nFFTs, bool inverse, double* single_ex_time) {
     size_t free_mem, total_mem;
