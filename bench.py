@@ -104,11 +104,45 @@ def device_info(torch, dev):
     info = {}
     try:
         p = torch.cuda.get_device_properties(dev)
-        for k in ("name", "gcnArchName", "total_memory", "multi_processor_count", "clock_rate", "memory_clock_rate", "memory_bus_width", "L2_cache_size"):
+        for k in ("name", "gcnArchName", "total_memory", "multi_processor_count", "clock_rate", "memory_clock_rate", "memory_bus_width", "L2_cache_size",
+                  "pci_domain_id", "pci_bus_id", "pci_device_id"):
             if hasattr(p, k):
                 info[k] = getattr(p, k)
     except Exception as e:   # informational only
         info["error"] = repr(e)
+    # clocks / partition modes of the first amdgpu device the driver exposes (best effort, read-only sysfs)
+    try:
+        import glob
+        want = None
+        if all(k in info for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+            want = "%04x:%02x:%02x." % (info["pci_domain_id"], info["pci_bus_id"], info["pci_device_id"])
+        for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+            try:
+                if open(os.path.join(d, "vendor")).read().strip() != "0x1002":
+                    continue
+            except OSError:
+                continue
+            bdf = os.path.basename(os.path.realpath(d))
+            if want is not None and not bdf.startswith(want):
+                continue
+            sysfs = {}
+            for name in ("current_memory_partition", "current_compute_partition", "pp_dpm_mclk", "pp_dpm_sclk", "pp_dpm_fclk",
+                         "mem_info_vram_total", "mem_info_vram_used", "power_dpm_force_performance_level"):
+                try:
+                    sysfs[name] = open(os.path.join(d, name)).read().strip().replace("\n", " | ")
+                except OSError:
+                    pass
+            for cap in glob.glob(os.path.join(d, "hwmon", "hwmon*", "power1_cap")):
+                try:
+                    sysfs["power1_cap_uW"] = open(cap).read().strip()
+                except OSError:
+                    pass
+            if sysfs:
+                sysfs["pci"] = bdf
+                info["sysfs"] = sysfs
+                break
+    except Exception as e:
+        info["sysfs_error"] = repr(e)
     return info
 
 
