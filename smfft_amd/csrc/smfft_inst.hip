@@ -19,9 +19,14 @@ int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int i
     if (count <= 0) return 0;
     dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
     if (path == 0) {
-        if (!inverse && reorder)  SMFFT_DIT_external<CT_CLASS(_forward)><<<grid, block, 0, stream>>>(d_input, d_output, count);
+#if SMFFT_N == 4096
+#define SMFFT_EXTERNAL_REORDER_KERNEL SMFFT_DIT_external_occ3
+#else
+#define SMFFT_EXTERNAL_REORDER_KERNEL SMFFT_DIT_external
+#endif
+        if (!inverse && reorder)  SMFFT_EXTERNAL_REORDER_KERNEL<CT_CLASS(_forward)><<<grid, block, 0, stream>>>(d_input, d_output, count);
         if (!inverse && !reorder) SMFFT_DIT_external<CT_CLASS(_forward_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count);
-        if (inverse && reorder)   SMFFT_DIT_external<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count);
+        if (inverse && reorder)   SMFFT_EXTERNAL_REORDER_KERNEL<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count);
         if (inverse && !reorder)  SMFFT_DIT_external<CT_CLASS(_inverse_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count);
     } else {
         if (!inverse && reorder)  SMFFT_DIT_multiple<CT_CLASS(_forward)><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
@@ -51,7 +56,12 @@ template <>
 int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int path, int grid_cap, int nreuses, hipStream_t stream) {
     if (count <= 0) return 0;
     dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
+#if SMFFT_N == 4096
+    // same transform (Engine<4096, inverse, reorder>) through the occupancy-3 build, see SMFFT_DIT_external_occ3
+    if (path == 0) SMFFT_DIT_external_occ3<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count);
+#else
     if (path == 0) FFT_GPU_external<ST_CLASS><<<grid, block, 0, stream>>>(d_input, d_output, count);
+#endif
     else           FFT_GPU_multiple<ST_CLASS><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
     return (int)hipGetLastError();
 }

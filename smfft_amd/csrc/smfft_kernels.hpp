@@ -358,6 +358,16 @@ __global__ void __launch_bounds__(256) SMFFT_DIT_external(const float2* d_input,
     __shared__ float2 s_input[const_params::fft_sm_required];
     smfft::c2c_external_body<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nFFTs, s_input);
 }
+// The same kernel compiled for exactly 3 waves per SIMD.  The launcher uses it for the N = 4096 reorder
+// transforms: their 134 VGPRs give 3 waves per SIMD either way, but with the target stated the scheduler
+// stops trading instruction-level parallelism for registers it cannot turn into a 4th wave: 5.89 -> 6.07 TB/s
+// (tools/ab_probe.py).  Every other length measured equal or worse with a stated target.
+template <class const_params>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+SMFFT_DIT_external_occ3(const float2* d_input, float2* d_output, int nFFTs) {
+    __shared__ float2 s_input[const_params::fft_sm_required];
+    smfft::c2c_external_body<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nFFTs, s_input);
+}
 
 template <class const_params>
 __global__ void SMFFT_MULT_BOUNDS SMFFT_DIT_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
