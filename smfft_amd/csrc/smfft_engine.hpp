@@ -132,6 +132,14 @@ __device__ __forceinline__ void fft_sync() {
     }
 }
 
+// One ds_read_b64 that the compiler cannot pair with a neighbour into ds_read2_b64: the element index passes
+// through an empty asm, so every read has its own address register.  (A `volatile` access would do the same but
+// is compiled to a FLAT load followed by s_waitcnt vmcnt(0): sixteen fully serialised round trips.)
+__device__ __forceinline__ float2 lds_read_single(const float2* region, int index) {
+    asm volatile("" : "+v"(index));
+    return region[index];
+}
+
 // ------------------------------------------------------------------------------------------------
 // Small in-register DFTs (R = 2, 4, 8, 16), decimation in time on compile-time indices.
 // in[k*STRIDE], k < R  ->  out[q], q < R (natural order).  DIR = 0: e^{-2 pi i/R}, 1: e^{+}.
@@ -270,6 +278,11 @@ struct Engine {
     // elements (position p at p + p/16), which makes both the write (consecutive lanes ->
     // consecutive p) and the read (lane -> its own row of 17) bank-conflict free.
     // Precondition: the region is free (earlier accesses ordered by fft_sync).
+    // PACED (external no-reorder kernels only): the read-back uses volatile generic-pointer loads, which the
+    // compiler turns into sixteen FLAT loads each followed by s_waitcnt vmcnt(0).  Slower as LDS code, but on the
+    // HBM-bound kernels this write + serialised flat read-back is exactly the "LDS trip" that raises the streaming
+    // rate by 3-8 % (smfft_kernels.hpp, lds_round_trip), so the transposition doubles as that trip.
+    template <bool PACED = false>
     __device__ __forceinline__ void to_pass1_layout(float2 (&r)[16], float2* sf) const {
         if constexpr (REORDER) {
             if constexpr (B1 > 1) {
@@ -318,11 +331,15 @@ struct Engine {
                 for (int r1 = 0; r1 < R1; ++r1) {
                     const int rb = (B1_BITS > 0) ? (int)(__brev((unsigned)b) >> (32 - (B1_BITS > 0 ? B1_BITS : 1))) : 0;
                     const int rr = (R1_BITS > 0) ? (int)(__brev((unsigned)r1) >> (32 - (R1_BITS > 0 ? R1_BITS : 1))) : 0;
-                    // volatile: keeps these as single ds_read_b64 (32-lane groups, 64 banks).  Merged
-                    // into ds_read2_b64 they are served in 16-lane groups over 32 banks, where the
-                    // rows of bit-reversed neighbours collide (measured 0.14 conflict cycles per LDS cycle).
-                    const v2f t = *reinterpret_cast<const volatile v2f*>(&sf[row + rb * R1 + rr]);
-                    r[b * R1 + r1] = make_float2(t.x, t.y);
+                    // single ds_read_b64 (32-lane groups, 64 banks): merged into ds_read2_b64 these reads are served
+                    // in 16-lane groups over 32 banks, where the rows of bit-reversed neighbours collide (measured
+                    // 0.14 conflict cycles per LDS cycle)
+                    if constexpr (PACED) {
+                        const v2f t = *reinterpret_cast<const volatile v2f*>(&sf[row + rb * R1 + rr]);
+                        r[b * R1 + r1] = make_float2(t.x, t.y);
+                    } else {
+                        r[b * R1 + r1] = lds_read_single(sf, row + rb * R1 + rr);
+                    }
                 }
             fft_sync<G::kMultiWave>();
         }
@@ -508,8 +525,9 @@ struct Engine {
     // registers (natural order, r[c] = x[u + T*c]) -> registers (r[q] = X[u + T*q]) through the
     // FFT's LDS region.
     // Precondition: every earlier LDS access of this FFT's region has been ordered by fft_sync.
+    template <bool PACED = false>
     __device__ __forceinline__ void transform(float2 (&r)[16], float2* sf) const {
-        to_pass1_layout(r, sf);
+        to_pass1_layout<PACED>(r, sf);
         pass1(r);
         if constexpr (G::kRegTwoPass) {
             float2 x[16];

@@ -90,15 +90,22 @@ __device__ __forceinline__ void lds_to_wave_chunk(float2* __restrict__ gwave, co
     }
 }
 
-// An empirical lever of the HBM-bound external kernels.  Passing the freshly loaded
-// tile once through LDS in natural order (every thread reads back exactly what it wrote) before the
-// transform makes the reorder kernels 3-8 % FASTER at every length except 1024 and 4096 (same buffers,
-// interleaved A/B, tools/ab_probe.py: N=32 5.64 -> 6.11 TB/s, 64: 5.63 -> 5.99, 128: 5.60 -> 5.95,
-// 256: 5.63 -> 5.91, 512: 5.67 -> 5.89, 2048: 5.73 -> 5.90; 1024: -0.5 %, 4096: +0.8 %), and it does the
-// same for a plain copy (SMFFT_stream_copy).  On the copy kernel a pure delay (s_sleep), holding all 16
-// loads before the first store, or the LDS allocation alone (occupancy) do NOT reproduce it, and a second
-// trip undoes it; the mechanism (how the load and store bursts of a CU's waves interleave on the way to
-// HBM) is not pinned down, so this is a per-length tuning switch like the grid cap, not a principle.
+// An empirical lever of the HBM-bound external kernels.  Writing the freshly loaded tile
+// to LDS in natural order and reading it back with VOLATILE generic-pointer loads -- which hipcc compiles to
+// sixteen flat_load_dwordx2, each followed by s_waitcnt vmcnt(0) -- before the transform makes the reorder kernels
+// 3-8 % FASTER at every length except 1024 and 4096 (same buffers, interleaved A/B, tools/ab_probe.py:
+// N=32 5.64 -> 6.11 TB/s, 64: 5.63 -> 5.99, 128: 5.60 -> 5.95, 256: 5.63 -> 5.91, 512: 5.67 -> 5.89,
+// 2048: 5.73 -> 5.90; 1024: -0.5 %, 4096: +0.8 %), and it does the same for a plain copy (SMFFT_stream_copy:
+// 5.73 -> 6.11).  What was separated on the copy kernel (tools/microbench/pacing.hip, profiles/r01_pacing.txt):
+// the same trip read back with ordinary ds_read_b64 (SMFFT_TRIP_FORM=1): nothing; serialised flat LDS loads
+// without the preceding writes: nothing; the trip over only K of the 16 registers: K=8 a third of the gain, K=12
+// most, K=16 all; all loads held before the first store, s_sleep of 512 ... 65000 cycles, the LDS allocation alone,
+// a second trip: nothing or worse.  The mechanism is not pinned down, so this is a per-length tuning switch like
+// the grid cap, not a principle.  The no-reorder kernels get the same effect from the read-back of their LDS
+// transposition (Engine::to_pass1_layout<PACED>).
+#ifndef SMFFT_TRIP_FORM
+#define SMFFT_TRIP_FORM 0
+#endif
 #ifndef SMFFT_EXTRA_TRIP
 #define SMFFT_EXTRA_TRIP 1
 #endif
@@ -110,8 +117,12 @@ __device__ __forceinline__ void lds_round_trip(float2 (&r)[16], float2* sf, int 
     fft_sync<G::kMultiWave>();
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
+#if SMFFT_TRIP_FORM == 1
+        r[c] = lds_read_single(sf, u + G::T * c);
+#else
         const v2f t = *reinterpret_cast<const volatile v2f*>(&sf[u + G::T * c]);
         r[c] = make_float2(t.x, t.y);
+#endif
     }
     fft_sync<G::kMultiWave>();
 }
@@ -121,8 +132,10 @@ __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_i
     using G = Geometry<N>;
     constexpr bool kStaged = (N <= SMFFT_STAGED_MAX_N);
     // see lds_round_trip: on for the reorder kernels of every length except 1024 and 4096
-    // (the no-reorder kernels make such a trip anyway for their transposition, except where that is done in registers)
+    // (the no-reorder kernels get the same effect from the read-back of their LDS transposition, see kPacedReads;
+    //  where that transposition is done in registers they make the explicit trip)
     constexpr bool kExtraTrip = SMFFT_EXTRA_TRIP && (REORDER || G::kRegTwoPass) && N != 1024 && N != 4096;
+    constexpr bool kPacedReads = SMFFT_EXTRA_TRIP && !REORDER && !G::kRegTwoPass && N != 4096;
     constexpr int kFftsPerWave = (N <= 1024) ? 1024 / N : 1;
     Engine<N, DIR, REORDER> eng;
     eng.init(threadIdx.x);
@@ -141,7 +154,7 @@ __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_i
             eng.load_lds(r, sf);
             fft_sync<false>();
             if constexpr (kExtraTrip) lds_round_trip<N>(r, sf, eng.u);
-            eng.transform(r, sf);
+            eng.template transform<kPacedReads>(r, sf);
             fft_sync<false>();
             eng.store_lds(r, sf);
             fft_sync<false>();
@@ -151,7 +164,7 @@ __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_i
             eng.load_global(r, d_input + (active ? f : 0) * N);
             if (G::kMultiWave) __syncthreads();   // the previous tile's exchange reads are complete
             if constexpr (kExtraTrip) lds_round_trip<N>(r, sf, eng.u);
-            eng.transform(r, sf);
+            eng.template transform<kPacedReads>(r, sf);
             eng.store_global(r, d_output + f * N, active);
         }
     }
@@ -340,8 +353,12 @@ __global__ void __launch_bounds__(256) SMFFT_stream_copy(const float2* __restric
             smfft::fft_sync<false>();
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
+#if SMFFT_TRIP_FORM == 1
+                r[c] = smfft::lds_read_single(sw, lane + 64 * c);
+#else
                 const smfft::v2f t = *reinterpret_cast<const volatile smfft::v2f*>(&sw[lane + 64 * c]);
                 r[c] = make_float2(t.x, t.y);
+#endif
             }
             smfft::fft_sync<false>();
         }

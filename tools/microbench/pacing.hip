@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(64 * WAVES) copyk(const char* __restrict__ in,
     using V = typename VecT<VEC>::type;
     constexpr int kWaveBytes = 64 * VEC * NLD;
     constexpr int kWaveElems = 64 * NLD;
-    __shared__ V s[TRIP == 1 ? WAVES * (kWaveElems + 64 * 8 / VEC) : 1];
+    __shared__ V s[(TRIP == 1 || TRIP >= 200) ? WAVES * (kWaveElems + 64 * 8 / VEC) : (TRIP >= 100 ? 64 * WAVES : 1)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     long iter = 0;
     for (long t0 = blockIdx.x; t0 < ntiles; t0 += gridDim.x, ++iter) {
@@ -53,6 +53,29 @@ __global__ void __launch_bounds__(64 * WAVES) copyk(const char* __restrict__ in,
 #pragma unroll
             for (int c = 0; c < NLD; ++c) r[c] = *reinterpret_cast<const volatile V*>(&sw[lane + 64 * c]);
             wave_sync();
+        } else if (TRIP >= 300) {
+            // TRIP = 300 + S: all loads complete, then S x s_sleep 127 (8128 cycles each), then the stores
+#pragma unroll
+            for (int c = 0; c < NLD; ++c) asm volatile("" : "+v"(r[c]));
+            for (int k = 0; k < TRIP - 300; ++k) __builtin_amdgcn_s_sleep(127);
+#pragma unroll
+            for (int c = 0; c < NLD; ++c) asm volatile("" : "+v"(r[c]));
+        } else if (TRIP >= 200) {
+            // TRIP = 200 + K: only the first K registers make the write + volatile (flat, serialised) read-back trip
+            constexpr int K = TRIP - 200;
+            V* sw = s + wave * (kWaveElems + 64 * 8 / VEC);
+#pragma unroll
+            for (int c = 0; c < K; ++c) sw[lane + 64 * c] = r[c];
+            wave_sync();
+#pragma unroll
+            for (int c = 0; c < K; ++c) r[c] = *reinterpret_cast<const volatile V*>(&sw[lane + 64 * c]);
+            wave_sync();
+        } else if (TRIP >= 100) {
+            // TRIP = 100 + K: K serialised FLAT loads from LDS (volatile generic-pointer reads: flat_load + s_waitcnt
+            // vmcnt(0) each), nothing written: the part of the "LDS trip" that turned out to matter
+            const volatile int* q = reinterpret_cast<const volatile int*>(s) + threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < TRIP - 100; ++k) (void)*q;
         } else if (TRIP == 2) {
 #pragma unroll
             for (int c = 0; c < NLD; ++c)
@@ -85,11 +108,7 @@ int main(int argc, char** argv) {
     const char* in = arena;
     char* out = arena + out_off;
     std::vector<Variant> vs = {
-        V(8, 16, 0, 4), V(8, 16, 1, 4), V(8, 16, 2, 4),
-        VM(8, 16, 0, 4, 1), VM(8, 16, 1, 4, 1), VM(8, 16, 0, 4, 2), VM(8, 16, 1, 4, 2), VM(8, 8, 0, 4, 1), VM(8, 8, 0, 4, 2),
-        V(16, 8, 0, 4), V(16, 8, 1, 4), V(16, 16, 0, 4), V(16, 16, 1, 4),
-        V(8, 32, 0, 4), V(8, 32, 1, 4), V(8, 8, 0, 4), V(8, 8, 1, 4),
-        V(8, 16, 1, 2), V(8, 16, 1, 8), V(8, 16, 0, 8), V(16, 8, 1, 8), V(8, 16, 1, 1),
+        V(8, 16, 0, 4), V(8, 16, 1, 4), V(8, 16, 301, 4), V(8, 16, 302, 4), V(8, 16, 304, 4), V(8, 16, 308, 4),
     };
     const int caps[] = {8192, 12288, 16384, 24576};
     hipEvent_t e0, e1;
