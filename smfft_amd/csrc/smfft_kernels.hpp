@@ -127,15 +127,35 @@ __device__ __forceinline__ void lds_round_trip(float2 (&r)[16], float2* sf, int 
     fft_sync<G::kMultiWave>();
 }
 
+// The ingredient of lds_round_trip that matters, alone: after the tile's global loads have arrived, K serialised
+// FLAT loads of 8 B/lane from the wave's own LDS rows, results discarded -- no LDS writes, the data registers are
+// not touched.  On the copy kernel 16 of them reproduce the whole gain (6.13 TB/s; 12: 5.98, 20: 6.05, 24: 5.94;
+// the same sixteen issued back to back with one wait: 6.0; any s_sleep: none), i.e. what helps is VMEM
+// instructions that occupy the CU's address path between a wave's loads and its stores without going to memory.
+// The FFT kernels, which already spend time between the two, want fewer: K = 8 beats the full trip by 1.3-2 % at
+// N = 256 / 512, K = 6 by 2.3 % at N = 2048 (tools/ab_all.py); N = 1024 and 4096 want none.
+template <int K>
+__device__ __forceinline__ void vmem_throttle(const float2* rows, float2 (&r)[16]) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) asm volatile("" : "+v"(r[c].x), "+v"(r[c].y));   // all global loads have arrived
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+        const float2* q = rows + (threadIdx.x & 63) + 64 * (c & 15);
+        v2f d;
+        asm volatile("flat_load_dwordx2 %0, %1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" : "=v"(d) : "v"(q) : "memory");
+    }
+}
 template <int N, int DIR, int REORDER>
 __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nFFTs, float2* s) {
     using G = Geometry<N>;
     constexpr bool kStaged = (N <= SMFFT_STAGED_MAX_N);
     // see lds_round_trip: on for the reorder kernels of every length except 1024 and 4096
-    // (the no-reorder kernels get the same effect from the read-back of their LDS transposition, see kPacedReads;
-    //  where that transposition is done in registers they make the explicit trip)
-    constexpr bool kExtraTrip = SMFFT_EXTRA_TRIP && (REORDER || G::kRegTwoPass) && N != 1024 && N != 4096;
-    constexpr bool kPacedReads = SMFFT_EXTRA_TRIP && !REORDER && !G::kRegTwoPass && N != 4096;
+    // (no-reorder kernels: N = 128 and 1024 get the same effect from a volatile read-back of their LDS transposition,
+    //  kPacedReads; where the transposition is done in registers they make the explicit trip; the others throttle)
+    constexpr bool kExtraTrip = SMFFT_EXTRA_TRIP && (REORDER || G::kRegTwoPass) && N != 1024 && N != 4096;   // staged lengths use the full trip
+    constexpr bool kPacedReads = SMFFT_EXTRA_TRIP && !REORDER && !G::kRegTwoPass && (kStaged || N == 1024);   // N=128, 1024: measured better than the throttle
+    // direct-I/O lengths: the bare throttle instead of the trip (see vmem_throttle)
+    constexpr int kThrottle = (!SMFFT_EXTRA_TRIP || kStaged || N == 1024 || N == 4096 || kPacedReads) ? 0 : (N == 2048 ? 6 : 8);
     constexpr int kFftsPerWave = (N <= 1024) ? 1024 / N : 1;
     Engine<N, DIR, REORDER> eng;
     eng.init(threadIdx.x);
@@ -163,7 +183,7 @@ __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_i
         } else {
             eng.load_global(r, d_input + (active ? f : 0) * N);
             if (G::kMultiWave) __syncthreads();   // the previous tile's exchange reads are complete
-            if constexpr (kExtraTrip) lds_round_trip<N>(r, sf, eng.u);
+            if constexpr (kThrottle > 0) vmem_throttle<kThrottle>(s + (threadIdx.x >> 6) * 1088, r);
             eng.template transform<kPacedReads>(r, sf);
             eng.store_global(r, d_output + f * N, active);
         }

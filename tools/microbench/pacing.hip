@@ -33,7 +33,8 @@ __global__ void __launch_bounds__(64 * WAVES) copyk(const char* __restrict__ in,
     using V = typename VecT<VEC>::type;
     constexpr int kWaveBytes = 64 * VEC * NLD;
     constexpr int kWaveElems = 64 * NLD;
-    __shared__ V s[(TRIP == 1 || TRIP >= 200) ? WAVES * (kWaveElems + 64 * 8 / VEC) : (TRIP >= 100 ? 64 * WAVES : 1)];
+    __shared__ V s[(TRIP == 1 || TRIP == 4 || TRIP == 5 || TRIP >= 200) ? WAVES * (kWaveElems + 64 * 8 / VEC) : (TRIP >= 100 ? 64 * WAVES : 1)];
+    static_assert(TRIP < 600 || TRIP >= 700 || true, "");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     long iter = 0;
     for (long t0 = blockIdx.x; t0 < ntiles; t0 += gridDim.x, ++iter) {
@@ -52,6 +53,70 @@ __global__ void __launch_bounds__(64 * WAVES) copyk(const char* __restrict__ in,
             wave_sync();
 #pragma unroll
             for (int c = 0; c < NLD; ++c) r[c] = *reinterpret_cast<const volatile V*>(&sw[lane + 64 * c]);
+            wave_sync();
+        } else if (TRIP >= 800 && TRIP < 1000) {
+            // TRIP = 800 + S: all loads complete, one s_sleep S (64 * S cycles), then the stores
+#pragma unroll
+            for (int c = 0; c < NLD; ++c) asm volatile("" : "+v"(r[c]));
+            __builtin_amdgcn_s_sleep(TRIP >= 800 && TRIP < 1000 ? TRIP - 800 : 0);
+#pragma unroll
+            for (int c = 0; c < NLD; ++c) asm volatile("" : "+v"(r[c]));
+        } else if (TRIP >= 700 && TRIP < 800) {
+            // TRIP = 700 + K: as 600 + K but every flat load is waited for before the next one is issued
+#pragma unroll
+            for (int c = 0; c < NLD; ++c) asm volatile("" : "+v"(r[c]));
+            V* sw = s + wave * (kWaveElems + 64 * 8 / VEC);
+            constexpr int KS = (TRIP >= 700 && TRIP < 800) ? TRIP - 700 : 1;
+#pragma unroll
+            for (int c = 0; c < KS; ++c) {
+                const V* q = &sw[lane + 64 * (c % NLD)];
+                V d;
+                asm volatile("flat_load_dwordx2 %0, %1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" : "=v"(d) : "v"(q) : "memory");
+            }
+        } else if (TRIP >= 600 && TRIP < 700) {
+            // TRIP = 600 + K: after all global loads have arrived, K FLAT loads of 8 B/lane from this wave's LDS rows
+            // (whatever is there), issued back to back, results discarded, one wait; the stored data never touch LDS
+#pragma unroll
+            for (int c = 0; c < NLD; ++c) asm volatile("" : "+v"(r[c]));
+            V* sw = s + wave * (kWaveElems + 64 * 8 / VEC);
+            constexpr int KF = (TRIP >= 600 && TRIP < 700) ? TRIP - 600 : 1;
+            V dummy[KF];
+#pragma unroll
+            for (int c = 0; c < KF; ++c) {
+                const V* q = &sw[lane + 64 * (c % NLD)];
+                asm volatile("flat_load_dwordx2 %0, %1" : "=v"(dummy[c]) : "v"(q) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < KF; ++c) asm volatile("" : : "v"(dummy[c]));
+        } else if (TRIP == 4) {
+            // LDS write, then ordinary ds_read read-back, each read waited for before the next is issued (serialised)
+            V* sw = s + wave * (kWaveElems + 64 * 8 / VEC);
+#pragma unroll
+            for (int c = 0; c < NLD; ++c) sw[lane + 64 * c] = r[c];
+            wave_sync();
+#pragma unroll
+            for (int c = 0; c < NLD; ++c) {
+                r[c] = sw[lane + 64 * c];
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[c]) : : "memory");
+            }
+            wave_sync();
+        } else if (TRIP == 5) {
+            // LDS write, then FLAT loads of the same locations issued back to back, ONE wait at the end (not serialised)
+            V* sw = s + wave * (kWaveElems + 64 * 8 / VEC);
+#pragma unroll
+            for (int c = 0; c < NLD; ++c) sw[lane + 64 * c] = r[c];
+            wave_sync();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < NLD; ++c) {
+                const V* q = &sw[lane + 64 * c];
+                if (VEC == 8) asm volatile("flat_load_dwordx2 %0, %1" : "=v"(r[c]) : "v"(q) : "memory");
+                else asm volatile("flat_load_dwordx4 %0, %1" : "=v"(r[c]) : "v"(q) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < NLD; ++c) asm volatile("" : "+v"(r[c]));
             wave_sync();
         } else if (TRIP >= 300) {
             // TRIP = 300 + S: all loads complete, then S x s_sleep 127 (8128 cycles each), then the stores
@@ -108,7 +173,7 @@ int main(int argc, char** argv) {
     const char* in = arena;
     char* out = arena + out_off;
     std::vector<Variant> vs = {
-        V(8, 16, 0, 4), V(8, 16, 1, 4), V(8, 16, 301, 4), V(8, 16, 302, 4), V(8, 16, 304, 4), V(8, 16, 308, 4),
+        V(8, 16, 0, 4), V(8, 16, 716, 4), V(8, 16, 816, 4), V(8, 16, 832, 4), V(8, 16, 848, 4), V(8, 16, 864, 4), V(8, 16, 880, 4), V(8, 16, 896, 4), V(8, 16, 920, 4),
     };
     const int caps[] = {8192, 12288, 16384, 24576};
     hipEvent_t e0, e1;
