@@ -7,15 +7,20 @@ import smfft_amd as sm
 libs = [ctypes.CDLL(os.path.abspath(p)) for p in sys.argv[1:3]]
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 var = sys.argv[4] if len(sys.argv) > 4 else "f1"
-inv, reo = int(var[0] == "i"), int(var[1] == "1")
+rc = var in ("r2c", "c2r")       # real transforms: n is the REAL length, half the bytes per FFT
+inv, reo = (int(var == "c2r"), 1) if rc else (int(var[0] == "i"), int(var[1] == "1"))
 nffts = (1 << 29) // n
-nbytes = (1 << 29) * 8
+nbytes = (1 << 29) * 8 if var not in ("r2c", "c2r") else (1 << 29) * 4
 for l in libs:
     l.smfft_ct_external_benchmark.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    l.smfft_rc_external_benchmark.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
 def t(l, i, o, k=1):
     v = ctypes.c_double(0)
     for _ in range(k):
-        l.smfft_ct_external_benchmark(i, o, n, nffts, inv, reo, ctypes.byref(v))
+        if rc:
+            l.smfft_rc_external_benchmark(i, o, n, nffts, inv, ctypes.byref(v))
+        else:
+            l.smfft_ct_external_benchmark(i, o, n, nffts, inv, reo, ctypes.byref(v))
     return v.value / k
 pa, pb = ctypes.c_void_p(), ctypes.c_void_p()
 assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(pa), ctypes.byref(pb)) == 0   # placement-probed pair
