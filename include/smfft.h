@@ -132,7 +132,9 @@ void* smfft_malloc(unsigned long long bytes);
  * faster than streams that share a region.  For buffers of 1 to 16 GiB, when
  * the device has the room, both are carved out of one arena (32 to 96 GiB) and the (input, output)
  * offsets are chosen on an 8 GiB lattice by timing a stream copy of the whole buffers per candidate
- * pair (a few hundred ms in total for 4 GiB buffers).
+ * pair; when the memory allows, a second arena is allocated and scanned while the first is alive (different physical
+ * memory: on part of the boxes some regions stream another 6 % faster) and the better one is kept; SMFFT_ONE_ARENA
+ * disables that.  About 0.7 s in total for 4 GiB buffers.
  * Falls back to two plain allocations (also with SMFFT_NO_PAIR_PLACEMENT set).  The L3 wrappers use
  * it.  Release with smfft_free_pair(d_read). */
 int smfft_malloc_pair(unsigned long long bytes, void** d_read, void** d_written);
