@@ -200,11 +200,11 @@ def main():
     # CT:850-853).  Measured (tools/alloc_probe.py): writing into a 4 GiB block of torch's caching
     # allocator is 6-7 % slower than into a hipMalloc'ed one (1.53 vs 1.43 ms per launch).
     nbytes = nffts * n * 8
-    # Buffer placement (profiles/r01_placement_map.txt): on MI355X a kernel that
-    # reads one buffer and writes another streams 6-8 % faster when the two addresses differ in bit 35
-    # (32 GiB interleave) than when they sit on the same side.  smfft_malloc_pair() -- the allocator the
-    # library's own L3 wrappers use -- carves both out of one arena, 32 GiB apart.  For transparency the
-    # same-side alternative (output 4 GiB after the input, inside the arena's spacer) is timed as well.
+    # Buffer placement (profiles/r01_chunk_map.txt): on MI355X the rate of a kernel that reads
+    # one buffer and writes another depends on which physical memory the two are (1.31 ... 1.55 ms for this batch).
+    # smfft_malloc_pair() -- the allocator the library's own L3 wrappers use -- allocates buffer-sized chunks over
+    # the free memory, times candidate (input, output) pairs with a stream copy and keeps the fastest.  For
+    # transparency the same launches are also timed on two plain allocations.
     pa, pb = ctypes.c_void_p(), ctypes.c_void_p()
     if sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(pa), ctypes.byref(pb)) != 0:
         raise SystemExit("smfft_malloc_pair failed")
@@ -230,11 +230,18 @@ def main():
         torch.cuda.synchronize(dev)
         return e0.elapsed_time(e1) / 8
 
-    off_gib = (b_out.ptr - b_in.ptr) / float(1 << 30)
-    in_arena = abs(off_gib) <= 96 and float(off_gib).is_integer()
-    adjacent = b_in.ptr + nbytes if off_gib >= 2 * nbytes / float(1 << 30) else (b_in.ptr - nbytes if off_gib <= -2 * nbytes / float(1 << 30) else None)
-    placement = {"output_minus_input_GiB": off_gib if in_arena else None, "paired_ms": round(_probe(b_in.ptr, b_out.ptr), 4),
-                 "adjacent_ms": round(_probe(b_in.ptr, adjacent), 4) if in_arena and adjacent is not None and off_gib > 0 else None}
+    # placement telemetry: the same launches on two plain allocations (what two hipMalloc calls give a caller who does
+    # not use smfft_malloc_pair), made after the pair and released again
+    plain_ms = None
+    try:
+        p_in, p_out = sm.DeviceBuffer(nbytes), sm.DeviceBuffer(nbytes)
+        sm.lib.smfft_memset(p_in.ptr, 0, nbytes)
+        plain_ms = round(_probe(p_in.ptr, p_out.ptr), 4)
+        p_in.free()
+        p_out.free()
+    except MemoryError:
+        pass
+    placement = {"paired_ms": round(_probe(b_in.ptr, b_out.ptr), 4), "plain_hipmalloc_ms": plain_ms}
 
     class _Ptr:                      # tiny adaptor so the rest of the script reads like tensor code
         def __init__(self, buf):

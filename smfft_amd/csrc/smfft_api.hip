@@ -95,39 +95,38 @@ int timed(F&& launch, double* FFT_time) {
 }
 
 // ---- paired allocation ----------------------------------------------------------------------------
-// Measured on MI355X (profiles/r01_placement_map.txt, tools/placement_map.py): the streaming rate of
-// a kernel that reads one buffer and writes another depends on bit 35 of the two (physical) addresses.
-// Read and write streams on the same side of that 32 GiB interleave run 6-8 % slower (1.53 vs
-// 1.44 ms for the 4 GiB + 4 GiB N=1024 batch) than streams on opposite sides.  With 288 GB of HBM the
-// library can afford to carve both buffers out of ONE arena, exactly 32 GiB apart, so that byte x of
-// the input and byte x of the output always sit on opposite sides whatever the arena's base is.
+// Measured on MI355X (profiles/r01_chunk_map.txt, tools/chunk_map.py): the streaming rate of a kernel that
+// reads one buffer and writes another depends on WHICH physical memory the two buffers are.  Separately
+// allocated chunks fall into a few classes; input and output in the same class run the 4 GiB + 4 GiB N=1024
+// batch in 1.51-1.55 ms, in different classes in 1.41-1.46 ms, and on most boxes one region (often the memory
+// allocated last) is faster still as a WRITE target: 1.31-1.39 ms with any input -- while reading from it is slow
+// (1.49-1.53 ms).  None of this is visible in the virtual addresses, so nothing is assumed: smfft_malloc_pair
+// allocates as many buffer-sized chunks as the device has room for, times the external kernels' own access shape
+// (the stream-copy kernel) from a reference chunk into every other chunk, then from every chunk into the best
+// output, keeps the fastest (input, output) and frees the rest.  With 288 GB of HBM that is about 66 candidates
+// for 4 GiB buffers and 4-5 s, nearly all of it hipMalloc / hipFree time.
 struct PairRec { void* a; void* b; void* arena; };
 PairRec g_pairs[64];
 std::mutex g_pairs_mutex;   // the table is shared by the per-GPU host threads of a multi-GPU driver
 
-// mean ms of a few stream-copy launches (the external kernels' access shape) over the whole buffers:
-// a window shorter than the buffers can sit entirely on one side of a region boundary they cross
-float probe_copy_ms(const void* in, void* out, size_t bytes) {
+// mean ms of a few stream-copy launches (the external kernels' access shape) over the whole buffers
+float probe_copy_ms(const void* in, void* out, size_t bytes, int launches) {
     const long n = (long)(bytes / 8 / 4096 * 4096);
     if (n <= 0) return 0.f;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 0.f;
-    for (int i = 0; i < 2; ++i) smfft::launch_stream_copy((const float2*)in, (float2*)out, n, 12288, 0);
+    smfft::launch_stream_copy((const float2*)in, (float2*)out, n, 12288, 0);
     (void)hipEventRecord(e0, 0);
-    for (int i = 0; i < 5; ++i) smfft::launch_stream_copy((const float2*)in, (float2*)out, n, 12288, 0);
+    for (int i = 0; i < launches; ++i) smfft::launch_stream_copy((const float2*)in, (float2*)out, n, 12288, 0);
     (void)hipEventRecord(e1, 0);
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    return ms / 5;
+    return ms / launches;
 }
 
-// Which offsets land on "opposite sides" differs from allocation to allocation (the fast region
-// started 24, 32 or 64 GiB after the input in different runs of tools/placement_map.py), so nothing
-// is assumed: (input, output) windows on an 8 GiB lattice inside one arena are each timed with a
-// short stream copy (about 3 ms per candidate pair) and the fastest pair wins.
 void set_pair(int slot, PairRec rec) {
     if (slot < 0) return;
     std::lock_guard<std::mutex> lock(g_pairs_mutex);
@@ -142,54 +141,46 @@ int alloc_pair(size_t bytes, void** d_a, void** d_b) {
         std::lock_guard<std::mutex> lock(g_pairs_mutex);
         for (int i = 0; i < 64; ++i) if (!g_pairs[i].a) { slot = i; g_pairs[i].a = (void*)&g_pairs[i]; break; }   // reserved
     }
-    const bool want_arena = getenv("SMFFT_NO_PAIR_PLACEMENT") == nullptr;
-    if (want_arena && slot >= 0 && bytes >= (1ull << 30) && bytes <= (16ull << 30) && hipMemGetInfo(&free_mem, &total_mem) == hipSuccess) {
-        // up to 96 GiB of arena when the device is mostly empty (more candidate pairs), else 32 or 64
-        const unsigned long long g = 1ull << 30;
-        const unsigned long long span = (free_mem > 160 * g) ? 96 * g : (free_mem > 100 * g) ? 64 * g : 32 * g;
-        // candidate (input offset, output offset) pairs on an 8 GiB lattice; input at 0, 32 or 64 GiB
-        auto scan = [&](void* arena, unsigned long long& best_in, unsigned long long& best_out) {
-            float best_ms = 1e30f;
-            best_in = 0; best_out = span;
-            for (unsigned long long in_off = 0; in_off <= span; in_off += 32 * g) {
-                for (unsigned long long out_off = 0; out_off <= span; out_off += 8 * g) {
-                    const unsigned long long lo = in_off < out_off ? in_off : out_off, hi = in_off < out_off ? out_off : in_off;
-                    if (hi - lo < bytes) continue;                       // overlapping windows
-                    const float ms = probe_copy_ms((char*)arena + in_off, (char*)arena + out_off, bytes);
-                    if (ms > 0.f && ms < best_ms) { best_ms = ms; best_in = in_off; best_out = out_off; }
+    const bool want_search = getenv("SMFFT_NO_PAIR_PLACEMENT") == nullptr;
+    if (want_search && slot >= 0 && bytes >= (1ull << 30) && bytes <= (16ull << 30) && hipMemGetInfo(&free_mem, &total_mem) == hipSuccess) {
+        // candidates of at least 4 GiB so that about 70 of them cover the whole memory (hipMalloc + hipFree cost
+        // about 15 ms per GiB whatever the chunk size: ~4 s for 288 GB; SMFFT_PAIR_SEARCH_CHUNKS=k stops after k
+        // candidates, e.g. 12 = 0.6 s, which still separates the two common classes but rarely reaches the fast
+        // write region)
+        constexpr int kMaxChunks = 72;
+        void* chunk[kMaxChunks];
+        int n = 0, limit = kMaxChunks;
+        if (const char* e = getenv("SMFFT_PAIR_SEARCH_CHUNKS")) limit = atoi(e) < 2 ? 2 : (atoi(e) > kMaxChunks ? kMaxChunks : atoi(e));
+        const size_t reserve = 6ull << 30;   // left to the rest of the application while the search runs
+        const size_t chunk_bytes = bytes > (4ull << 30) ? bytes : (4ull << 30);
+        while (n < limit && hipMemGetInfo(&free_mem, &total_mem) == hipSuccess && free_mem > chunk_bytes + reserve
+               && hipMalloc(&chunk[n], chunk_bytes) == hipSuccess) ++n;
+        (void)hipGetLastError();
+        if (n >= 2) {
+            int best_in = 0, best_out = 1;
+            if (n > 2) {
+                const int ref = n / 2;
+                float best = 1e30f;
+                for (int j = 0; j < n; ++j) {          // best write target for a reference input
+                    if (j == ref) continue;
+                    const float ms = probe_copy_ms(chunk[ref], chunk[j], bytes, 3);
+                    if (ms > 0.f && ms < best) { best = ms; best_out = j; }
+                }
+                best = 1e30f;
+                for (int i = 0; i < n; ++i) {          // best input for that target
+                    if (i == best_out) continue;
+                    const float ms = probe_copy_ms(chunk[i], chunk[best_out], bytes, 3);
+                    if (ms > 0.f && ms < best) { best = ms; best_in = i; }
                 }
             }
-            return best_ms;
-        };
-        void* arena = nullptr;
-        if (free_mem > span + bytes + 4 * g && hipMalloc(&arena, span + bytes) == hipSuccess) {
-            unsigned long long best_in = 0, best_out = 0;
-            float best_ms = scan(arena, best_in, best_out);
-            // A second arena, allocated while the first is alive so that it is different physical memory.  On part
-            // of the boxes some regions hold (input, output) pairs that stream another 6 % faster than the usual fast
-            // class (config 2 at 1.34 instead of 1.42 ms; tools/arena_lottery.py: first arena best 1.416 ms, second
-            // 1.339 ms with 6 of 36 pairs below 1.38), and which regions is not predictable: the better arena stays.
-            void* arena2 = nullptr;
-            size_t free_now = 0;
-            if (getenv("SMFFT_ONE_ARENA") == nullptr && hipMemGetInfo(&free_now, &total_mem) == hipSuccess && free_now > span + bytes + 8 * g
-                && hipMalloc(&arena2, span + bytes) == hipSuccess) {
-                unsigned long long in2 = 0, out2 = 0;
-                const float ms2 = scan(arena2, in2, out2);
-                if (ms2 < best_ms) {
-                    (void)hipFree(arena);
-                    arena = arena2; best_ms = ms2; best_in = in2; best_out = out2;
-                } else {
-                    (void)hipFree(arena2);
-                }
-            } else {
-                (void)hipGetLastError();
-            }
-            *d_a = (char*)arena + best_in;
-            *d_b = (char*)arena + best_out;
-            set_pair(slot, {*d_a, *d_b, arena});
+            for (int i = 0; i < n; ++i)
+                if (i != best_in && i != best_out) (void)hipFree(chunk[i]);
+            *d_a = chunk[best_in];
+            *d_b = chunk[best_out];
+            set_pair(slot, {*d_a, *d_b, nullptr});
             return 0;
         }
-        (void)hipGetLastError();
+        if (n == 1) (void)hipFree(chunk[0]);
     }
     if (hipMalloc(d_a, bytes) != hipSuccess) { set_pair(slot, {nullptr, nullptr, nullptr}); return 1; }
     if (hipMalloc(d_b, bytes) != hipSuccess) { (void)hipFree(*d_a); *d_a = nullptr; set_pair(slot, {nullptr, nullptr, nullptr}); return 1; }

@@ -393,7 +393,7 @@ def test_beyond_32bit_element_index(sm, oracle_lib):
 
 
 def test_malloc_pair(sm):
-    """smfft_malloc_pair: two usable buffers; 32 GiB apart in one arena when the device has room."""
+    """smfft_malloc_pair: two usable, disjoint buffers chosen by the placement search; everything else is released."""
     import ctypes
     a, b = ctypes.c_void_p(), ctypes.c_void_p()
     nbytes = 1 << 30                       # >= 1 GiB: the placement search is active
@@ -407,6 +407,8 @@ def test_malloc_pair(sm):
     sm.lib.smfft_memcpy_d2h(got.ctypes.data, b.value, x.nbytes)
     ref.assert_close_fp32(got, ref.ct_c2c(x, False, True), "paired buffers")
     assert sm.lib.smfft_free_pair(a.value) == 0
+    big = sm.DeviceBuffer(200 << 30)        # the candidates of the search are gone: most of the memory is allocatable again
+    big.free()
 
 
 @pytest.mark.parametrize("n", [32, 1024, 4096])
