@@ -278,7 +278,7 @@ struct Engine {
     // elements (position p at p + p/16), which makes both the write (consecutive lanes ->
     // consecutive p) and the read (lane -> its own row of 17) bank-conflict free.
     // Precondition: the region is free (earlier accesses ordered by fft_sync).
-    // PACED (external no-reorder kernels of N = 128 and 1024 only): the read-back uses volatile generic-pointer loads, which the
+    // PACED (external no-reorder kernel of N = 128 only): the read-back uses volatile generic-pointer loads, which the
     // compiler turns into sixteen FLAT loads each followed by s_waitcnt vmcnt(0).  Slower as LDS code, but on the
     // HBM-bound kernels this write + serialised flat read-back is exactly the "LDS trip" that raises the streaming
     // rate by 3-8 % (smfft_kernels.hpp, lds_round_trip), so the transposition doubles as that trip.

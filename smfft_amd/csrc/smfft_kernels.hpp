@@ -150,10 +150,12 @@ __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_i
     using G = Geometry<N>;
     constexpr bool kStaged = (N <= SMFFT_STAGED_MAX_N);
     // see lds_round_trip: on for the reorder kernels of every length except 1024 and 4096
-    // (no-reorder kernels: N = 128 and 1024 get the same effect from a volatile read-back of their LDS transposition,
+    // (no-reorder kernels: N = 128 gets the same effect from a volatile read-back of its LDS transposition,
     //  kPacedReads; where the transposition is done in registers they make the explicit trip; the others throttle)
     constexpr bool kExtraTrip = SMFFT_EXTRA_TRIP && (REORDER || G::kRegTwoPass) && N != 1024 && N != 4096;   // staged lengths use the full trip
-    constexpr bool kPacedReads = SMFFT_EXTRA_TRIP && !REORDER && !G::kRegTwoPass && (kStaged || N == 1024);   // N=128, 1024: measured better than the throttle
+    // N = 128 only.  (N = 1024 no-reorder: +1 % with it on ordinary placements, -5 % on a smfft_malloc_pair placement,
+    //  where none of the pacing forms matters any more: off.)
+    constexpr bool kPacedReads = SMFFT_EXTRA_TRIP && !REORDER && !G::kRegTwoPass && kStaged;
     // direct-I/O lengths: the bare throttle instead of the trip (see vmem_throttle)
     constexpr int kThrottle = (!SMFFT_EXTRA_TRIP || kStaged || N == 1024 || N == 4096 || kPacedReads) ? 0 : (N == 2048 ? 6 : 8);
     constexpr int kFftsPerWave = (N <= 1024) ? 1024 / N : 1;

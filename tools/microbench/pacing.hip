@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
 #include <vector>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
@@ -71,7 +73,8 @@ __global__ void __launch_bounds__(64 * WAVES) copyk(const char* __restrict__ in,
             for (int c = 0; c < KS; ++c) {
                 const V* q = &sw[lane + 64 * (c % NLD)];
                 V d;
-                asm volatile("flat_load_dwordx2 %0, %1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" : "=v"(d) : "v"(q) : "memory");
+                if (VEC == 8) asm volatile("flat_load_dwordx2 %0, %1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" : "=v"(d) : "v"(q) : "memory");
+                else asm volatile("flat_load_dwordx4 %0, %1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" : "=v"(d) : "v"(q) : "memory");
             }
         } else if (TRIP >= 600 && TRIP < 700) {
             // TRIP = 600 + K: after all global loads have arrived, K FLAT loads of 8 B/lane from this wave's LDS rows
@@ -84,7 +87,8 @@ __global__ void __launch_bounds__(64 * WAVES) copyk(const char* __restrict__ in,
 #pragma unroll
             for (int c = 0; c < KF; ++c) {
                 const V* q = &sw[lane + 64 * (c % NLD)];
-                asm volatile("flat_load_dwordx2 %0, %1" : "=v"(dummy[c]) : "v"(q) : "memory");
+                if (VEC == 8) asm volatile("flat_load_dwordx2 %0, %1" : "=v"(dummy[c]) : "v"(q) : "memory");
+                else asm volatile("flat_load_dwordx4 %0, %1" : "=v"(dummy[c]) : "v"(q) : "memory");
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -166,14 +170,28 @@ void launch(const char* in, char* out, long nbytes, int cap) {
 
 int main(int argc, char** argv) {
     const long nbytes = 4L << 30;
-    const long out_off = (argc > 1 ? atol(argv[1]) : 40) << 30;
-    char* arena;
-    CK(hipMalloc(&arena, out_off + nbytes));
-    CK(hipMemset(arena, 1, nbytes));
-    const char* in = arena;
-    char* out = arena + out_off;
+    long out_off = (argc > 1 ? atol(argv[1]) : 40) << 30;
+    const char* in;
+    char* out;
+    if (argc > 1 && !strcmp(argv[1], "pair")) {
+        // buffers from the library's placement search (run from the repository root)
+        void* lib = dlopen("smfft_amd/libsmfft_amd.so", RTLD_NOW);
+        if (!lib) { printf("dlopen failed: %s\n", dlerror()); return 1; }
+        auto pair = (int (*)(unsigned long long, void**, void**))dlsym(lib, "smfft_malloc_pair");
+        void *a, *b;
+        if (!pair || pair((unsigned long long)nbytes, &a, &b) != 0) { printf("smfft_malloc_pair failed\n"); return 1; }
+        in = (const char*)a; out = (char*)b; out_off = 0;
+        CK(hipMemset(a, 1, nbytes));
+    } else {
+        char* arena;
+        CK(hipMalloc(&arena, out_off + nbytes));
+        CK(hipMemset(arena, 1, nbytes));
+        in = arena;
+        out = arena + out_off;
+    }
     std::vector<Variant> vs = {
-        V(8, 16, 0, 4), V(8, 16, 716, 4), V(8, 16, 816, 4), V(8, 16, 832, 4), V(8, 16, 848, 4), V(8, 16, 864, 4), V(8, 16, 880, 4), V(8, 16, 896, 4), V(8, 16, 920, 4),
+        V(8, 16, 0, 4), V(8, 16, 1, 4), V(8, 16, 708, 4), V(8, 16, 712, 4), V(8, 16, 716, 4), V(8, 16, 720, 4),
+        V(8, 8, 0, 4), V(8, 8, 708, 4), V(16, 8, 0, 4), V(16, 8, 708, 4), V(16, 16, 0, 4), V(16, 16, 716, 4), V(8, 32, 0, 4), V(8, 32, 716, 4),
     };
     const int caps[] = {8192, 12288, 16384, 24576};
     hipEvent_t e0, e1;
