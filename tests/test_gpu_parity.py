@@ -411,6 +411,30 @@ def test_malloc_pair(sm):
     big.free()
 
 
+def test_malloc_pair_search_controls(sm, monkeypatch):
+    """SMFFT_PAIR_SEARCH_CHUNKS caps the placement search, SMFFT_NO_PAIR_PLACEMENT turns it off; either way the pair is
+    usable and freed cleanly (a second full-size pair can be made afterwards)."""
+    import ctypes
+    import time
+    nbytes = 2 << 30
+    took = {}
+    for name, env in (("capped", {"SMFFT_PAIR_SEARCH_CHUNKS": "4"}), ("off", {"SMFFT_NO_PAIR_PLACEMENT": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        t0 = time.perf_counter()
+        assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
+        took[name] = time.perf_counter() - t0
+        assert a.value and b.value and abs(b.value - a.value) >= nbytes
+        assert sm.lib.smfft_memset(a.value, 0, nbytes) == 0 and sm.lib.smfft_memset(b.value, 0, nbytes) == 0
+        rc, ms = sm.FFT_external_benchmark(a.value, b.value, 1024, nbytes // (1024 * 8))
+        assert rc == 0 and ms > 0
+        assert sm.lib.smfft_free_pair(a.value) == 0
+        for k in env:
+            monkeypatch.delenv(k)
+    assert took["off"] < 1.0 and took["capped"] < 3.0, took
+
+
 @pytest.mark.parametrize("n", [32, 1024, 4096])
 def test_config3_full_batch_multiple_path(sm, oracle_lib, n):
     """Config 3 at the README batch (2^29/N FFTs, 4 GiB buffers), in-LDS `multiple` path:
