@@ -138,6 +138,10 @@ void* smfft_malloc(unsigned long long bytes);
  * allocations).  The L3 wrappers use it.  Release with smfft_free_pair(d_read). */
 int smfft_malloc_pair(unsigned long long bytes, void** d_read, void** d_written);
 int smfft_free_pair(void* d_read);
+/* smfft_free_pair keeps the most recently released SEARCHED pair (its two candidates, >= 8 GiB of device memory) for the
+ * next smfft_malloc_pair on the same device that fits into it, because finding one costs seconds; this call (or
+ * SMFFT_NO_PAIR_CACHE in the environment) gives the memory back. */
+int smfft_pair_cache_release(void);
 int smfft_free(void* d_ptr);
 int smfft_memcpy_h2d(void* d_dst, const void* h_src, unsigned long long bytes);
 int smfft_memcpy_d2h(void* h_dst, const void* d_src, unsigned long long bytes);

@@ -57,6 +57,7 @@ _SIGS = {
     "smfft_malloc": (_vp, [_ull]),
     "smfft_malloc_pair": (_i, [_ull, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "smfft_free_pair": (_i, [_vp]),
+    "smfft_pair_cache_release": (_i, []),
     "smfft_free": (_i, [_vp]),
     "smfft_memcpy_h2d": (_i, [_vp, _vp, _ull]),
     "smfft_memcpy_d2h": (_i, [_vp, _vp, _ull]),

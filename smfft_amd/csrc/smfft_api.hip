@@ -105,8 +105,9 @@ int timed(F&& launch, double* FFT_time) {
 // (the stream-copy kernel) from a reference chunk into every other chunk, then from every chunk into the best
 // output, keeps the fastest (input, output) and frees the rest.  With 288 GB of HBM that is about 66 candidates
 // for 4 GiB buffers and 4-5 s, nearly all of it hipMalloc / hipFree time.
-struct PairRec { void* a; void* b; void* arena; };
+struct PairRec { void* a; void* b; size_t searched; int device; };   // searched: candidate size of a placement search, 0 = plain pair
 PairRec g_pairs[64];
+PairRec g_pair_cache = {nullptr, nullptr, 0, -1};   // the last searched pair that was released (see free_pair)
 std::mutex g_pairs_mutex;   // the table is shared by the per-GPU host threads of a multi-GPU driver
 
 // mean ms of a few stream-copy launches (the external kernels' access shape) over the whole buffers
@@ -142,6 +143,18 @@ int alloc_pair(size_t bytes, void** d_a, void** d_b) {
         for (int i = 0; i < 64; ++i) if (!g_pairs[i].a) { slot = i; g_pairs[i].a = (void*)&g_pairs[i]; break; }   // reserved
     }
     const bool want_search = getenv("SMFFT_NO_PAIR_PLACEMENT") == nullptr;
+    int device = -1;
+    (void)hipGetDevice(&device);
+    if (want_search && slot >= 0) {   // a searched pair released earlier on this device that is large enough: no new search
+        std::lock_guard<std::mutex> lock(g_pairs_mutex);
+        if (g_pair_cache.a && g_pair_cache.device == device && g_pair_cache.searched >= bytes) {
+            g_pairs[slot] = g_pair_cache;
+            *d_a = g_pair_cache.a;
+            *d_b = g_pair_cache.b;
+            g_pair_cache = {nullptr, nullptr, 0, -1};
+            return 0;
+        }
+    }
     if (want_search && slot >= 0 && bytes >= (1ull << 30) && bytes <= (16ull << 30) && hipMemGetInfo(&free_mem, &total_mem) == hipSuccess) {
         // candidates of at least 4 GiB so that about 70 of them cover the whole memory (hipMalloc + hipFree cost
         // about 15 ms per GiB whatever the chunk size: ~4 s for 288 GB; SMFFT_PAIR_SEARCH_CHUNKS=k stops after k
@@ -177,31 +190,50 @@ int alloc_pair(size_t bytes, void** d_a, void** d_b) {
                 if (i != best_in && i != best_out) (void)hipFree(chunk[i]);
             *d_a = chunk[best_in];
             *d_b = chunk[best_out];
-            set_pair(slot, {*d_a, *d_b, nullptr});
+            set_pair(slot, {*d_a, *d_b, n > 2 ? chunk_bytes : 0, device});
             return 0;
         }
         if (n == 1) (void)hipFree(chunk[0]);
     }
-    if (hipMalloc(d_a, bytes) != hipSuccess) { set_pair(slot, {nullptr, nullptr, nullptr}); return 1; }
-    if (hipMalloc(d_b, bytes) != hipSuccess) { (void)hipFree(*d_a); *d_a = nullptr; set_pair(slot, {nullptr, nullptr, nullptr}); return 1; }
-    set_pair(slot, {*d_a, *d_b, nullptr});
+    if (hipMalloc(d_a, bytes) != hipSuccess) { set_pair(slot, {nullptr, nullptr, 0, -1}); return 1; }
+    if (hipMalloc(d_b, bytes) != hipSuccess) { (void)hipFree(*d_a); *d_a = nullptr; set_pair(slot, {nullptr, nullptr, 0, -1}); return 1; }
+    set_pair(slot, {*d_a, *d_b, 0, device});
     return 0;
 }
 
+// A searched pair costs seconds to find, so the most recently released one is kept (8 GiB or more of device memory)
+// for the next smfft_malloc_pair of this device that fits into it -- the L3 wrappers are typically called several
+// times in a row -- until smfft_pair_cache_release() or a newer searched pair replaces it.
 int free_pair(void* d_a) {
-    PairRec rec = {nullptr, nullptr, nullptr};
+    PairRec rec = {nullptr, nullptr, 0, -1}, evicted = {nullptr, nullptr, 0, -1};
     {
         std::lock_guard<std::mutex> lock(g_pairs_mutex);
         for (int i = 0; i < 64; ++i) {
             if (g_pairs[i].a == d_a && d_a) {
                 rec = g_pairs[i];
-                g_pairs[i] = {nullptr, nullptr, nullptr};
+                g_pairs[i] = {nullptr, nullptr, 0, -1};
                 break;
             }
         }
+        if (rec.a && rec.searched && getenv("SMFFT_NO_PAIR_CACHE") == nullptr) {
+            evicted = g_pair_cache;
+            g_pair_cache = rec;
+            rec = evicted;          // free the previous occupant (possibly nothing) instead
+            if (!rec.a) return 0;
+        }
     }
     if (!rec.a) return (int)hipFree(d_a);
-    if (rec.arena) return (int)hipFree(rec.arena);
+    return (int)hipFree(rec.a) | (int)hipFree(rec.b);
+}
+
+int release_pair_cache() {
+    PairRec rec;
+    {
+        std::lock_guard<std::mutex> lock(g_pairs_mutex);
+        rec = g_pair_cache;
+        g_pair_cache = {nullptr, nullptr, 0, -1};
+    }
+    if (!rec.a) return 0;
     return (int)hipFree(rec.a) | (int)hipFree(rec.b);
 }
 
@@ -486,6 +518,7 @@ const char* smfft_version(void) { return "smfft_amd 0.1 (gfx950)"; }
 
 int smfft_malloc_pair(unsigned long long bytes, void** d_read, void** d_written) { read_env(); return alloc_pair((size_t)bytes, d_read, d_written); }
 int smfft_free_pair(void* d_read) { return free_pair(d_read); }
+int smfft_pair_cache_release(void) { return release_pair_cache(); }
 void* smfft_malloc(unsigned long long bytes) { void* p = nullptr; return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr; }
 int smfft_free(void* d_ptr) { return (int)hipFree(d_ptr); }
 int smfft_memcpy_h2d(void* d_dst, const void* h_src, unsigned long long bytes) { return (int)hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice); }

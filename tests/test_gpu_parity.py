@@ -409,6 +409,15 @@ def test_malloc_pair(sm):
     assert sm.lib.smfft_free_pair(a.value) == 0
     big = sm.DeviceBuffer(200 << 30)        # the candidates of the search are gone: most of the memory is allocatable again
     big.free()
+    # the released searched pair is kept for the next request that fits into it: same pointers, no second search
+    import time
+    a2, b2 = ctypes.c_void_p(), ctypes.c_void_p()
+    t0 = time.perf_counter()
+    assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(a2), ctypes.byref(b2)) == 0
+    assert time.perf_counter() - t0 < 0.5 and (a2.value, b2.value) == (a.value, b.value)
+    assert sm.lib.smfft_free_pair(a2.value) == 0
+    assert sm.lib.smfft_pair_cache_release() == 0
+    assert sm.lib.smfft_pair_cache_release() == 0   # idempotent
 
 
 def test_malloc_pair_search_controls(sm, monkeypatch):
