@@ -271,6 +271,65 @@ __device__ __forceinline__ void hermitian_pass(float2* sf, int u) {
     }
 }
 
+// The same split / merge on the NATURAL REGISTER layout (r[q] = element u + T*q of the thread's FFT), for FFTs that
+// live in one wave (L <= 1024).  Element i pairs with L - i, which thread (T - u) mod T holds in register 15 - q
+// (thread 0 pairs with itself, register 16 - q): one ds_bpermute per dword fetches it -- no LDS memory, no
+// barrier -- and the ONE formula  out[i] = H1 + W^i * H2,  A = x[i], B = x[L - i],  covers both halves (for L - i it
+// evaluates to the conjugate expression the LDS version writes there, RC:302-308).  W^i = W^u * W_32^q: one table
+// value per thread and 15 constants.  Replaces store_lds + hermitian_pass + load_lds (4 LDS passes, 3 syncs) in the
+// external kernels where that measured faster.
+#ifndef SMFFT_RC_REGISTERS
+#define SMFFT_RC_REGISTERS 1
+#endif
+template <int L, int DIR>
+struct HermitianRegisters {
+    static constexpr int T = L / 16;
+    // used by the external kernels of real N = 1024 and 2048 (measured: 2048 R2C +2.6 %, C2R +3.0 %; 1024 0 / +1.8 %;
+    // 512 -1.8 / -0.7 %: LDS form there; in-LDS path 1-5 % slower with it: LDS form there too)
+    static constexpr bool kEnabled = SMFFT_RC_REGISTERS && (L == 512 || L == 1024);
+    float2 wu;          // W_{2L}^u (conjugated for DIR = 1)
+    int partner_addr;   // byte address of the partner lane for ds_bpermute
+    bool first;         // u == 0
+    __device__ __forceinline__ void init(int tid) {
+        const int u = tid % T, lane = tid & 63;
+        first = (u == 0);
+        partner_addr = 4 * ((lane - u) + ((T - u) % T));
+        wu = twiddle<DIR>(u * (4096 / (2 * L)));
+    }
+    __device__ __forceinline__ void apply(float2 (&r)[16]) const {
+        constexpr float c32[16] = {1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f, 0.55557023301960229f,
+                                   0.38268343236508984f, 0.19509032201612833f, 0.f, -0.19509032201612819f, -0.38268343236508973f, -0.55557023301960196f,
+                                   -0.70710678118654746f, -0.83146961230254535f, -0.92387953251128674f, -0.98078528040323043f};
+        constexpr float s32[16] = {0.f, 0.19509032201612825f, 0.38268343236508978f, 0.55557023301960218f, 0.70710678118654746f, 0.83146961230254524f,
+                                   0.92387953251128674f, 0.98078528040323043f, 1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254546f,
+                                   0.70710678118654757f, 0.55557023301960218f, 0.38268343236508989f, 0.19509032201612861f};
+        constexpr float ohx = DIR ? -0.5f : 0.5f, ohy = DIR ? 0.5f : -0.5f;
+        float2 B[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float2 src = r[15 - q];
+            const float bx = __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(src.x)));
+            const float by = __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(src.y)));
+            const float2 own = r[(16 - q) & 15];
+            B[q] = first ? own : make_float2(bx, by);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float2 A = r[q];
+            const float2 H1 = make_float2(0.5f * (A.x + B[q].x), 0.5f * (A.y - B[q].y));
+            const float2 H2 = make_float2(ohx * (A.y + B[q].y), ohy * (A.x - B[q].x));
+            const float2 W = (q == 0) ? wu : cmul(wu, make_float2(c32[q], DIR ? s32[q] : -s32[q]));
+            const float2 WH = cmul(H2, W);
+            float2 out = make_float2(H1.x + WH.x, H1.y + WH.y);
+            if (q == 0) {   // element 0 of thread 0 packs DC and Nyquist (RC:280-286, 332-339)
+                const float2 packed = DIR ? make_float2(0.5f * (A.x + A.y), 0.5f * (A.x - A.y)) : make_float2(A.x + A.y, A.x - A.y);
+                out = first ? packed : out;
+            }
+            r[q] = out;
+        }
+    }
+};
+
 // In place on LDS, natural layout, region per FFT (device-function form; RC:269-344).
 template <int L, int DIR>
 __device__ __forceinline__ void r2c_c2r_lds_inplace(float2* s, const Engine<L, DIR, 1>& eng) {
@@ -292,13 +351,21 @@ __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__
     using G = Geometry<L>;
     Engine<L, DIR, 1> eng;
     eng.init(threadIdx.x);
+    HermitianRegisters<L, DIR> herm;
+    herm.init(threadIdx.x);
     float2* sf = s + eng.fft * G::SF;
     const int ntiles = (nFFTs + G::kFftsPerBlock - 1) / G::kFftsPerBlock;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long f = (long)tile * G::kFftsPerBlock + eng.fft;
         const bool active = f < nFFTs;
         float2 r[16];
-        if (DIR == 0) {
+        if constexpr (HermitianRegisters<L, DIR>::kEnabled) {
+            eng.load_global(r, d_input + (active ? f : 0) * L);
+            if (DIR == 1) herm.apply(r);
+            eng.transform(r, sf);
+            if (DIR == 0) herm.apply(r);
+            eng.store_global(r, d_output + f * L, active);
+        } else if (DIR == 0) {
             eng.load_global(r, d_input + (active ? f : 0) * L);
             if (G::kMultiWave) __syncthreads();
             eng.transform(r, sf);
