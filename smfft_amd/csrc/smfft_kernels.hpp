@@ -6,11 +6,15 @@
 //   FFT_GPU_R2C_C2R_external/multiple<P,D>  RC/FFT-GPU-32bit-Stockham.cu:349-384
 //
 // Every kernel uses 256-thread workgroups that own a tile of 4096 float2 (= 4096/N FFTs) and
-// P::fft_sm_required = 4352 float2 of LDS (34 KiB -> 4 workgroups = 16 waves per CU).  The
-// external kernels never stage through LDS on the way in or out: pass 1 loads straight from
-// global memory into registers (each wave instruction reads 512 contiguous bytes for N >= 1024)
-// and the last pass stores straight from registers, so the only LDS traffic is the exchanges.
-// Grids are grid-strided over tiles so a capped ("persistent") grid keeps twiddles in registers.
+// P::fft_sm_required = 4352 float2 of LDS (34 KiB -> 4 workgroups = 16 waves per CU).  For
+// N >= 256 the external kernels do not stage through LDS on the way in or out: pass 1 loads
+// straight from global memory into registers (each wave instruction reads 512 contiguous bytes
+// for N >= 1024) and the last pass stores straight from registers, so the only LDS traffic is the
+// exchanges; N <= 128 (an FFT is at most 8 threads) moves wave-sized chunks through the LDS regions
+// with 512-byte instructions.  Per length, one of three pacing forms sits between a tile's loads
+// and its stores (lds_round_trip, vmem_throttle, Engine::to_pass1_layout<PACED>; DESIGN.md
+// section 5).  Grids are grid-strided over tiles so a capped ("persistent") grid keeps twiddles in
+// registers.
 #pragma once
 #include "smfft_engine.hpp"
 #include "SM_FFT_stockham_parameters.hpp"
@@ -101,8 +105,8 @@ __device__ __forceinline__ void lds_to_wave_chunk(float2* __restrict__ gwave, co
 // without the preceding writes: nothing; the trip over only K of the 16 registers: K=8 a third of the gain, K=12
 // most, K=16 all; all loads held before the first store, s_sleep of 512 ... 65000 cycles, the LDS allocation alone,
 // a second trip: nothing or worse.  The mechanism is not pinned down, so this is a per-length tuning switch like
-// the grid cap, not a principle.  The no-reorder kernels get the same effect from the read-back of their LDS
-// transposition (Engine::to_pass1_layout<PACED>).
+// the grid cap, not a principle.  vmem_throttle below is the isolated ingredient; the N = 128 no-reorder kernel gets
+// the same effect from a volatile read-back of its LDS transposition (Engine::to_pass1_layout<PACED>).
 #ifndef SMFFT_TRIP_FORM
 #define SMFFT_TRIP_FORM 0
 #endif
