@@ -130,7 +130,10 @@ void* smfft_malloc(unsigned long long bytes);
 /* Two buffers of `bytes` each for a kernel that READS the first and WRITES the second.  On MI355X the rate of
  * such a kernel depends on which physical memory the two buffers are: 1.31 ... 1.55 ms for the 4 GiB + 4 GiB N=1024
  * batch, i.e. 0.69 ... 0.82 of the HBM peak (profiles/r01_chunk_map.txt); two plain hipMalloc
- * calls land anywhere in that range.  For buffers of 1 to 16 GiB this call allocates candidates (>= 4 GiB each) over
+ * calls land anywhere in that range.  For buffers of 1 to 16 GiB this call first tries a shortcut -- input from hipMalloc,
+ * output from the stream-ordered allocator (hipMallocAsync), which on most boxes hands out the fast write region: one
+ * copy probe, 0.1-0.3 s, accepted at 6.2 TB/s or more (SMFFT_NO_POOL_SHORTCUT disables it) -- and otherwise runs the
+ * search: it allocates candidates (>= 4 GiB each) over
  * the free memory, times a stream copy from a reference candidate into every other one and then from every candidate
  * into the best target, keeps the fastest (input, output) and releases the rest.  Cost: 4-5 s on an empty 288 GB
  * device, nearly all of it hipMalloc / hipFree; SMFFT_PAIR_SEARCH_CHUNKS=k limits the search to k candidates (12:

@@ -105,7 +105,8 @@ int timed(F&& launch, double* FFT_time) {
 // (the stream-copy kernel) from a reference chunk into every other chunk, then from every chunk into the best
 // output, keeps the fastest (input, output) and frees the rest.  With 288 GB of HBM that is about 66 candidates
 // for 4 GiB buffers and 4-5 s, nearly all of it hipMalloc / hipFree time.
-struct PairRec { void* a; void* b; size_t searched; int device; };   // searched: candidate size of a placement search, 0 = plain pair
+struct PairRec { void* a; void* b; size_t searched; int device; bool pool_b = false; };   // searched: candidate size of a
+                                                                                     // placement search, 0 = none; pool_b: b is from hipMallocAsync
 PairRec g_pairs[64];
 PairRec g_pair_cache = {nullptr, nullptr, 0, -1};   // the last searched pair that was released (see free_pair)
 std::mutex g_pairs_mutex;   // the table is shared by the per-GPU host threads of a multi-GPU driver
@@ -154,6 +155,30 @@ int alloc_pair(size_t bytes, void** d_a, void** d_b) {
             g_pair_cache = {nullptr, nullptr, 0, -1};
             return 0;
         }
+    }
+    // Shortcut before the search: on most boxes the memory the stream-ordered allocator (hipMallocAsync) hands out at
+    // this point IS the fast write region (tools/microbench/alloc_kinds.hip, tools/async_pool_probe.py: hipMalloc input +
+    // pool output 1.33-1.34 ms on two boxes of three, 1.50 ms on the third, where the search still found 1.33).  One copy
+    // probe decides: at 6.2 TB/s or more the pair is in the class the search would end in, and it cost 0.3 s, not 4-5.
+    if (want_search && slot >= 0 && bytes >= (1ull << 30) && bytes <= (16ull << 30) && getenv("SMFFT_NO_POOL_SHORTCUT") == nullptr) {
+        void *in = nullptr, *out = nullptr;
+        if (hipMalloc(&in, bytes) == hipSuccess) {
+            if (hipMallocAsync(&out, bytes, 0) == hipSuccess && hipStreamSynchronize(0) == hipSuccess) {
+                const float ms = probe_copy_ms(in, out, bytes, 3);
+                if (ms > 0.f && 2.0 * (double)bytes / (ms * 1e-3) >= 6.2e12) {
+                    *d_a = in;
+                    *d_b = out;
+                    PairRec rec = {in, out, 0, device};
+                    rec.pool_b = true;
+                    set_pair(slot, rec);
+                    return 0;
+                }
+                (void)hipFreeAsync(out, 0);
+                (void)hipStreamSynchronize(0);
+            }
+            (void)hipFree(in);
+        }
+        (void)hipGetLastError();
     }
     if (want_search && slot >= 0 && bytes >= (1ull << 30) && bytes <= (16ull << 30) && hipMemGetInfo(&free_mem, &total_mem) == hipSuccess) {
         // candidates of at least 4 GiB so that about 70 of them cover the whole memory (hipMalloc + hipFree cost
@@ -223,6 +248,10 @@ int free_pair(void* d_a) {
         }
     }
     if (!rec.a) return (int)hipFree(d_a);
+    if (rec.pool_b) {
+        int rc = (int)hipFree(rec.a) | (int)hipFreeAsync(rec.b, 0);
+        return rc | (int)hipStreamSynchronize(0);
+    }
     return (int)hipFree(rec.a) | (int)hipFree(rec.b);
 }
 

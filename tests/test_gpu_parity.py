@@ -392,29 +392,41 @@ def test_beyond_32bit_element_index(sm, oracle_lib):
     print(f"2^21+5 FFTs of 1024: {ms:.3f} ms = {2 * nbytes / ms / 1e6:.0f} GB/s")
 
 
-def test_malloc_pair(sm):
-    """smfft_malloc_pair: two usable, disjoint buffers chosen by the placement search; everything else is released."""
+def test_malloc_pair(sm, monkeypatch):
+    """smfft_malloc_pair: two usable, disjoint buffers (pool shortcut or placement search); the search releases its
+    other candidates; a released SEARCHED pair is kept for the next request that fits."""
     import ctypes
-    a, b = ctypes.c_void_p(), ctypes.c_void_p()
-    nbytes = 1 << 30                       # >= 1 GiB: the placement search is active
-    assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
-    assert a.value and b.value and a.value != b.value
-    assert abs(b.value - a.value) >= nbytes
-    x = (np.random.default_rng(0).random((64, 1024, 2), dtype=np.float32)).view(np.complex64).reshape(64, 1024)
-    sm.lib.smfft_memcpy_h2d(a.value, x.ctypes.data, x.nbytes)
-    rc, _ = sm.FFT_external_benchmark(a.value, b.value, 1024, 64)
-    got = np.empty_like(x)
-    sm.lib.smfft_memcpy_d2h(got.ctypes.data, b.value, x.nbytes)
-    ref.assert_close_fp32(got, ref.ct_c2c(x, False, True), "paired buffers")
-    assert sm.lib.smfft_free_pair(a.value) == 0
-    big = sm.DeviceBuffer(200 << 30)        # the candidates of the search are gone: most of the memory is allocatable again
-    big.free()
-    # the released searched pair is kept for the next request that fits into it: same pointers, no second search
     import time
+    nbytes = 1 << 30                       # >= 1 GiB: placement is active
+    x = (np.random.default_rng(0).random((64, 1024, 2), dtype=np.float32)).view(np.complex64).reshape(64, 1024)
+
+    def use(a, b):
+        assert a.value and b.value and abs(b.value - a.value) >= nbytes
+        sm.lib.smfft_memcpy_h2d(a.value, x.ctypes.data, x.nbytes)
+        rc, _ = sm.FFT_external_benchmark(a.value, b.value, 1024, 64)
+        got = np.empty_like(x)
+        sm.lib.smfft_memcpy_d2h(got.ctypes.data, b.value, x.nbytes)
+        ref.assert_close_fp32(got, ref.ct_c2c(x, False, True), "paired buffers")
+
+    # default path (stream-ordered-pool shortcut when its copy probe is fast enough, else the search)
+    a, b = ctypes.c_void_p(), ctypes.c_void_p()
+    assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
+    use(a, b)
+    assert sm.lib.smfft_free_pair(a.value) == 0
+    assert sm.lib.smfft_pair_cache_release() == 0
+    # the search itself (shortcut off, a few candidates): everything but the pair is released, the pair is cached on free
+    monkeypatch.setenv("SMFFT_NO_POOL_SHORTCUT", "1")
+    monkeypatch.setenv("SMFFT_PAIR_SEARCH_CHUNKS", "6")
+    a, b = ctypes.c_void_p(), ctypes.c_void_p()
+    assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
+    use(a, b)
+    big = sm.DeviceBuffer(200 << 30)        # the other candidates are gone: most of the memory is allocatable
+    big.free()
+    assert sm.lib.smfft_free_pair(a.value) == 0
     a2, b2 = ctypes.c_void_p(), ctypes.c_void_p()
     t0 = time.perf_counter()
     assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(a2), ctypes.byref(b2)) == 0
-    assert time.perf_counter() - t0 < 0.5 and (a2.value, b2.value) == (a.value, b.value)
+    assert time.perf_counter() - t0 < 0.5 and (a2.value, b2.value) == (a.value, b.value)   # same pair, no second search
     assert sm.lib.smfft_free_pair(a2.value) == 0
     assert sm.lib.smfft_pair_cache_release() == 0
     assert sm.lib.smfft_pair_cache_release() == 0   # idempotent
