@@ -132,7 +132,7 @@ void* smfft_malloc(unsigned long long bytes);
  * batch, i.e. 0.69 ... 0.82 of the HBM peak (profiles/r01_chunk_map.txt); two plain hipMalloc
  * calls land anywhere in that range.  For buffers of 1 to 16 GiB this call first tries a shortcut -- input from hipMalloc,
  * output from the stream-ordered allocator (hipMallocAsync), which on most boxes hands out the fast write region: one
- * copy probe, 0.1-0.3 s, accepted at 6.2 TB/s or more (SMFFT_NO_POOL_SHORTCUT disables it) -- and otherwise runs the
+ * copy probe, 0.1-0.3 s, accepted at 6.25 TB/s or more (SMFFT_NO_POOL_SHORTCUT disables it) -- and otherwise runs the
  * search: it allocates candidates (>= 4 GiB each) over
  * the free memory, times a stream copy from a reference candidate into every other one and then from every candidate
  * into the best target, keeps the fastest (input, output) and releases the rest.  Cost: 4-5 s on an empty 288 GB

@@ -159,13 +159,13 @@ int alloc_pair(size_t bytes, void** d_a, void** d_b) {
     // Shortcut before the search: on most boxes the memory the stream-ordered allocator (hipMallocAsync) hands out at
     // this point IS the fast write region (tools/microbench/alloc_kinds.hip, tools/async_pool_probe.py: hipMalloc input +
     // pool output 1.33-1.34 ms on two boxes of three, 1.50 ms on the third, where the search still found 1.33).  One copy
-    // probe decides: at 6.2 TB/s or more the pair is in the class the search would end in, and it cost 0.3 s, not 4-5.
+    // probe decides: at 6.25 TB/s or more the pair is in the class the search would end in, and it cost 0.3 s, not 4-5.
     if (want_search && slot >= 0 && bytes >= (1ull << 30) && bytes <= (16ull << 30) && getenv("SMFFT_NO_POOL_SHORTCUT") == nullptr) {
         void *in = nullptr, *out = nullptr;
         if (hipMalloc(&in, bytes) == hipSuccess) {
             if (hipMallocAsync(&out, bytes, 0) == hipSuccess && hipStreamSynchronize(0) == hipSuccess) {
                 const float ms = probe_copy_ms(in, out, bytes, 3);
-                if (ms > 0.f && 2.0 * (double)bytes / (ms * 1e-3) >= 6.2e12) {
+                if (ms > 0.f && 2.0 * (double)bytes / (ms * 1e-3) >= 6.25e12) {   // fast write region: 6.4-6.5; best ordinary class: <= 6.17
                     *d_a = in;
                     *d_b = out;
                     PairRec rec = {in, out, 0, device};
