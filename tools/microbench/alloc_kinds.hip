@@ -26,6 +26,22 @@ int main() {
     CK(hipDeviceSynchronize());
     for (int i = 0; i < 2; ++i) { if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) == hipSuccess) add(p, "uncached"); else (void)hipGetLastError(); }
     for (int i = 0; i < 2; ++i) { if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) == hipSuccess) add(p, "finegr"); else (void)hipGetLastError(); }
+    {   // explicit virtual-memory management: physical handle + reserved address range + mapping
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = 0;
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        for (int i = 0; i < 2; ++i) {
+            hipMemGenericAllocationHandle_t h;
+            void* va = nullptr;
+            if (hipMemCreate(&h, bytes, &prop, 0) == hipSuccess && hipMemAddressReserve(&va, bytes, 0, nullptr, 0) == hipSuccess
+                && hipMemMap(va, bytes, 0, h, 0) == hipSuccess && hipMemSetAccess(va, bytes, &acc, 1) == hipSuccess) add(va, "vmm");
+            else { printf("vmm allocation failed: %s\n", hipGetErrorString(hipGetLastError())); }
+        }
+    }
     for (auto q : cand) CK(hipMemset(q, 0, bytes));
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
