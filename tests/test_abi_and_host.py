@@ -89,3 +89,38 @@ def test_shard_range_tiles_batch():
             assert pos == nffts
     with pytest.raises(ValueError):
         shard_range(8, 2, 2)
+
+
+def test_reference_style_harness_compiles_and_links_through_the_shim(built, tmp_path):
+    """A translation unit written the way the reference's FFT.c is (CUDA header names, the reference's own prototypes
+    with float2 and bool, C++ linkage, cudaDeviceReset) compiles with g++ against include/shim and links against
+    libsmfft_amd.so + libsmfft_vendor.so: the drop-in boundary of INTEGRATION.md section A.  Link only: no GPU here."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("g++ / ROCm headers not available")
+    root = os.path.join(os.path.dirname(__file__), "..")
+    src = tmp_path / "main.c"
+    src.write_text(
+        "#include <cuda.h>\n#include <cuda_runtime.h>\n#include <cuda_runtime_api.h>\n#include <stdio.h>\n#include <stdlib.h>\n"
+        "int GPU_smFFT_4elements(float2 *h_input, float2 *h_output, int FFT_size, int nFFTs, bool inverse, bool reorder, int nRuns, double *single_ex_time, double *multi_ex_time);\n"
+        "int GPU_cuFFT(float2 *h_input, float2 *h_output, int FFT_size, int nFFTs, bool inverse, int nRuns, double *single_ex_time);\n"
+        "int GPU_FFT_C2C_Stockham(float2 *h_input, float2 *h_smFFT_output, int FFT_size, int nFFTs, int nRuns, double *single_ex_time, double *multi_ex_time);\n"
+        "int GPU_smFFT_R2C(float2 *h_output, float *h_input, int FFT_size, int nFFTs, int nRuns);\n"
+        "int GPU_smFFT_C2R(float *h_output, float2 *h_input, int FFT_size, int nFFTs, int nRuns);\n"
+        "int main(int argc, char **argv) {\n"
+        "  if (argc < 99) return 0;   /* never runs the GPU part in this test */\n"
+        "  float2 *a = (float2 *) malloc(1024*sizeof(float2)), *b = (float2 *) malloc(1024*sizeof(float2)); double t1, t2;\n"
+        "  GPU_cuFFT(a, b, 1024, 1, false, 1, &t1);\n"
+        "  GPU_smFFT_4elements(a, b, 1024, 1, false, true, 1, &t1, &t2);\n"
+        "  GPU_FFT_C2C_Stockham(a, b, 1024, 1, 1, &t1, &t2);\n"
+        "  GPU_smFFT_R2C(b, (float *) a, 1024, 1, 1); GPU_smFFT_C2R((float *) a, b, 1024, 1, 1);\n"
+        "  cudaDeviceReset(); return 0; }\n")
+    exe = tmp_path / "FFT.exe"
+    cmd = ["g++", "-O1", "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(root, "include", "shim"), "-I/opt/rocm/include", str(src), "-o", str(exe),
+           "-L" + os.path.join(root, "smfft_amd"), "-lsmfft_amd", "-lsmfft_vendor", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + os.path.abspath(os.path.join(root, "smfft_amd")), "-Wl,-rpath,/opt/rocm/lib"]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert subprocess.run([str(exe)], capture_output=True).returncode == 0   # argc < 99: exits before touching a device
+
