@@ -1,0 +1,269 @@
+// placement_study -- why does the streaming rate of "read buffer A, write buffer B" depend on WHICH memory A and B are?
+//
+// Round 1 found (profiles/r01_chunk_map.txt) that separately allocated chunks fall into three classes (same class:
+// 1.51-1.55 ms for the 4 GiB + 4 GiB N=1024 batch, different classes: 1.41-1.46 ms) plus a "fast write region"
+// (1.31-1.39 ms as an output, slow as an input).  This tool produces the evidence round 2 needs:
+//
+//   placement_study map [chunk_GiB] [max_chunks]
+//       allocates chunks in order, and per chunk j prints: pure read rate, pure write rate, copy 0 -> j, copy j -> 0,
+//       copy (j-1) -> j; then the full (input, output) matrix.  Also dumps the KFD memory-bank properties.
+//   placement_study pmc [chunk_GiB] [max_chunks]
+//       the same allocation + classification against chunk 0, then a fixed sequence of TAGGED dispatches (the tag is a
+//       template argument, so it is part of the kernel name a `rocprofv3 --pmc` csv reports):
+//         study_copy<1>  0 -> S   S = a chunk of chunk 0's class (slowest output)
+//         study_copy<2>  0 -> X   X = a chunk of another class
+//         study_copy<3>  0 -> F   F = the best write target found
+//         study_copy<4>  F -> 0
+//         study_copy<5>  S -> 0
+//         study_copy<6>  X -> 0
+//         study_read<1..3> on 0 / S|X / F, study_write<1..3> likewise
+//         study_copy_paced<1..3>  the same three outputs with the 16-flat-load "VMEM throttle" of the external kernels
+//       Classification dispatches use tag 0.
+// Build: hipcc -O3 --offload-arch=gfx950 placement_study.hip -o placement_study
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// the external kernels' access shape: 256-thread workgroups, tile = 4096 float2, each wave moves 8 KiB with
+// 16 x 8 B/lane non-temporal loads at 512 B stride, grid-stride over tiles
+template <int TAG>
+__global__ void __launch_bounds__(256) study_copy(const v2f* __restrict__ in, v2f* __restrict__ out, long ntiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const v2f* g = in + tile * 4096 + wave * 1024 + lane;
+        v2f* o = out + tile * 4096 + wave * 1024 + lane;
+        v2f r[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) r[c] = __builtin_nontemporal_load(g + 64 * c);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) __builtin_nontemporal_store(r[c], o + 64 * c);
+    }
+}
+
+// same, with K serialised flat loads from LDS between the loads and the stores (smfft_kernels.hpp vmem_throttle)
+template <int TAG, int K>
+__global__ void __launch_bounds__(256) study_copy_paced(const v2f* __restrict__ in, v2f* __restrict__ out, long ntiles) {
+    __shared__ v2f s[4352];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const v2f* g = in + tile * 4096 + wave * 1024 + lane;
+        v2f* o = out + tile * 4096 + wave * 1024 + lane;
+        v2f r[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) r[c] = __builtin_nontemporal_load(g + 64 * c);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) asm volatile("" : "+v"(r[c]));
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+            const v2f* q = s + wave * 1088 + lane + 64 * (c & 15);
+            v2f d;
+            asm volatile("flat_load_dwordx2 %0, %1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" : "=v"(d) : "v"(q) : "memory");
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) __builtin_nontemporal_store(r[c], o + 64 * c);
+    }
+}
+
+template <int TAG>
+__global__ void __launch_bounds__(256) study_read(const v2f* __restrict__ in, v2f* __restrict__ sink, long ntiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v2f acc = {0.f, 0.f};
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const v2f* g = in + tile * 4096 + wave * 1024 + lane;
+        v2f r[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) r[c] = __builtin_nontemporal_load(g + 64 * c);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc += r[c];
+    }
+    if (acc.x == 123.456f && acc.y == 654.321f) sink[threadIdx.x] = acc;   // never true for the data used
+}
+
+template <int TAG>
+__global__ void __launch_bounds__(256) study_write(v2f* __restrict__ out, long ntiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const v2f v = {(float)lane, (float)wave};
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        v2f* o = out + tile * 4096 + wave * 1024 + lane;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) __builtin_nontemporal_store(v, o + 64 * c);
+    }
+}
+
+static long g_ntiles;
+static int g_grid = 12288;
+static hipEvent_t g_e0, g_e1;
+
+template <class F>
+static float time_ms(F&& launch, int reps) {
+    launch();
+    CK(hipEventRecord(g_e0, 0));
+    for (int i = 0; i < reps; ++i) launch();
+    CK(hipEventRecord(g_e1, 0));
+    CK(hipEventSynchronize(g_e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, g_e0, g_e1));
+    return ms / reps;
+}
+
+template <int TAG> static float t_copy(const void* a, void* b, int reps) {
+    return time_ms([&] { study_copy<TAG><<<g_grid, 256>>>((const v2f*)a, (v2f*)b, g_ntiles); }, reps);
+}
+template <int TAG> static float t_paced(const void* a, void* b, int reps) {
+    return time_ms([&] { study_copy_paced<TAG, 16><<<g_grid, 256>>>((const v2f*)a, (v2f*)b, g_ntiles); }, reps);
+}
+template <int TAG> static float t_read(const void* a, void* sink, int reps) {
+    return time_ms([&] { study_read<TAG><<<g_grid, 256>>>((const v2f*)a, (v2f*)sink, g_ntiles); }, reps);
+}
+template <int TAG> static float t_write(void* b, int reps) {
+    return time_ms([&] { study_write<TAG><<<g_grid, 256>>>((v2f*)b, g_ntiles); }, reps);
+}
+
+// bytes the driver reports as used VRAM (first amdgpu card that exposes the file), -1 if unreadable
+static long long vram_used() {
+    for (int card = 0; card < 64; ++card) {
+        char p[128];
+        snprintf(p, sizeof p, "/sys/class/drm/card%d/device/mem_info_vram_used", card);
+        FILE* f = fopen(p, "r");
+        if (!f) continue;
+        long long v = -1;
+        if (fscanf(f, "%lld", &v) != 1) v = -1;
+        fclose(f);
+        return v;
+    }
+    return -1;
+}
+
+static void dump_file(const char* path) {
+    FILE* f = fopen(path, "r");
+    if (!f) return;
+    char line[512];
+    printf("--- %s\n", path);
+    while (fgets(line, sizeof line, f)) printf("    %s", line);
+    fclose(f);
+}
+
+int main(int argc, char** argv) {
+    const std::string mode = argc > 1 ? argv[1] : "map";
+    const size_t chunk_gib = argc > 2 ? atol(argv[2]) : 4;
+    const int max_chunks = argc > 3 ? atoi(argv[3]) : 64;
+    const size_t window = 4ull << 30;                 // every probe moves the first 4 GiB of a chunk
+    const size_t chunk_bytes = std::max(chunk_gib << 30, window);
+    g_ntiles = (long)(window / 8 / 4096);
+    CK(hipSetDevice(0));
+    CK(hipEventCreate(&g_e0));
+    CK(hipEventCreate(&g_e1));
+    size_t free_b = 0, total_b = 0;
+    CK(hipMemGetInfo(&free_b, &total_b));
+    printf("mode %s: chunk %zu GiB, free %.1f GiB of %.1f GiB\n", mode.c_str(), chunk_bytes >> 30, free_b / 1073741824.0, total_b / 1073741824.0);
+    if (mode == "map") {
+        for (int node = 0; node < 16; ++node) {
+            char p[256];
+            for (int bank = 0; bank < 4; ++bank) {
+                snprintf(p, sizeof p, "/sys/class/kfd/kfd/topology/nodes/%d/mem_banks/%d/properties", node, bank);
+                dump_file(p);
+            }
+        }
+    }
+    std::vector<void*> chunk;
+    const size_t reserve = 6ull << 30;
+    printf("vram_used at start: %.2f GiB\n", vram_used() / 1073741824.0);
+    // a stream-ordered-pool allocation made FIRST (round 1: such memory was the fast write region on 2 boxes of 3);
+    // it becomes the LAST entry of the chunk list
+    void* pool_chunk = nullptr;
+    if (hipMallocAsync(&pool_chunk, window, 0) != hipSuccess || hipStreamSynchronize(0) != hipSuccess) { (void)hipGetLastError(); pool_chunk = nullptr; }
+    printf("vram_used after the pool allocation: %.2f GiB\n", vram_used() / 1073741824.0);
+    while ((int)chunk.size() < max_chunks) {
+        CK(hipMemGetInfo(&free_b, &total_b));
+        if (free_b < chunk_bytes + reserve) break;
+        void* p = nullptr;
+        if (hipMalloc(&p, chunk_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        chunk.push_back(p);
+    }
+    printf("vram_used after %zu hipMalloc chunks: %.2f GiB\n", chunk.size(), vram_used() / 1073741824.0);
+    if (pool_chunk) chunk.push_back(pool_chunk);
+    const int n = (int)chunk.size();
+    if (pool_chunk) printf("chunk %d is the hipMallocAsync allocation made first\n", n - 1);
+    printf("%d chunks allocated; virtual addresses (GiB):", n);
+    for (int j = 0; j < n; ++j) printf(" %.1f", (double)(uintptr_t)chunk[j] / 1073741824.0);
+    printf("\n");
+    if (n < 3) return 1;
+    // touch everything once (first-touch effects out of the way) and warm the clocks
+    for (int j = 0; j < n; ++j) study_write<0><<<g_grid, 256>>>((v2f*)chunk[j], g_ntiles);
+    CK(hipDeviceSynchronize());
+    for (int k = 0; k < 200; ++k) study_copy<0><<<g_grid, 256>>>((const v2f*)chunk[0], (v2f*)chunk[1], g_ntiles);
+    CK(hipDeviceSynchronize());
+
+    std::vector<float> rd(n), wr(n), out0(n), in0(n), adj(n);
+    void* sink = chunk[n - 2];
+    for (int j = 0; j < n; ++j) {
+        rd[j] = t_read<0>(chunk[j], sink, 3);
+        wr[j] = t_write<0>(chunk[j], 3);
+        out0[j] = j ? t_copy<0>(chunk[0], chunk[j], 3) : 0.f;
+        in0[j] = j ? t_copy<0>(chunk[j], chunk[0], 3) : 0.f;
+        adj[j] = j ? t_copy<0>(chunk[j - 1], chunk[j], 3) : 0.f;
+    }
+    printf("per chunk (ms for the 4 GiB window; copies move 4 GiB in + 4 GiB out):\n  j   read  write  0->j   j->0  (j-1)->j\n");
+    for (int j = 0; j < n; ++j) printf("%3d  %.3f  %.3f  %.3f  %.3f  %.3f\n", j, rd[j], wr[j], out0[j], in0[j], adj[j]);
+
+    if (mode == "map") {
+        printf("matrix: rows = input chunk, columns = output chunk (ms x 100, same chunk = 0)\n");
+        for (int i = 0; i < n; ++i) {
+            printf("%3d", i);
+            for (int j = 0; j < n; ++j) {
+                const float ms = (i == j) ? 0.f : t_copy<0>(chunk[i], chunk[j], 2);
+                printf(" %3d", (int)(ms * 100.f + 0.5f));
+            }
+            printf("\n");
+            fflush(stdout);
+        }
+    } else {
+        // S: slowest output for input 0 (same class), F: fastest, X: the output closest to the midpoint of the two
+        int S = 1, F = 1, X = 1;
+        for (int j = 1; j < n; ++j) {
+            if (out0[j] > out0[S]) S = j;
+            if (out0[j] < out0[F]) F = j;
+        }
+        // X: an ordinary other-class chunk = the median output time
+        std::vector<int> order;
+        for (int j = 1; j < n; ++j) order.push_back(j);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return out0[a] < out0[b]; });
+        X = order[order.size() / 2];
+        printf("tags: S=%d (0->S %.3f ms)  X=%d (0->X %.3f ms)  F=%d (0->F %.3f ms)\n", S, out0[S], X, out0[X], F, out0[F]);
+        const int reps = 6;
+        printf("copy<1> 0->S %.3f\n", t_copy<1>(chunk[0], chunk[S], reps));
+        printf("copy<2> 0->X %.3f\n", t_copy<2>(chunk[0], chunk[X], reps));
+        printf("copy<3> 0->F %.3f\n", t_copy<3>(chunk[0], chunk[F], reps));
+        printf("copy<4> F->0 %.3f\n", t_copy<4>(chunk[F], chunk[0], reps));
+        printf("copy<5> S->0 %.3f\n", t_copy<5>(chunk[S], chunk[0], reps));
+        printf("copy<6> X->0 %.3f\n", t_copy<6>(chunk[X], chunk[0], reps));
+        printf("read<1> 0 %.3f\n", t_read<1>(chunk[0], sink, reps));
+        printf("read<2> X %.3f\n", t_read<2>(chunk[X], sink, reps));
+        printf("read<3> F %.3f\n", t_read<3>(chunk[F], sink, reps));
+        printf("write<1> S %.3f\n", t_write<1>(chunk[S], reps));
+        printf("write<2> X %.3f\n", t_write<2>(chunk[X], reps));
+        printf("write<3> F %.3f\n", t_write<3>(chunk[F], reps));
+        printf("paced<1> 0->S %.3f\n", t_paced<1>(chunk[0], chunk[S], reps));
+        printf("paced<2> 0->X %.3f\n", t_paced<2>(chunk[0], chunk[X], reps));
+        printf("paced<3> 0->F %.3f\n", t_paced<3>(chunk[0], chunk[F], reps));
+    }
+    if (pool_chunk) { chunk.pop_back(); (void)hipFreeAsync(pool_chunk, 0); (void)hipStreamSynchronize(0); }
+    printf("vram_used before freeing: %.2f GiB\n", vram_used() / 1073741824.0);
+    for (void* p : chunk) (void)hipFree(p);
+    printf("vram_used right after hipFree of everything: %.2f GiB\n", vram_used() / 1073741824.0);
+    CK(hipDeviceSynchronize());
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, 0) == hipSuccess) {
+        (void)hipMemPoolTrimTo(pool, 0);
+        printf("vram_used after hipMemPoolTrimTo(0): %.2f GiB\n", vram_used() / 1073741824.0);
+    }
+    return 0;
+}
