@@ -124,3 +124,32 @@ def test_reference_style_harness_compiles_and_links_through_the_shim(built, tmp_
     assert p.returncode == 0, p.stderr
     assert subprocess.run([str(exe)], capture_output=True).returncode == 0   # argc < 99: exits before touching a device
 
+
+
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.parametrize("program", ["SMFFT_CooleyTukey_C2C", "SMFFT_Stockham_C2C", "SMFFT_Stockham_R2C_C2R"])
+def test_the_references_own_harness_links_unchanged(built, tmp_path, program):
+    """The reference's OWN host harness (its FFT.c, compiled IN PLACE from /root/reference: nothing is copied) builds
+    with g++ against include/shim and links against libsmfft_amd.so + libsmfft_vendor.so without a single edit: every
+    symbol it binds (GPU_smFFT_4elements, GPU_cuFFT, GPU_FFT_C2C_Stockham, GPU_smFFT_R2C/C2R, GPU_cuFFT_R2C/C2R, with
+    the reference's C++ mangling) is exported.  Link only; the artefact lives in tmp_path.  Skipped where the
+    reference checkout does not exist (the GPU box)."""
+    import shutil
+    src = os.path.join(REFERENCE, program, "FFT.c")
+    if not os.path.exists(src):
+        pytest.skip("reference checkout not present")
+    if shutil.which("g++") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("g++ / ROCm headers not available")
+    exe = tmp_path / "FFT.exe"
+    # -I<program dir>: FFT.c includes its own debug.h (compile-time switches, a reference header used in place)
+    cmd = ["g++", "-O1", "-w", "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include", "shim"), "-I/opt/rocm/include",
+           "-I" + os.path.join(REFERENCE, program), src, "-o", str(exe),
+           "-L" + os.path.join(ROOT, "smfft_amd"), "-lsmfft_amd", "-lsmfft_vendor", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + os.path.join(ROOT, "smfft_amd"), "-Wl,-rpath,/opt/rocm/lib"]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    # no arguments: the reference's main prints its usage text and returns before touching a device
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert "FFT" in (run.stdout + run.stderr)
