@@ -5,15 +5,17 @@
 // given:  y = IFFT( FFT(x) .* H ) / N.  One 256-thread workgroup owns 4 series (a 4096-element
 // tile); everything between the global load and the global store stays in LDS / registers:
 //     global -> LDS | do_SMFFT_CT_DIT<FFT_1024_forward> | .* H | do_SMFFT_CT_DIT<FFT_1024_inverse> | -> global
+// (the device functions in the engine's tiled contract, namespace smfft::tiled; the reference-shaped form of the same
+//  functions -- blockDim.x = N/4, contiguous data -- is exercised by examples/reference_shape_kernel.hip)
 // Build: hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-slp-vectorize -fPIC -shared \
-//        -I smfft_amd/csrc examples/fft_convolution.hip -o smfft_amd/libsmfft_examples.so
+//        -I include examples/fft_convolution.hip -o smfft_amd/libsmfft_examples.so
 #include <hip/hip_runtime.h>
-#include "smfft_engine.hpp"
+#include <smfft_device.hpp>
 
 template <class Fwd, class Inv>
 __global__ void __launch_bounds__(256) convolve_kernel(const float2* __restrict__ x, const float2* __restrict__ H, float2* __restrict__ y, int nSeries) {
     constexpr int N = Fwd::fft_size;
-    __shared__ float2 s[Fwd::fft_sm_required];
+    __shared__ float2 s[Fwd::tile_sm_required];
     const long first = (long)blockIdx.x * Fwd::fft_per_block;
     // natural order, series j of the workgroup at s[j*fft_region + n]
     for (int e = threadIdx.x; e < 4096; e += 256) {
@@ -21,7 +23,7 @@ __global__ void __launch_bounds__(256) convolve_kernel(const float2* __restrict_
         s[j * Fwd::fft_region + n] = (first + j < nSeries) ? x[first * N + e] : make_float2(0.f, 0.f);
     }
     __syncthreads();
-    do_SMFFT_CT_DIT<Fwd>(s);
+    smfft::tiled::do_SMFFT_CT_DIT<Fwd>(s);
     __syncthreads();
     for (int e = threadIdx.x; e < 4096; e += 256) {
         const int j = e / N, k = e % N;
@@ -29,7 +31,7 @@ __global__ void __launch_bounds__(256) convolve_kernel(const float2* __restrict_
         s[j * Fwd::fft_region + k] = make_float2(a.x * h.x - a.y * h.y, a.x * h.y + a.y * h.x);
     }
     __syncthreads();
-    do_SMFFT_CT_DIT<Inv>(s);
+    smfft::tiled::do_SMFFT_CT_DIT<Inv>(s);
     __syncthreads();
     const float scale = 1.0f / N;
     for (int e = threadIdx.x; e < 4096; e += 256) {

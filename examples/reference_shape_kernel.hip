@@ -1,0 +1,76 @@
+// reference_shape_kernel.hip -- user kernels written the way a KAdamek/SMFFT user writes them (reference
+// README.md:10-18, 48-60; CT/FFT-GPU-32bit.cu:534-551, 586-595): one thread block per fft_length elements,
+// blockDim.x = fft_length / 4, four float2 per thread into `__shared__ float2 s[P::fft_sm_required]`,
+// __syncthreads, do_SMFFT_CT_DIT<P>(s), __syncthreads, four float2 per thread out -- and launched with the
+// reference's grid arithmetic.  Nothing here knows about 64-lane waves, tiles or regions: the only change against
+// a CUDA build is the include line.  tests/test_gpu_parity.py runs every length and variant against the oracle.
+//
+// Build: hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -I include examples/reference_shape_kernel.hip
+#include <hip/hip_runtime.h>
+#include <smfft_device.hpp>
+
+// a user's own kernel around the device function (the "expected to be called within a GPU kernel" use, README.md:10)
+template <class const_params>
+__global__ void user_fft_kernel(float2* d_input, float2* d_output) {
+    __shared__ float2 s_data[const_params::fft_sm_required];
+    const int offset = blockIdx.x * const_params::fft_length;
+    for (int k = 0; k < 4; k++) s_data[threadIdx.x + k * const_params::fft_length_quarter] = d_input[offset + threadIdx.x + k * const_params::fft_length_quarter];
+    __syncthreads();
+    do_SMFFT_CT_DIT<const_params>(s_data);
+    __syncthreads();
+    for (int k = 0; k < 4; k++) d_output[offset + threadIdx.x + k * const_params::fft_length_quarter] = s_data[threadIdx.x + k * const_params::fft_length_quarter];
+}
+
+// which = 0: the user's kernel above; 1: the library's reference-shaped SMFFT_DIT_external<P>(in, out)
+template <class P>
+static int launch_ct(float2* in, float2* out, int nFFTs, int which, hipStream_t st) {
+    // the reference's launch arithmetic (CT:586-595): nFFTs blocks of N/4 threads; N = 32 / 64: nFFTs/4, nFFTs/2 blocks of 32
+    dim3 grid(nFFTs / (P::fft_length / P::fft_size)), block(P::fft_length / 4);
+    if (which == 0) user_fft_kernel<P><<<grid, block, 0, st>>>(in, out);
+    else SMFFT_DIT_external<P><<<grid, block, 0, st>>>(in, out);
+    return (int)hipGetLastError();
+}
+
+#define CT_CASE(N)                                                                                              \
+    case N:                                                                                                     \
+        if (!inverse && reorder) return launch_ct<FFT_##N##_forward>(in, out, nFFTs, which, st);               \
+        if (!inverse && !reorder) return launch_ct<FFT_##N##_forward_noreorder>(in, out, nFFTs, which, st);    \
+        if (inverse && reorder) return launch_ct<FFT_##N##_inverse>(in, out, nFFTs, which, st);                \
+        return launch_ct<FFT_##N##_inverse_noreorder>(in, out, nFFTs, which, st);
+
+extern "C" int smfft_example_reference_shape_ct(void* d_in, void* d_out, int FFT_size, int nFFTs, int inverse, int reorder, int which, void* stream) {
+    float2 *in = (float2*)d_in, *out = (float2*)d_out;
+    hipStream_t st = (hipStream_t)stream;
+    switch (FFT_size) {
+        CT_CASE(32) CT_CASE(64) CT_CASE(128) CT_CASE(256) CT_CASE(512) CT_CASE(1024) CT_CASE(2048) CT_CASE(4096)
+        default: return -1;
+    }
+}
+
+// Stockham C2C program in the reference's shape: <<<nFFTs, N/4, N*8 bytes>>> (ST:309-319)
+#define ST_CASE(N) case N: FFT_GPU_external<FFT_##N><<<dim3(nFFTs), dim3(N / 4), N * 8, st>>>(in, out); break;
+extern "C" int smfft_example_reference_shape_st(void* d_in, void* d_out, int FFT_size, int nFFTs, void* stream) {
+    float2 *in = (float2*)d_in, *out = (float2*)d_out;
+    hipStream_t st = (hipStream_t)stream;
+    switch (FFT_size) {
+        ST_CASE(256) ST_CASE(512) ST_CASE(1024) ST_CASE(2048) ST_CASE(4096)
+        default: return -1;
+    }
+    return (int)hipGetLastError();
+}
+
+// R2C / C2R program in the reference's shape: real length FFT_size -> FFT_<FFT_size/2>, <<<nFFTs, (FFT_size/2)/4>>> (RC:399-428)
+#define RC_CASE(NREAL, L)                                                                                        \
+    case NREAL:                                                                                                  \
+        if (!inverse) FFT_GPU_R2C_C2R_external<FFT_##L, FFT_forward><<<dim3(nFFTs), dim3(L / 4), 0, st>>>(in, out); \
+        else FFT_GPU_R2C_C2R_external<FFT_##L, FFT_inverse><<<dim3(nFFTs), dim3(L / 4), 0, st>>>(in, out);       \
+        break;
+extern "C" int smfft_example_reference_shape_rc(void* d_in, void* d_out, int FFT_size, int nFFTs, int inverse, void* stream) {
+    float2 *in = (float2*)d_in, *out = (float2*)d_out;
+    hipStream_t st = (hipStream_t)stream;
+    switch (FFT_size) {
+        RC_CASE(512, 256) RC_CASE(1024, 512) RC_CASE(2048, 1024) RC_CASE(4096, 2048)
+        default: return -1;
+    }
+    return (int)hipGetLastError();
+}

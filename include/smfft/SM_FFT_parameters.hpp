@@ -2,24 +2,29 @@
 //
 // Same class names and members as the reference's parameter header
 // (SMFFT_CooleyTukey_C2C/SM_FFT_parameters.cuh:1-390: FFT_Params and the 32 classes
-// FFT_<N>_{forward,inverse}{,_noreorder}), so code templated on them keeps compiling; the VALUES
-// describe the gfx950 engine (smfft_engine.hpp), not the CUDA one:
-//   warp                      64 (a CDNA wavefront; the reference has 32)
+// FFT_<N>_{forward,inverse}{,_noreorder}).  The members the reference defines keep the reference's
+// MEANING, so a kernel written against them (README.md:48-60, CT:534-551) compiles unchanged:
 //   fft_exp                   log2 of the transform length
-//   fft_size                  the transform length N                              (new)
-//   fft_length                float2 elements one workgroup processes = 4096 for every N
-//                             (the reference uses max(N,128): 4x32, 2x64 or one FFT per block)
-//   fft_length_quarter/half/three_quarters   fractions of fft_length (kept for source parity)
-//   fft_sm_required           float2 elements of LDS one workgroup needs = 4352 (= 4096*17/16:
-//                             every FFT owns a region of 17N/16 float2 that holds its natural-order
-//                             data and the padded exchange layouts; reference: (N/32)*33)
+//   fft_length                float2 elements one thread block of the reference-shaped kernels holds:
+//                             max(N, 128) -- 4 x 32, 2 x 64 or one FFT, exactly as upstream (:8-18, :56-66)
+//   fft_length_quarter/half/three_quarters   fractions of fft_length; blockDim.x = fft_length_quarter
+//   fft_sm_required           float2 elements of LDS the caller declares for do_SMFFT_CT_DIT:
+//                             17 * fft_length / 16 (the data in [0, fft_length), the rest is the engine's
+//                             padded exchange space; upstream: (fft_length / 32) * 33, README.md:18)
 //   fft_direction             0 forward (e^-), 1 inverse (e^+); both un-normalised
 //   fft_reorder               1: out = DFT(in); 0: out = DFT(in[bitrev(n)]) (DIT network on natural input)
-//   fft_threads               threads that cooperate on one FFT = N/16                (new)
-//   fft_per_block             FFTs one 256-thread workgroup holds = 4096/N            (new)
-//   fft_region                float2 stride between consecutive FFTs of a block in LDS = 17N/16 (new)
+//   warp                      64: a CDNA wavefront (upstream 32)
+// Members that describe the gfx950 engine (include/smfft/smfft_engine.hpp) and the library's own
+// tiled kernels; none of them exists upstream:
+//   fft_size                  the transform length N
+//   fft_threads               threads that cooperate on one FFT = N / 16
+//   tile_length               float2 elements one 256-thread workgroup of the tiled kernels owns = 4096
+//   tile_sm_required          LDS float2 of such a workgroup = 4352
+//   fft_per_block             FFTs in a tile = 4096 / N
+//   fft_region                float2 stride between consecutive FFTs of a tile in LDS = 17 N / 16
 // Deviation, documented: the reference's FFT_4096_inverse_noreorder has fft_direction = 0
-// (SM_FFT_parameters.cuh:388, a typo that silently computes the forward transform); here it is 1.
+// (SM_FFT_parameters.cuh:388, a typo that silently computes the forward transform); here it is 1
+// (tests/test_lane_emulation.py shows both behaviours).
 #pragma once
 
 class FFT_Params {
@@ -32,16 +37,20 @@ public:
 template<int EXP, int DIRECTION, int REORDER>
 class FFT_ParamsOf : public FFT_Params {
 public:
+	// ---- the reference's members ----
 	static const int fft_exp = EXP;
-	static const int fft_size = 1 << EXP;
-	static const int fft_length = 4096;
-	static const int fft_length_quarter = 1024;
-	static const int fft_length_half = 2048;
-	static const int fft_length_three_quarters = 3072;
-	static const int fft_sm_required = 4352;
+	static const int fft_length = (1 << EXP) < 128 ? 128 : (1 << EXP);
+	static const int fft_length_quarter = fft_length / 4;
+	static const int fft_length_half = fft_length / 2;
+	static const int fft_length_three_quarters = 3 * (fft_length / 4);
+	static const int fft_sm_required = (fft_length / 16) * 17;
 	static const int fft_direction = DIRECTION;
 	static const int fft_reorder = REORDER;
+	// ---- the engine's ----
+	static const int fft_size = 1 << EXP;
 	static const int fft_threads = (1 << EXP) / 16;
+	static const int tile_length = 4096;
+	static const int tile_sm_required = 4352;
 	static const int fft_per_block = 4096 >> EXP;
 	static const int fft_region = ((1 << EXP) / 16) * 17;
 };

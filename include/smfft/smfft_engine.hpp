@@ -22,11 +22,13 @@
 //   * Twiddles W_N^m come from a 4096-entry table rounded once from fp64 (<= 0.5 ulp); a thread
 //     needs only 15 + (RM-1) of them, loaded once and kept in VGPRs across a persistent loop.
 //
-// Data layout contract of the device functions: `s` points at the workgroup's LDS array of
-// P::fft_sm_required float2; FFT j of the workgroup (j < P::fft_per_block) occupies
-// s[j*P::fft_region + n], n in [0, N), natural order, before and after the call; the rest of each
-// region is scratch.  All 256 threads of the workgroup call the function (blockDim.x == 256).
-// Callers barrier (__syncthreads) between filling s and the call, and between the call and reading s.
+// This header is the engine only.  The device functions under the reference's names (do_SMFFT_CT_DIT,
+// do_FFT_Stockham_*), in the reference's own launch shape and in the engine's tiled shape, are in
+// smfft_device_functions.hpp; include/smfft_device.hpp pulls in everything a user kernel needs.
+//
+// LDS layout the engine works on: every FFT owns a REGION of Geometry::SF float2 (17N/16 with padding,
+// N without); its data sit at region[0 .. N) in natural order before and after a transform, the rest
+// of the region is exchange space.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "SM_FFT_parameters.hpp"
@@ -38,7 +40,10 @@ static __device__ const float2 twiddle_4096[4096] = {
 };
 
 // ------------------------------------------------------------------------------------------------
-template <int N>
+// PAD = false: the exchange layouts without their bank-conflict padding, so that a transform fits
+// into exactly N float2 of LDS (the reference's Stockham device functions get no more than that from
+// their callers, ST:319); slower, used only by the reference-shaped Stockham entry points.
+template <int N, bool PAD = true>
 struct Geometry {
     static_assert(N >= 32 && N <= 4096 && (N & (N - 1)) == 0, "N must be a power of two in [32, 4096]");
     static constexpr int T = N / 16;                      // threads per FFT
@@ -47,9 +52,10 @@ struct Geometry {
     static constexpr int T1 = N / R1;                     // butterflies in pass 1
     static constexpr int B1 = 16 / R1;                    // pass-1 butterflies per thread
     static constexpr int BM = 16 / RM;                    // middle butterflies per thread
-    static constexpr int S1 = T1 + T1 / 16;               // row stride of exchange 1 (q1-major)
-    static constexpr int S2 = T + 1;                      // row stride of the last layout (t-major)
-    static constexpr int SF = 17 * (N / 16);              // LDS region of one FFT (float2)
+    static constexpr int S1 = T1 + (PAD ? T1 / 16 : 0);   // row stride of exchange 1 (q1-major)
+    static constexpr int S2 = T + (PAD ? 1 : 0);          // row stride of the last layout (t-major)
+    static constexpr int S0 = PAD ? 17 : 16;              // row stride of the two-pass sizes' only layout
+    static constexpr int SF = PAD ? 17 * (N / 16) : N;    // LDS region of one FFT (float2)
     static constexpr bool kMultiWave = (T > 64);
     // N = 512 / 1024: exchange 1 is a transpose between the lane's row bits (lane >> 4) and the top
     // register-index bits, done in registers with v_permlane16_swap / v_permlane32_swap: no LDS.
@@ -65,7 +71,18 @@ struct Geometry {
 #define SMFFT_REG_TWOPASS_MAX_N 64
 #endif
     static constexpr bool kRegTwoPass = (RM == 1) && (N <= SMFFT_REG_TWOPASS_MAX_N);
-    static constexpr int kFftsPerBlock = 4096 / N;
+    static constexpr int kFftsPerBlock = 4096 / N;        // tiled kernels: 256 threads own 4096 elements
+    // compact kernels (the in-LDS `multiple` path): the smallest workgroup that holds whole FFTs --
+    // one wave and 1024 elements for N <= 1024, N / 16 threads and one FFT above
+    static constexpr int kCompactThreads = T < 64 ? 64 : T;
+    static constexpr int kCompactTile = N < 1024 ? 1024 : N;
+    static constexpr int kCompactFfts = kCompactTile / N;
+    static constexpr int kCompactLds = (kCompactTile / N) * SF;
+    // no-reorder variants keep their data in LDS with one pad per 2^kPadShift elements (p -> p + (p >> kPadShift)),
+    // the layout from which a thread can read its 16 bit-reversal-contiguous elements without bank conflicts
+    // (N = 1024: roles must equal lanes for the register exchange 1, so the rows a read group touches are the
+    // even or the odd ones: one pad per 32 elements makes those 32 rows distinct mod 32 as well)
+    static constexpr int kPadShift = (N == 1024) ? 5 : 4;
 };
 
 constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n >> 1); }
@@ -140,6 +157,40 @@ __device__ __forceinline__ float2 lds_read_single(const float2* region, int inde
     return region[index];
 }
 
+// Sixteen single ds_read_b64 off ONE address register with compile-time byte offsets 8 * STRIDE * i, as one
+// inline-assembly block that ends with its own s_waitcnt (the compiler does not count inline-assembly DS
+// operations).  Why not plain C++: hipcc merges two reads of one base into ds_read2_b64, which the LDS serves in
+// 16-lane groups over 32 banks at half the rate of ds_read_b64 (MI355X_MICROARCH.md, LDS table).
+// SMFFT_SINGLE_READS = 0 leaves the merging to the compiler (A/B switch).
+#ifndef SMFFT_SINGLE_READS
+#define SMFFT_SINGLE_READS 1
+#endif
+template <int STRIDE>
+__device__ __forceinline__ void lds_read16(float2 (&r)[16], const float2* base) {
+#if SMFFT_SINGLE_READS
+    static_assert(8 * STRIDE * 15 < 65536, "DS offset field is 16 bits");
+    typedef __attribute__((address_space(3))) const float2 lds_float2;
+    const unsigned a = (unsigned)(unsigned long)(lds_float2*)base;
+    v2f v[16];
+    asm volatile(
+        "ds_read_b64 %0, %16 offset:%17\n\tds_read_b64 %1, %16 offset:%18\n\tds_read_b64 %2, %16 offset:%19\n\tds_read_b64 %3, %16 offset:%20\n\t"
+        "ds_read_b64 %4, %16 offset:%21\n\tds_read_b64 %5, %16 offset:%22\n\tds_read_b64 %6, %16 offset:%23\n\tds_read_b64 %7, %16 offset:%24\n\t"
+        "ds_read_b64 %8, %16 offset:%25\n\tds_read_b64 %9, %16 offset:%26\n\tds_read_b64 %10, %16 offset:%27\n\tds_read_b64 %11, %16 offset:%28\n\t"
+        "ds_read_b64 %12, %16 offset:%29\n\tds_read_b64 %13, %16 offset:%30\n\tds_read_b64 %14, %16 offset:%31\n\tds_read_b64 %15, %16 offset:%32\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+          "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])
+        : "v"(a), "n"(0), "n"(8 * STRIDE), "n"(16 * STRIDE), "n"(24 * STRIDE), "n"(32 * STRIDE), "n"(40 * STRIDE), "n"(48 * STRIDE), "n"(56 * STRIDE),
+          "n"(64 * STRIDE), "n"(72 * STRIDE), "n"(80 * STRIDE), "n"(88 * STRIDE), "n"(96 * STRIDE), "n"(104 * STRIDE), "n"(112 * STRIDE), "n"(120 * STRIDE)
+        : "memory");
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = make_float2(v[i].x, v[i].y);
+#else
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = base[STRIDE * i];
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // Small in-register DFTs (R = 2, 4, 8, 16), decimation in time on compile-time indices.
 // in[k*STRIDE], k < R  ->  out[q], q < R (natural order).  DIR = 0: e^{-2 pi i/R}, 1: e^{+}.
@@ -206,11 +257,12 @@ struct Twiddles {
 // ------------------------------------------------------------------------------------------------
 // The engine.  One instance per thread; tid = threadIdx.x in a 256-thread workgroup.
 // ------------------------------------------------------------------------------------------------
-template <int N, int DIR, int REORDER>
+template <int N, int DIR, int REORDER, bool PAD = true>
 struct Engine {
-    using G = Geometry<N>;
+    using G = Geometry<N, PAD>;
+    static_assert(PAD || REORDER, "the unpadded engine exists for the natural-order (Stockham) entry points only");
     static constexpr int T = G::T, R1 = G::R1, RM = G::RM, T1 = G::T1, B1 = G::B1, BM = G::BM;
-    static constexpr int S1 = G::S1, S2 = G::S2, SF = G::SF;
+    static constexpr int S1 = G::S1, S2 = G::S2, S0 = G::S0, SF = G::SF;
     static constexpr int E_BITS = ilog2c(N), T_BITS = ilog2c(T), R1_BITS = ilog2c(R1), B1_BITS = ilog2c(B1);
 
 #ifndef SMFFT_ROW_TOP_LANES
@@ -265,10 +317,7 @@ struct Engine {
 #pragma unroll
         for (int c = 0; c < 16; ++c) r[c] = gload(g + u + T * c);
     }
-    __device__ __forceinline__ void load_lds(float2 (&r)[16], const float2* sf) const {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) r[c] = sf[u + T * c];
-    }
+    __device__ __forceinline__ void load_lds(float2 (&r)[16], const float2* sf) const { lds_read16<T>(r, sf + u); }
 
     // ---- natural registers -> pass-1 slots r[b*R1 + r1] = x'[t1 + T1*r1], t1 = u + T*b ------------
     // REORDER: x' = x, and t1 + T1*r1 = u + T*(b + B1*r1): a compile-time renaming of registers.
@@ -313,37 +362,74 @@ struct Engine {
                     r[b * R1 + r1] = t[((j & (T - 1)) << B1_BITS) | (j >> T_BITS)];
                 }
         } else {
-            // pad shift: one pad per 16 elements, except N = 1024 (roles must equal lanes for the
-            // register exchange 1, so the rows a read group touches are the even or the odd ones):
-            // one pad per 32 elements makes those 32 rows distinct mod 32 as well.
-            constexpr int PS = (N == 1024) ? 5 : 4;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const int p = u + T * c;
-                sf[p + (p >> PS)] = r[c];
-            }
+            bitrev_write(r, sf);
             fft_sync<G::kMultiWave>();
-            const int g16 = 16 * (int)(__brev((unsigned)t1) >> (32 - T_BITS));
-            const int row = g16 + (g16 >> PS);
-#pragma unroll
-            for (int b = 0; b < B1; ++b)
-#pragma unroll
-                for (int r1 = 0; r1 < R1; ++r1) {
-                    const int rb = (B1_BITS > 0) ? (int)(__brev((unsigned)b) >> (32 - (B1_BITS > 0 ? B1_BITS : 1))) : 0;
-                    const int rr = (R1_BITS > 0) ? (int)(__brev((unsigned)r1) >> (32 - (R1_BITS > 0 ? R1_BITS : 1))) : 0;
-                    // single ds_read_b64 (32-lane groups, 64 banks): merged into ds_read2_b64 these reads are served
-                    // in 16-lane groups over 32 banks, where the rows of bit-reversed neighbours collide (measured
-                    // 0.14 conflict cycles per LDS cycle)
-                    if constexpr (PACED) {
-                        const v2f t = *reinterpret_cast<const volatile v2f*>(&sf[row + rb * R1 + rr]);
-                        r[b * R1 + r1] = make_float2(t.x, t.y);
-                    } else {
-                        r[b * R1 + r1] = lds_read_single(sf, row + rb * R1 + rr);
-                    }
-                }
+            bitrev_read<PACED>(r, sf);
             fft_sync<G::kMultiWave>();
         }
     }
+
+    // The two halves of the LDS transposition of the no-reorder variants (N >= 128).
+    // bitrev_write: natural registers (r[c] = x[u + T*c]; also the layout of a transform's RESULT) -> the padded
+    // image, element p at p + (p >> kPadShift): consecutive lanes write consecutive p, conflict free.
+    __device__ __forceinline__ void bitrev_write(const float2 (&r)[16], float2* sf) const {
+        constexpr int PS = G::kPadShift;
+        // (u + T*c) >> PS == (u >> PS) + (T*c >> PS): T*c is a multiple of 2^PS (T >= 2^PS), or u + (T*c mod 2^PS) < 2^PS
+        // (T < 2^PS, where u >> PS = 0): one base address and sixteen compile-time offsets
+        const int base = u + (u >> PS);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sf[base + T * c + ((T * c) >> PS)] = r[c];
+    }
+    // bitrev_read: padded image -> pass-1 slots; the thread with role t1 reads the 16 contiguous elements of row
+    // rev_T(t1), in bit-reversed order within the row.  Sixteen single ds_read_b64 off ONE address register with
+    // immediate offsets.  Written as inline assembly because hipcc merges neighbouring reads into ds_read2_b64, which
+    // is served in 16-lane groups over 32 banks -- half the rate of ds_read_b64 (MI355X_MICROARCH.md, LDS table) and,
+    // here, with the rows of bit-reversed neighbours colliding (measured 0.14 conflict cycles per LDS cycle in round 1).
+    // The compiler does not count inline-assembly DS operations, so the block ends with its own s_waitcnt.
+    // PACED: volatile generic-pointer loads instead (flat_load + s_waitcnt vmcnt(0) each): the "LDS trip" of the
+    // external N = 128 no-reorder kernel, smfft_kernels.hpp.
+    template <bool PACED = false>
+    __device__ __forceinline__ void bitrev_read(float2 (&r)[16], const float2* sf) const {
+        constexpr int PS = G::kPadShift;
+        const int g16 = 16 * (int)(__brev((unsigned)t1) >> (32 - T_BITS));
+        const float2* row = sf + g16 + (g16 >> PS);
+        if constexpr (PACED) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const v2f t = *reinterpret_cast<const volatile v2f*>(&row[slot_source(i)]);
+                r[i] = make_float2(t.x, t.y);
+            }
+        } else {
+            typedef __attribute__((address_space(3))) const float2 lds_float2;
+            const unsigned a = (unsigned)(unsigned long)(lds_float2*)row;
+            v2f v[16];
+            asm volatile(
+                "ds_read_b64 %0, %16 offset:%17\n\tds_read_b64 %1, %16 offset:%18\n\tds_read_b64 %2, %16 offset:%19\n\tds_read_b64 %3, %16 offset:%20\n\t"
+                "ds_read_b64 %4, %16 offset:%21\n\tds_read_b64 %5, %16 offset:%22\n\tds_read_b64 %6, %16 offset:%23\n\tds_read_b64 %7, %16 offset:%24\n\t"
+                "ds_read_b64 %8, %16 offset:%25\n\tds_read_b64 %9, %16 offset:%26\n\tds_read_b64 %10, %16 offset:%27\n\tds_read_b64 %11, %16 offset:%28\n\t"
+                "ds_read_b64 %12, %16 offset:%29\n\tds_read_b64 %13, %16 offset:%30\n\tds_read_b64 %14, %16 offset:%31\n\tds_read_b64 %15, %16 offset:%32\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+                  "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])
+                : "v"(a), "n"(8 * slot_source(0)), "n"(8 * slot_source(1)), "n"(8 * slot_source(2)), "n"(8 * slot_source(3)), "n"(8 * slot_source(4)),
+                  "n"(8 * slot_source(5)), "n"(8 * slot_source(6)), "n"(8 * slot_source(7)), "n"(8 * slot_source(8)), "n"(8 * slot_source(9)),
+                  "n"(8 * slot_source(10)), "n"(8 * slot_source(11)), "n"(8 * slot_source(12)), "n"(8 * slot_source(13)), "n"(8 * slot_source(14)),
+                  "n"(8 * slot_source(15))
+                : "memory");
+#pragma unroll
+            for (int i = 0; i < 16; ++i) r[i] = make_float2(v[i].x, v[i].y);
+        }
+    }
+    // pass-1 slot i = b*R1 + r1 takes element rev_B1(b)*R1 + rev_R1(r1) of the thread's row
+    static constexpr int slot_source(int i) {
+        const int b = i / R1, r1 = i % R1;
+        int rb = 0, rr = 0;
+        for (int k = 0; k < B1_BITS; ++k) rb |= ((b >> k) & 1) << (B1_BITS - 1 - k);
+        for (int k = 0; k < R1_BITS; ++k) rr |= ((r1 >> k) & 1) << (R1_BITS - 1 - k);
+        return rb * R1 + rr;
+    }
+    // position of element n of an FFT in the padded image
+    __device__ static __forceinline__ int padded_index(int n) { return n + (n >> G::kPadShift); }
 
     // ---- pass 1: B1 radix-R1 butterflies, then W_N^{t1*q1} -------------------------------------
     __device__ __forceinline__ void pass1(float2 (&r)[16]) const {
@@ -462,11 +548,11 @@ struct Engine {
 #pragma unroll
             for (int q1 = 0; q1 < 16; ++q1) sf[q1 * S1 + t1] = r[q1];
         } else {
-            // two-pass sizes go straight to the last layout: element (t1, q1) at q1*17 + t1
+            // two-pass sizes go straight to the last layout: element (t1, q1) at q1*S0 + t1
 #pragma unroll
             for (int b = 0; b < B1; ++b)
 #pragma unroll
-                for (int q1 = 0; q1 < R1; ++q1) sf[q1 * 17 + t1 + T * b] = r[b * R1 + q1];
+                for (int q1 = 0; q1 < R1; ++q1) sf[q1 * S0 + t1 + T * b] = r[b * R1 + q1];
         }
     }
 
@@ -500,13 +586,8 @@ struct Engine {
     // ---- last pass: one radix-16 butterfly per thread; r[q3] = X[u + T*q3] -----------------------
     __device__ __forceinline__ void last(float2 (&r)[16], const float2* sf) const {
         float2 x[16];
-        if constexpr (RM > 1) {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) x[t] = sf[t * S2 + u];
-        } else {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) x[t] = sf[u * 17 + t];
-        }
+        if constexpr (RM > 1) lds_read16<S2>(x, sf + u);
+        else lds_read16<1>(x, sf + u * S0);
         SmallDft<16, 1, DIR>::run(x, r);
     }
 
@@ -528,6 +609,10 @@ struct Engine {
     template <bool PACED = false>
     __device__ __forceinline__ void transform(float2 (&r)[16], float2* sf) const {
         to_pass1_layout<PACED>(r, sf);
+        transform_from_pass1_slots(r, sf);
+    }
+    // the transform of registers that already hold the pass-1 slots (after to_pass1_layout or bitrev_read)
+    __device__ __forceinline__ void transform_from_pass1_slots(float2 (&r)[16], float2* sf) const {
         pass1(r);
         if constexpr (G::kRegTwoPass) {
             float2 x[16];
@@ -547,13 +632,14 @@ struct Engine {
 };
 
 // ------------------------------------------------------------------------------------------------
-// Device-function surface (reference names).  In place on the workgroup's LDS array; see the
-// layout contract at the top of this file.
+// In place on one FFT's LDS region (natural order in, natural order out): the building block of the
+// device functions in smfft_device_functions.hpp.  `stride` = float2 distance between the FFTs the
+// workgroup holds (Geometry::SF in the tiled kernels, N where FFTs are packed contiguously).
 // ------------------------------------------------------------------------------------------------
-template <int N, int DIR, int REORDER>
-__device__ __forceinline__ void fft_lds_inplace(float2* s, const Engine<N, DIR, REORDER>& eng) {
-    using G = Geometry<N>;
-    float2* sf = s + eng.fft * G::SF;
+template <int N, int DIR, int REORDER, bool PAD>
+__device__ __forceinline__ void fft_lds_inplace(float2* s, const Engine<N, DIR, REORDER, PAD>& eng, int stride = Geometry<N, PAD>::SF) {
+    using G = Geometry<N, PAD>;
+    float2* sf = s + eng.fft * stride;
     float2 r[16];
     eng.load_lds(r, sf);
     fft_sync<G::kMultiWave>();          // all inputs are in registers before the region is reused
@@ -562,13 +648,4 @@ __device__ __forceinline__ void fft_lds_inplace(float2* s, const Engine<N, DIR, 
     eng.store_lds(r, sf);
 }
 
-template <class const_params>
-__device__ void do_SMFFT_CT_DIT(float2* s_input) {
-    Engine<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder> eng;
-    eng.init(threadIdx.x);
-    fft_lds_inplace(s_input, eng);
-}
-
 }  // namespace smfft
-
-using smfft::do_SMFFT_CT_DIT;

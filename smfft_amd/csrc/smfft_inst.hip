@@ -29,6 +29,9 @@ int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int i
         if (inverse && reorder)   SMFFT_EXTERNAL_REORDER_KERNEL<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count);
         if (inverse && !reorder)  SMFFT_DIT_external<CT_CLASS(_inverse_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count);
     } else {
+        // in-LDS path: compact workgroups (one wave per 1024 elements for N <= 1024, one FFT per workgroup above)
+        grid = dim3(grid_for(count, Geometry<SMFFT_N>::kCompactFfts, grid_cap));
+        block = dim3(Geometry<SMFFT_N>::kCompactThreads);
         if (!inverse && reorder)  SMFFT_DIT_multiple<CT_CLASS(_forward)><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
         if (!inverse && !reorder) SMFFT_DIT_multiple<CT_CLASS(_forward_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
         if (inverse && reorder)   SMFFT_DIT_multiple<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
@@ -62,7 +65,7 @@ int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int p
 #else
     if (path == 0) FFT_GPU_external<ST_CLASS><<<grid, block, 0, stream>>>(d_input, d_output, count);
 #endif
-    else           FFT_GPU_multiple<ST_CLASS><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
+    else           FFT_GPU_multiple<ST_CLASS><<<dim3(grid_for(count, Geometry<SMFFT_N>::kCompactFfts, grid_cap)), dim3(Geometry<SMFFT_N>::kCompactThreads), 0, stream>>>(d_input, d_output, count, nreuses);
     return (int)hipGetLastError();
 }
 
@@ -75,6 +78,8 @@ int launch_rc<SMFFT_N>(const float2* d_input, float2* d_output, int count, int i
         if (!inverse) FFT_GPU_R2C_C2R_external<ST_CLASS, FFT_forward><<<grid, block, 0, stream>>>(d_input, d_output, count);
         else          FFT_GPU_R2C_C2R_external<ST_CLASS, FFT_inverse><<<grid, block, 0, stream>>>(d_input, d_output, count);
     } else {
+        grid = dim3(grid_for(count, Geometry<SMFFT_N>::kCompactFfts, grid_cap));
+        block = dim3(Geometry<SMFFT_N>::kCompactThreads);
         if (!inverse) FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_forward><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
         else          FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_inverse><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
     }

@@ -16,21 +16,8 @@
 // section 5).  Grids are grid-strided over tiles so a capped ("persistent") grid keeps twiddles in
 // registers.
 #pragma once
-#include "smfft_engine.hpp"
-#include "SM_FFT_stockham_parameters.hpp"
+#include "smfft/smfft_device_functions.hpp"
 
-#ifndef NREUSES
-#define NREUSES 100
-#endif
-// minimum waves per SIMD requested for the in-LDS `multiple` kernels (0 = let the compiler decide)
-#ifndef SMFFT_MULT_WAVES
-#define SMFFT_MULT_WAVES 0
-#endif
-#if SMFFT_MULT_WAVES > 0
-#define SMFFT_MULT_BOUNDS __launch_bounds__(256, SMFFT_MULT_WAVES)
-#else
-#define SMFFT_MULT_BOUNDS __launch_bounds__(256)
-#endif
 // external kernels stage through LDS with wave-coalesced global access up to this length
 #ifndef SMFFT_STAGED_MAX_N
 #define SMFFT_STAGED_MAX_N 128
@@ -196,85 +183,119 @@ __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_i
     }
 }
 
-// tile <-> LDS copies in the natural per-FFT-region layout (used by the `multiple` kernels and
-// by the R2C/C2R kernels): element e of the tile belongs to FFT e/N, position e%N.
-template <int N>
+// ------------------------------------------------------------------------------------------------
+// In-LDS (`multiple`) path.  COMPACT workgroups: the smallest workgroup that holds whole FFTs -- one wave owning
+// 1024 elements (1024/N FFTs) for N <= 1024, N/16 threads owning one FFT above -- so that (a) an N <= 1024 kernel
+// has no workgroup barrier anywhere (a wave's DS operations execute in order) and (b) the README batches, which
+// are 5242 waves' worth of FFT slots for every N, spread over the chip's wave slots one wave at a time instead
+// of in 1311 four-wave blocks on 1024 block slots (the tail quantisation round 1 measured at 25 %).
+// tile <-> LDS copies: element e of the tile belongs to FFT e/N, position n = e%N of its region; PADDED: position
+// n + (n >> kPadShift), the image the no-reorder variants keep their data in (Engine::bitrev_write / bitrev_read).
+// ------------------------------------------------------------------------------------------------
+// LDS index of tile element e = threadIdx.x + kCompactThreads * c, split into a per-thread base and a compile-time
+// offset (so that the sixteen accesses share one address register): element e is position n = e % N of FFT e / N.
+// Either N >= kCompactThreads (the thread index is the low part of n and never carries into the offset) or N divides
+// kCompactThreads (the thread index contributes its own FFT number and position); the pad term splits the same way
+// because kCompactThreads * c is a multiple of 2^kPadShift.
+template <int N, bool PADDED>
+__device__ __forceinline__ int compact_lds_base() {
+    using G = Geometry<N>;
+    const int t = threadIdx.x % N, j = threadIdx.x / N;
+    return j * G::SF + t + (PADDED ? (t >> G::kPadShift) : 0);
+}
+template <int N, bool PADDED>
+constexpr int compact_lds_offset(int c) {
+    using G = Geometry<N>;
+    const int e = G::kCompactThreads * c;
+    return (e / N) * G::SF + (e % N) + (PADDED ? ((e % N) >> G::kPadShift) : 0);
+}
+template <int N, bool PADDED>
 __device__ __forceinline__ void tile_to_lds(const float2* __restrict__ g, float2* s, long first_fft, long limit_fft) {
     using G = Geometry<N>;
+    constexpr int C = G::kCompactTile / G::kCompactThreads;
+    static_assert(!PADDED || N >= G::kCompactThreads, "the padded image exists for N >= 128 only");
+    float2 v[C];
+    if (first_fft + G::kCompactFfts <= limit_fft) {      // whole tile inside the batch: loads back to back, no predicate
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const int e = threadIdx.x + 256 * c;
-        const int j = e / N, n = e % N;
-        s[j * G::SF + n] = (first_fft + j < limit_fft) ? g[e] : make_float2(0.f, 0.f);
+        for (int c = 0; c < C; ++c) v[c] = g[threadIdx.x + G::kCompactThreads * c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int e = threadIdx.x + G::kCompactThreads * c;
+            const bool ok = first_fft + e / N < limit_fft;
+            const float2 t = g[ok ? e : 0];              // g[0] belongs to FFT first_fft, which exists
+            v[c] = ok ? t : make_float2(0.f, 0.f);
+        }
     }
+    float2* base = s + compact_lds_base<N, PADDED>();
+#pragma unroll
+    for (int c = 0; c < C; ++c) base[compact_lds_offset<N, PADDED>(c)] = v[c];
 }
-template <int N>
+template <int N, bool PADDED>
 __device__ __forceinline__ void lds_to_tile(float2* __restrict__ g, const float2* s, long first_fft, long limit_fft) {
     using G = Geometry<N>;
+    constexpr int C = G::kCompactTile / G::kCompactThreads;
+    float2 v[C];
+    const float2* base = s + compact_lds_base<N, PADDED>();
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const int e = threadIdx.x + 256 * c;
-        const int j = e / N, n = e % N;
-        if (first_fft + j < limit_fft) g[e] = s[j * G::SF + n];
+    for (int c = 0; c < C; ++c) v[c] = base[compact_lds_offset<N, PADDED>(c)];
+    if (first_fft + G::kCompactFfts <= limit_fft) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) g[threadIdx.x + G::kCompactThreads * c] = v[c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int e = threadIdx.x + G::kCompactThreads * c;
+            if (first_fft + e / N < limit_fft) g[e] = v[c];
+        }
     }
 }
 
 // C2C, multiple: the first nSlots FFTs are loaded once, transformed nreuses (= NREUSES = 100 in the
 // benchmark; a kernel argument so the tests can run 1, 2 and 4 applications) times in LDS, stored once.
+// Every application reads its input from LDS and writes its result to LDS (the device function's contract);
+// what the kernel chooses is the IMAGE the data are kept in between applications: natural order for the reorder
+// variants (and for N <= 64, whose bit-reversal is a register transposition), the padded image of
+// Engine::bitrev_write for the no-reorder variants of N >= 128 -- a result is stored straight into the layout the
+// next application's bit-reversed read wants, instead of natural order + a second write and read (round 1: 64 LDS
+// instructions per N = 1024 FFT against 32 for reorder; now 32 + 32 either way).
 template <int N, int DIR, int REORDER>
 __device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, float2* s) {
     using G = Geometry<N>;
+    constexpr bool kPaddedImage = !REORDER && !G::kRegTwoPass;
     Engine<N, DIR, REORDER> eng;
     eng.init(threadIdx.x);
-    const int ntiles = (nSlots + G::kFftsPerBlock - 1) / G::kFftsPerBlock;
+    float2* sf = s + eng.fft * G::SF;
+    const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long first = (long)tile * G::kFftsPerBlock;
-        __syncthreads();
-        tile_to_lds<N>(d_input + first * N, s, first, nSlots);
-        __syncthreads();
+        const long first = (long)tile * G::kCompactFfts;
+        fft_sync<G::kMultiWave>();
+        tile_to_lds<N, kPaddedImage>(d_input + first * N, s, first, nSlots);
+        fft_sync<G::kMultiWave>();
         for (int f = 0; f < nreuses; ++f) {
-            fft_lds_inplace(s, eng);
+            float2 r[16];
+            if constexpr (kPaddedImage) {
+                eng.bitrev_read(r, sf);
+                fft_sync<G::kMultiWave>();          // all inputs are in registers before the region is reused
+                eng.transform_from_pass1_slots(r, sf);
+                fft_sync<G::kMultiWave>();          // all exchange reads done before the results overwrite them
+                eng.bitrev_write(r, sf);
+            } else {
+                eng.load_lds(r, sf);
+                fft_sync<G::kMultiWave>();
+                eng.transform(r, sf);
+                fft_sync<G::kMultiWave>();
+                eng.store_lds(r, sf);
+            }
             fft_sync<G::kMultiWave>();   // the reference omits this (latent race, CT:563-565)
         }
-        __syncthreads();
-        lds_to_tile<N>(d_output + first * N, s, first, nSlots);
+        lds_to_tile<N, kPaddedImage>(d_output + first * N, s, first, nSlots);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// R2C / C2R (real length 2L through a complex FFT of length L).  RC:269-344.
-// Hermitian split (forward, after the C2C) / merge (inverse, before the C2C) on the natural
-// layout in LDS; thread u of an FFT handles the 8 index pairs i = 1 + u + T*j, (i, L - i).
+// R2C / C2R external kernels (real length 2L through a complex FFT of length L, RC:269-365): tiled form.
 // ------------------------------------------------------------------------------------------------
-template <int L, int DIR>
-__device__ __forceinline__ void hermitian_pass(float2* sf, int u) {
-    constexpr int T = L / 16;
-    constexpr float ohx = DIR ? -0.5f : 0.5f, ohy = DIR ? 0.5f : -0.5f;
-    if (DIR) {
-        if (u == 0) {
-            float2 z = sf[0];
-            sf[0] = make_float2(0.5f * (z.x + z.y), 0.5f * (z.x - z.y));
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int i = 1 + u + T * j;
-        float2 A = sf[i], B = sf[L - i];
-        float2 H1 = make_float2(0.5f * (A.x + B.x), 0.5f * (A.y - B.y));
-        float2 H2 = make_float2(ohx * (A.y + B.y), ohy * (A.x - B.x));
-        float2 W = twiddle<DIR>(i * (4096 / (2 * L)));
-        float2 WH = cmul(H2, W);
-        sf[i] = make_float2(H1.x + WH.x, H1.y + WH.y);
-        sf[L - i] = make_float2(H1.x - WH.x, -H1.y + WH.y);   // for i == L/2 this value stays (RC:308)
-    }
-    if (!DIR) {
-        if (u == 0) {   // sf[0] is not touched by the pair loop (i >= 1, L - i >= L/2)
-            float2 z = sf[0];
-            sf[0] = make_float2(z.x + z.y, z.x - z.y);
-        }
-    }
-}
-
 // The same split / merge on the NATURAL REGISTER layout (r[q] = element u + T*q of the thread's FFT), for FFTs that
 // live in one wave (L <= 1024).  Element i pairs with L - i, which thread (T - u) mod T holds in register 15 - q
 // (thread 0 pairs with itself, register 16 - q): one ds_bpermute per dword fetches it -- no LDS memory, no
@@ -334,22 +355,6 @@ struct HermitianRegisters {
     }
 };
 
-// In place on LDS, natural layout, region per FFT (device-function form; RC:269-344).
-template <int L, int DIR>
-__device__ __forceinline__ void r2c_c2r_lds_inplace(float2* s, const Engine<L, DIR, 1>& eng) {
-    using G = Geometry<L>;
-    float2* sf = s + eng.fft * G::SF;
-    if (DIR == 0) {
-        fft_lds_inplace(s, eng);
-        fft_sync<G::kMultiWave>();
-        hermitian_pass<L, 0>(sf, eng.u);
-    } else {
-        hermitian_pass<L, 1>(sf, eng.u);
-        fft_sync<G::kMultiWave>();
-        fft_lds_inplace(s, eng);
-    }
-}
-
 template <int L, int DIR>
 __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nFFTs, float2* s) {
     using G = Geometry<L>;
@@ -400,18 +405,17 @@ __device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__
     using G = Geometry<L>;
     Engine<L, DIR, 1> eng;
     eng.init(threadIdx.x);
-    const int ntiles = (nSlots + G::kFftsPerBlock - 1) / G::kFftsPerBlock;
+    const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long first = (long)tile * G::kFftsPerBlock;
-        __syncthreads();
-        tile_to_lds<L>(d_input + first * L, s, first, nSlots);
-        __syncthreads();
+        const long first = (long)tile * G::kCompactFfts;
+        fft_sync<G::kMultiWave>();
+        tile_to_lds<L, false>(d_input + first * L, s, first, nSlots);
+        fft_sync<G::kMultiWave>();
         for (int f = 0; f < nreuses; ++f) {
-            r2c_c2r_lds_inplace<L, DIR>(s, eng);
+            r2c_c2r_lds_inplace<L, DIR, true>(s, eng);
             fft_sync<G::kMultiWave>();
         }
-        __syncthreads();
-        lds_to_tile<L>(d_output + first * L, s, first, nSlots);
+        lds_to_tile<L, false>(d_output + first * L, s, first, nSlots);
     }
 }
 
@@ -461,11 +465,12 @@ __global__ void __launch_bounds__(256) SMFFT_stream_copy(const float2* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// Kernels and device functions under the reference's names.
+// The library's kernels (reference names, one more argument than upstream: the batch size, because grids are
+// capped and grid-strided).  The reference-shaped two-argument forms are in smfft/smfft_device_functions.hpp.
 // ------------------------------------------------------------------------------------------------
 template <class const_params>
 __global__ void __launch_bounds__(256) SMFFT_DIT_external(const float2* d_input, float2* d_output, int nFFTs) {
-    __shared__ float2 s_input[const_params::fft_sm_required];
+    __shared__ float2 s_input[const_params::tile_sm_required];
     smfft::c2c_external_body<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nFFTs, s_input);
 }
 // The same kernel compiled for exactly 3 waves per SIMD.  The launcher uses it for the N = 4096 reorder
@@ -475,54 +480,43 @@ __global__ void __launch_bounds__(256) SMFFT_DIT_external(const float2* d_input,
 template <class const_params>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 SMFFT_DIT_external_occ3(const float2* d_input, float2* d_output, int nFFTs) {
-    __shared__ float2 s_input[const_params::fft_sm_required];
+    __shared__ float2 s_input[const_params::tile_sm_required];
     smfft::c2c_external_body<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nFFTs, s_input);
 }
 
+// SMFFT_MULT_MINWAVES (experiment switch): minimum waves per SIMD the compact kernels are compiled for
+#ifdef SMFFT_MULT_MINWAVES
+#define SMFFT_COMPACT_BOUNDS(N) __launch_bounds__(smfft::Geometry<N>::kCompactThreads, SMFFT_MULT_MINWAVES)
+#else
+#define SMFFT_COMPACT_BOUNDS(N) __launch_bounds__(smfft::Geometry<N>::kCompactThreads)
+#endif
+
 template <class const_params>
-__global__ void SMFFT_MULT_BOUNDS SMFFT_DIT_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
-    __shared__ float2 s_input[const_params::fft_sm_required];
+__global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_size) SMFFT_DIT_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
+    __shared__ float2 s_input[smfft::Geometry<const_params::fft_size>::kCompactLds];
     smfft::c2c_multiple_body<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nSlots, nreuses, s_input);
 }
 
 // Stockham C2C program: un-normalised INVERSE (+i) transform, natural order (ST:76, :429).
-template <class const_params>
-__device__ void do_FFT_Stockham_mk6(float2* s_input) {
-    smfft::Engine<const_params::fft_length, 1, 1> eng;
-    eng.init(threadIdx.x);
-    smfft::fft_lds_inplace(s_input, eng);
-}
 template <class const_params>
 __global__ void __launch_bounds__(256) FFT_GPU_external(const float2* d_input, float2* d_output, int nFFTs) {
     __shared__ float2 s_input[4352];
     smfft::c2c_external_body<const_params::fft_length, 1, 1>(d_input, d_output, nFFTs, s_input);
 }
 template <class const_params>
-__global__ void SMFFT_MULT_BOUNDS FFT_GPU_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
-    __shared__ float2 s_input[4352];
+__global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_length) FFT_GPU_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
+    __shared__ float2 s_input[smfft::Geometry<const_params::fft_length>::kCompactLds];
     smfft::c2c_multiple_body<const_params::fft_length, 1, 1>(d_input, d_output, nSlots, nreuses, s_input);
 }
 
 // R2C/C2R program.
-template <class const_params, class const_direction>
-__device__ void do_FFT_Stockham_C2C(float2* s_input) {
-    smfft::Engine<const_params::fft_length, const_direction::fft_direction, 1> eng;
-    eng.init(threadIdx.x);
-    smfft::fft_lds_inplace(s_input, eng);
-}
-template <class const_params, class const_direction>
-__device__ void do_FFT_Stockham_R2C_C2R(float2* s_input) {
-    smfft::Engine<const_params::fft_length, const_direction::fft_direction, 1> eng;
-    eng.init(threadIdx.x);
-    smfft::r2c_c2r_lds_inplace<const_params::fft_length, const_direction::fft_direction>(s_input, eng);
-}
 template <class const_params, class const_direction>
 __global__ void __launch_bounds__(256) FFT_GPU_R2C_C2R_external(const float2* d_input, float2* d_output, int nFFTs) {
     __shared__ float2 s_input[4352];
     smfft::r2c_c2r_external_body<const_params::fft_length, const_direction::fft_direction>(d_input, d_output, nFFTs, s_input);
 }
 template <class const_params, class const_direction>
-__global__ void SMFFT_MULT_BOUNDS FFT_GPU_R2C_C2R_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
-    __shared__ float2 s_input[4352];
+__global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_length) FFT_GPU_R2C_C2R_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
+    __shared__ float2 s_input[smfft::Geometry<const_params::fft_length>::kCompactLds];
     smfft::r2c_c2r_multiple_body<const_params::fft_length, const_direction::fft_direction>(d_input, d_output, nSlots, nreuses, s_input);
 }

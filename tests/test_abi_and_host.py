@@ -67,14 +67,53 @@ def test_missing_library_fails_loudly(tmp_path):
     assert p.returncode != 0 and "no CPU fallback" in p.stderr
 
 
-def test_parameter_classes_match_reference_names():
-    hdr = open(os.path.join(ROOT, "smfft_amd", "csrc", "SM_FFT_parameters.hpp")).read()
-    for n in (32, 64, 128, 256, 512, 1024, 2048, 4096):
-        for suf in ("forward", "forward_noreorder", "inverse", "inverse_noreorder"):
-            assert f"class FFT_{n}_{suf} " in hdr
-    for member in ("fft_exp", "fft_sm_required", "fft_length", "fft_length_quarter", "fft_length_half",
-                   "fft_length_three_quarters", "fft_direction", "fft_reorder", "warp"):
-        assert member in hdr
+def test_parameter_classes_match_reference_names_and_values(tmp_path):
+    """The 32 parameter classes carry the reference's names, and the members the reference defines keep the reference's
+    VALUES (fft_exp, fft_length and its fractions, fft_direction, fft_reorder): a kernel written against them
+    (README.md:48-60) sees what it saw upstream.  Checked by compiling the header with g++ and, where the reference
+    checkout exists, against the numbers parsed out of SM_FFT_parameters.cuh itself.  Deliberate differences:
+    warp = 64, fft_sm_required = 17 * fft_length / 16 (>= upstream's (fft_length / 32) * 33), and
+    FFT_4096_inverse_noreorder::fft_direction = 1 (upstream 0, a typo)."""
+    import re
+    import shutil
+    hdr_path = os.path.join(ROOT, "include", "smfft", "SM_FFT_parameters.hpp")
+    hdr = open(hdr_path).read()
+    names = [f"FFT_{n}_{suf}" for n in (32, 64, 128, 256, 512, 1024, 2048, 4096) for suf in ("forward", "forward_noreorder", "inverse", "inverse_noreorder")]
+    for name in names:
+        assert f"class {name} " in hdr
+    members = ("fft_exp", "fft_sm_required", "fft_length", "fft_length_quarter", "fft_length_half", "fft_length_three_quarters", "fft_direction", "fft_reorder", "warp")
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    src = tmp_path / "params.cpp"
+    body = "".join('printf("%s' % name + " %d" * len(members) + '\\n", ' + ", ".join(f"(int){name}::{m}" for m in members) + ");\n" for name in names)
+    src.write_text('#include <cstdio>\n#include "smfft/SM_FFT_parameters.hpp"\nint main() {\n' + body + "return 0; }\n")
+    exe = tmp_path / "params"
+    subprocess.run(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = {}
+    for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines():
+        f = line.split()
+        got[f[0]] = dict(zip(members, map(int, f[1:])))
+    ref_path = "/root/reference/SMFFT_CooleyTukey_C2C/SM_FFT_parameters.cuh"
+    ref = {}
+    if os.path.exists(ref_path):
+        for m in re.finditer(r"class (FFT_\w+)\s*:\s*public FFT_Params\s*\{(.*?)\};", open(ref_path).read(), re.S):
+            ref[m.group(1)] = {k: int(v) for k, v in re.findall(r"static const int (\w+)\s*=\s*(-?\d+);", m.group(2))}
+        assert set(names) <= set(ref)
+    for name in names:
+        n = int(name.split("_")[1])
+        v = got[name]
+        length = max(n, 128)
+        want = {"fft_exp": n.bit_length() - 1, "fft_length": length, "fft_length_quarter": length // 4, "fft_length_half": length // 2,
+                "fft_length_three_quarters": 3 * length // 4, "fft_direction": int("inverse" in name), "fft_reorder": int("noreorder" not in name)}
+        for k, val in want.items():
+            assert v[k] == val, (name, k)
+            if ref and not (name == "FFT_4096_inverse_noreorder" and k == "fft_direction"):
+                assert ref[name][k] == val, (name, k, "reference value differs")
+        assert v["warp"] == 64 and v["fft_sm_required"] == 17 * length // 16
+        if ref:
+            assert v["fft_sm_required"] >= ref[name]["fft_sm_required"]
+    if ref:
+        assert ref["FFT_4096_inverse_noreorder"]["fft_direction"] == 0   # the upstream typo this library does not reproduce
 
 
 def test_shard_range_tiles_batch():

@@ -290,6 +290,78 @@ def test_example_convolution_kernel(sm, n, sym):
     assert l2 < 1e-6 and mx < 2e-6, (l2, mx)
 
 
+# ------------------------------------ the reference's own device contract (examples/reference_shape_kernel.hip)
+def _examples(sm):
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(sm.LIB_PATH), "libsmfft_examples.so")
+    if not os.path.exists(path):
+        pytest.skip("examples not built")
+    return ctypes.CDLL(path)
+
+
+@pytest.mark.parametrize("n", C2C_SIZES)
+@pytest.mark.parametrize("inv,reo", [(0, 1), (1, 1), (0, 0), (1, 0)])
+@pytest.mark.parametrize("which", [0, 1])
+def test_reference_shaped_kernel_matches_oracle(sm, oracle_lib, n, inv, reo, which):
+    """A kernel written exactly the way the reference's users write it -- blockDim.x = fft_length / 4 (32 for N <= 128),
+    the block's data contiguous in `__shared__ float2 s[P::fft_sm_required]`, do_SMFFT_CT_DIT<P>(s) between two
+    barriers, <<<nFFTs * N / fft_length, fft_length / 4>>> (README.md:48-60, CT:534-551, 586-595) -- gives the oracle's
+    result for every length and variant.  which = 0: a user-written kernel; 1: the library's two-argument
+    SMFFT_DIT_external<P>(in, out)."""
+    import ctypes
+    ex = _examples(sm)
+    fn = ex.smfft_example_reference_shape_ct
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    rng = np.random.default_rng(1000 * n + 10 * inv + reo)
+    nffts = 12 if n <= 128 else 5
+    x = (rng.random((nffts, n), dtype=np.float32) + 1j * rng.random((nffts, n), dtype=np.float32)).astype(np.complex64)
+    dx, dy = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
+    assert fn(dx.ptr, dy.ptr, n, nffts, inv, reo, which, None) == 0
+    assert sm.lib.smfft_synchronize() == 0
+    got = dy.to_host(np.complex64, x.shape)
+    ref.assert_close_fp32(got, oa.ct_c2c(oracle_lib, x, inv, reo, "f64"), f"reference-shaped kernel N={n} inv={inv} reorder={reo}")
+    # and it agrees with the library's tiled kernel (same engine behind both)
+    ref.assert_close_fp32(got, sm.c2c(x, inverse=bool(inv), reorder=bool(reo)).astype(np.complex128), "reference-shaped vs tiled kernel")
+
+
+@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096])
+def test_reference_shaped_stockham_kernel(sm, oracle_lib, n):
+    """FFT_GPU_external<FFT_N><<<nFFTs, N/4, N*8>>>(in, out) calling do_FFT_Stockham_mk6 on exactly N float2 of dynamic
+    LDS (ST:243-258, 309-319): the + sign transform, natural order."""
+    import ctypes
+    ex = _examples(sm)
+    fn = ex.smfft_example_reference_shape_st
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    rng = np.random.default_rng(n)
+    x = (rng.random((5, n), dtype=np.float32) + 1j * rng.random((5, n), dtype=np.float32)).astype(np.complex64)
+    dx, dy = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
+    assert fn(dx.ptr, dy.ptr, n, 5, None) == 0
+    assert sm.lib.smfft_synchronize() == 0
+    ref.assert_close_fp32(dy.to_host(np.complex64, x.shape), oa.st_c2c(oracle_lib, x, True, "f64"), f"reference-shaped Stockham N={n}")
+
+
+@pytest.mark.parametrize("n", R2C_SIZES)
+def test_reference_shaped_r2c_c2r_kernel(sm, oracle_lib, n):
+    """FFT_GPU_R2C_C2R_external<FFT_{N/2}, D><<<nFFTs, N/8>>>(in, out) on N/2 + 1 float2 of LDS (RC:349-365, 399-428)."""
+    import ctypes
+    ex = _examples(sm)
+    fn = ex.smfft_example_reference_shape_rc
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    rng = np.random.default_rng(n + 7)
+    x = rng.random((5, n), dtype=np.float32)
+    dx, dy = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
+    assert fn(dx.ptr, dy.ptr, n, 5, 0, None) == 0
+    assert sm.lib.smfft_synchronize() == 0
+    packed = dy.to_host(np.complex64, (5, n // 2))
+    ref.assert_close_fp32(packed, oa.r2c(oracle_lib, x, "f64"), f"reference-shaped R2C N={n}")
+    dz = sm.DeviceBuffer(x.nbytes)
+    assert fn(dy.ptr, dz.ptr, n, 5, 1, None) == 0
+    assert sm.lib.smfft_synchronize() == 0
+    back = dz.to_host(np.float32, x.shape)
+    ref.assert_close_fp32(back, oa.c2r(oracle_lib, packed, "f64"), f"reference-shaped C2R N={n}")
+
+
 # --------------------------------------------------------------------- API conventions (8(b))
 def test_time_accumulates_and_launch_on_stream(sm, oracle_lib):
     """`*FFT_time += elapsed` (CT:598,660-662): two calls on one accumulator add up; the launch-only
