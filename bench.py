@@ -10,12 +10,21 @@ batch (config 5: weak scaling, no data-path collective; RCCL only reduces the ti
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
-  roofline     : the dominant kernel against the HBM roofline (8.0 TB/s datasheet peak); `achieved`
-                 = algorithmic bytes per launch (2 * N * nFFTs * 8 B) / average launch duration
-                 measured with events on the launch stream over the timed region.
-  cpu_baseline : FFTW-API batched C2C (MKL's FFTW3 interface; real FFTW is not in the image) on the
-                 host cores of this box, bounded sample; falls back to the oracle's C restatement.
+`--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself: the parent process never touches
+the GPU, it only spawns one child per rank and returns the worst exit code.  `--gpus N` under a launcher whose
+WORLD_SIZE is not N is an error.
+
+Prints ONE JSON line on rank 0 (see the driver contract).  Objects beyond the contract:
+  roofline        the dominant kernel against the HBM roofline (8.0 TB/s datasheet peak) on the buffers the
+                  library's allocator hands out (smfft_malloc_pair: budget-bounded placement, DESIGN.md section 5);
+                  `achieved` = algorithmic bytes per launch (2 * N * nFFTs * 8 B) / average launch duration measured
+                  with events on the launch stream over the timed region.
+  roofline_plain  the same kernel, same pre-warm, same number of timed launches, on two PLAIN hipMalloc buffers
+                  (what a caller of FFT_external_benchmark brings along, CT:850-853).
+  configs         config 3 (N = 32..4096 no-reorder, FFT_multiple_benchmark: ms, FFT/s, TFLOP/s) and config 4
+                  (real N = 2048 R2C and C2R: ms, TB/s, fraction of peak), N = 1 only.
+  cpu_baseline    FFTW-API batched C2C (MKL's FFTW3 interface; real FFTW is not in the image) on the host cores of
+                  this box over the SAME input as the GPU run; falls back to the oracle's C restatement.
 PyTorch is plumbing only (device memory, stream, torch.distributed); the transform is the HIP
 library behind the C ABI (include/smfft.h).  There is no CPU fallback in the timed path.
 """
@@ -23,6 +32,8 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,15 +41,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FFT_SIZE = 1024
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak (spec)
 
 
-def cpu_baseline(n, sample_ffts, threads):
-    """FFTW-API batched plan on the host (oracle/fftw_baseline.so); fallback: oracle restatement."""
+def cpu_baseline(x, threads):
+    """FFTW-API batched plan on the host (oracle/fftw_baseline.so) over x = (nFFTs, N) complex64 -- the GPU run's own
+    input; fallback: the oracle's restatement on a slice of it."""
     import numpy as np
 
-    rng = np.random.default_rng(1)
-    x = (rng.random((sample_ffts, n), dtype=np.float32) + 1j * rng.random((sample_ffts, n), dtype=np.float32)).astype(np.complex64)
+    sample_ffts, n = x.shape
     out = np.empty_like(x)
     fp = ctypes.POINTER(ctypes.c_float)
     res = None
@@ -46,40 +58,39 @@ def cpu_baseline(n, sample_ffts, threads):
         fb = ctypes.CDLL(os.path.join(ROOT, "oracle", "fftw_baseline.so"))
         fb.fftw_baseline_init.argtypes = [ctypes.c_int]
         fb.fftw_baseline_backend.restype = ctypes.c_char_p
-        fb.fftw_baseline_c2c.restype = ctypes.c_double
-        fb.fftw_baseline_c2c.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         fb.fftw_baseline_c2c_sliced.restype = ctypes.c_double
         fb.fftw_baseline_c2c_sliced.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         # one single-threaded plan per batch slice, slices run concurrently (oracle/fftw_baseline.c);
         # a few thread counts are tried for a bounded time, `cores` = the count that won
-        cands = sorted({c for c in (1, 8, 32, 64, 128, threads // 2, threads) if 1 <= c <= threads})
+        cands = sorted({c for c in (8, 32, 64, 128, threads // 2, threads) if 1 <= c <= threads})
         best_all, best_thr = 1e30, 0
         t_start = time.time()
         if fb.fftw_baseline_init(1):
             for thr in cands:
                 if time.time() - t_start > 25.0:
                     break
-                t = fb.fftw_baseline_c2c_sliced(x.ctypes.data_as(fp), out.ctypes.data_as(fp), n, sample_ffts, 0, 5, thr)
+                t = fb.fftw_baseline_c2c_sliced(x.ctypes.data_as(fp), out.ctypes.data_as(fp), n, sample_ffts, 0, 3, thr)
                 if 0 < t < best_all:
                     best_all, best_thr = t, thr
         if best_all < 1e29:
             res = {"value": sample_ffts / best_all, "unit": "FFT/s", "cores": best_thr, "kind": "port",
                    "impl": fb.fftw_baseline_backend().decode() + " fftwf_plan_many_dft (FFTW_ESTIMATE) per batch slice, out of place, slices on pthreads; thread counts tried " + str(cands),
-                   "sample": f"N={n} C2C forward, {sample_ffts} FFTs ({x.nbytes >> 20} MiB in), best of 5 rounds",
+                   "sample": f"N={n} C2C forward, {sample_ffts} FFTs ({x.nbytes >> 20} MiB): the GPU run's own input copied to the host, best of 3 passes per thread count",
                    "host_cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
     except OSError:
         pass
     if res is None:
         olib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
         olib.oracle_ct_c2c_f32.argtypes = [fp, fp, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int]
+        part = min(sample_ffts, 131072)
         best = 1e30
         for _ in range(3):
             t0 = time.time()
-            olib.oracle_ct_c2c_f32(x.ctypes.data_as(fp), out.ctypes.data_as(fp), n, sample_ffts, 0, 1)
+            olib.oracle_ct_c2c_f32(x.ctypes.data_as(fp), out.ctypes.data_as(fp), n, part, 0, 1)
             best = min(best, time.time() - t0)
-        res = {"value": sample_ffts / best, "unit": "FFT/s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
+        res = {"value": part / best, "unit": "FFT/s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
                "kind": "port", "impl": "oracle/smfft_oracle.c radix-2 restatement, OpenMP over FFTs",
-               "sample": f"N={n} C2C forward, {sample_ffts} FFTs, best of 3"}
+               "sample": f"N={n} C2C forward, the first {part} FFTs of the GPU run's input, best of 3"}
     res["GB/s"] = res["value"] * 2 * n * 8 / 1e9
     return res
 
@@ -110,7 +121,7 @@ def device_info(torch, dev):
                 info[k] = getattr(p, k)
     except Exception as e:   # informational only
         info["error"] = repr(e)
-    # clocks / partition modes of the first amdgpu device the driver exposes (best effort, read-only sysfs)
+    # clocks / partition modes of the amdgpu device (best effort, read-only sysfs)
     try:
         import glob
         want = None
@@ -132,11 +143,6 @@ def device_info(torch, dev):
                     sysfs[name] = open(os.path.join(d, name)).read().strip().replace("\n", " | ")
                 except OSError:
                     pass
-            for cap in glob.glob(os.path.join(d, "hwmon", "hwmon*", "power1_cap")):
-                try:
-                    sysfs["power1_cap_uW"] = open(cap).read().strip()
-                except OSError:
-                    pass
             if sysfs:
                 sysfs["pci"] = bdf
                 info["sysfs"] = sysfs
@@ -146,6 +152,24 @@ def device_info(torch, dev):
     return info
 
 
+def spawn_ranks(args):
+    """--gpus N without a launcher: one child process per rank.  This parent has not initialised HIP (and never
+    will): it imports neither torch.cuda state nor the library, so nothing is re-executed from a GPU process."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        code = p.wait()
+        rc = rc or code
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,7 +177,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nffts", type=int, default=524288, help="FFTs per GPU per step (default: 4 GiB of N=1024 float2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the config 3 / config 4 measurements (N = 1 extras)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            raise SystemExit(spawn_ranks(args))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
 
     import torch  # first: the HIP runtime torch bundles must be the one the library binds to
 
@@ -192,139 +224,153 @@ def main():
 
     n, nffts = FFT_SIZE, args.nffts
     dev = torch.device("cuda", local_rank)
+    stats_dev = dev if backend == "nccl" else torch.device("cpu")
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     # U[0,1) re/im like the reference harness (SMFFT_CooleyTukey_C2C/FFT.c:141-142); float2 = 2 floats
     t_in = torch.rand((nffts, n, 2), dtype=torch.float32, device=dev, generator=gen)
-    # The batch lives in plain hipMalloc'ed buffers, as in the reference's wrapper (cudaMalloc,
-    # CT:850-853).  Measured (tools/alloc_probe.py): writing into a 4 GiB block of torch's caching
-    # allocator is 6-7 % slower than into a hipMalloc'ed one (1.53 vs 1.43 ms per launch).
     nbytes = nffts * n * 8
-    # Buffer placement (profiles/r01_chunk_map.txt): on MI355X the rate of a kernel that reads
-    # one buffer and writes another depends on which physical memory the two are (1.31 ... 1.55 ms for this batch).
-    # smfft_malloc_pair() -- the allocator the library's own L3 wrappers use -- allocates buffer-sized chunks over
-    # the free memory, times candidate (input, output) pairs with a stream copy and keeps the fastest.  For
-    # transparency the same launches are also timed on two plain allocations.
+    # Two buffer pairs, filled with the same batch:
+    #  * `pair`:  from the library's allocator smfft_malloc_pair (the buffers of `value` and `roofline`).  On MI355X the
+    #    rate of a kernel that reads one buffer and writes another depends on which physical memory the two are
+    #    (DESIGN.md section 5); the allocator looks for a good pair within a budget (a quarter of the free memory, 2 s).
+    #  * `plain`: two ordinary hipMalloc calls, as in the reference's wrapper (CT:850-853) -> `roofline_plain`.
     pa, pb = ctypes.c_void_p(), ctypes.c_void_p()
+    t_alloc = time.perf_counter()
     if sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(pa), ctypes.byref(pb)) != 0:
         raise SystemExit("smfft_malloc_pair failed")
-
-    class _Raw:
-        def __init__(self, ptr):
-            self.ptr = ptr
-    b_in, b_out = _Raw(pa.value), _Raw(pb.value)
-    sm.lib.smfft_memcpy_d2d(b_in.ptr, t_in.data_ptr(), nbytes)
+    alloc_s = time.perf_counter() - t_alloc
+    p_in, p_out = sm.DeviceBuffer(nbytes), sm.DeviceBuffer(nbytes)
+    sm.lib.smfft_memcpy_d2d(pa.value, t_in.data_ptr(), nbytes)
+    sm.lib.smfft_memcpy_d2d(p_in.ptr, t_in.data_ptr(), nbytes)
     xs = torch.view_as_complex(t_in[:4].contiguous()).to(torch.complex128)   # kept for the spot check
+    host_in = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        host_in = torch.view_as_complex(t_in).cpu().numpy()                  # the CPU baseline's input = the GPU's
     del t_in
     torch.cuda.empty_cache()
-
-    def _probe(i_ptr, o_ptr):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s0 = torch.cuda.current_stream(dev)
-        for _ in range(2):
-            sm.launch("ct", "external", i_ptr, o_ptr, n, nffts, stream=s0.cuda_stream)
-        e0.record(s0)
-        for _ in range(8):
-            sm.launch("ct", "external", i_ptr, o_ptr, n, nffts, stream=s0.cuda_stream)
-        e1.record(s0)
-        torch.cuda.synchronize(dev)
-        return e0.elapsed_time(e1) / 8
-
-    # placement telemetry: the same launches on two plain allocations (what two hipMalloc calls give a caller who does
-    # not use smfft_malloc_pair), made after the pair and released again
-    plain_ms = None
-    try:
-        p_in, p_out = sm.DeviceBuffer(nbytes), sm.DeviceBuffer(nbytes)
-        sm.lib.smfft_memset(p_in.ptr, 0, nbytes)
-        plain_ms = round(_probe(p_in.ptr, p_out.ptr), 4)
-        p_in.free()
-        p_out.free()
-    except MemoryError:
-        pass
-    placement = {"paired_ms": round(_probe(b_in.ptr, b_out.ptr), 4), "plain_hipmalloc_ms": plain_ms}
-
-    class _Ptr:                      # tiny adaptor so the rest of the script reads like tensor code
-        def __init__(self, buf):
-            self.buf = buf
-
-        def data_ptr(self):
-            return self.buf.ptr
-    d_in, d_out = _Ptr(b_in), _Ptr(b_out)
     stream = torch.cuda.current_stream(dev)
     sh = stream.cuda_stream
-
-    def step():
-        sm.launch("ct", "external", d_in.data_ptr(), d_out.data_ptr(), n, nffts, inverse=False, reorder=True, stream=sh)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    # device pre-warm (not part of the W warm-up steps of the contract): clocks / power state settle
-    prewarm_s = float(os.environ.get("SMFFT_BENCH_PREWARM_S", "1.0"))
-    t_pw = time.perf_counter()
-    while time.perf_counter() - t_pw < prewarm_s:
-        for _ in range(20):
+    def run_timed(i_ptr, o_ptr, contract):
+        """pre-warm, W warm-up steps, K timed steps; returns (wall seconds, average kernel ms from stream events).
+        contract = True: the barrier-bracketed region of the driver contract."""
+        def step():
+            sm.launch("ct", "external", i_ptr, o_ptr, n, nffts, inverse=False, reorder=True, stream=sh)
+        prewarm_s = float(os.environ.get("SMFFT_BENCH_PREWARM_S", "1.0"))   # clocks / power state settle (not part of W)
+        t_pw = time.perf_counter()
+        while time.perf_counter() - t_pw < prewarm_s:
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize(dev)
+        for _ in range(args.warmup):
             step()
         torch.cuda.synchronize(dev)
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    barrier()
-    torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    torch.cuda.synchronize(dev)
-    barrier()
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch duration on the launch stream
+        if contract:
+            barrier()
+            torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(args.steps):
+            step()
+        ev1.record(stream)
+        torch.cuda.synchronize(dev)
+        if contract:
+            barrier()
+            torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1) / args.steps
 
-    # sanity on the timed output (cheap, outside the timed region): spot-check 4 FFTs against torch fp64
-    y4 = torch.empty((4, n, 2), dtype=torch.float32, device=dev)
-    sm.lib.smfft_memcpy_d2d(y4.data_ptr(), b_out.ptr, 4 * n * 8)
-    ys = torch.view_as_complex(y4).to(torch.complex128)
-    err = (torch.linalg.vector_norm(ys - torch.fft.fft(xs, dim=-1)) / torch.linalg.vector_norm(torch.fft.fft(xs, dim=-1))).item()
+    # the plain pair first (so that the contract's timed region is the last thing before the reductions)
+    plain_wall, plain_kernel_ms = run_timed(p_in.ptr, p_out.ptr, False)
+    wall, kernel_ms = run_timed(pa.value, pb.value, True)
+
+    # sanity on the timed output (cheap, outside the timed region): spot-check 4 FFTs of BOTH outputs against torch fp64
+    want = torch.fft.fft(xs, dim=-1)
+    err = 0.0
+    for o_ptr in (pb.value, p_out.ptr):
+        y4 = torch.empty((4, n, 2), dtype=torch.float32, device=dev)
+        sm.lib.smfft_memcpy_d2d(y4.data_ptr(), o_ptr, 4 * n * 8)
+        ys = torch.view_as_complex(y4).to(torch.complex128)
+        err = max(err, (torch.linalg.vector_norm(ys - want) / torch.linalg.vector_norm(want)).item())
     assert err < 5e-7, f"timed output failed the spot check: relL2={err}"
 
     from smfft_amd.sharding import reduce_stats
-    wall_max, kernel_ms_max, _ = reduce_stats(dist, dev if backend == "nccl" else torch.device("cpu"), wall, kernel_ms)
+    wall_max, kernel_ms_max, ranks_seen = reduce_stats(dist, stats_dev, wall, kernel_ms, 1)
+    plain_wall_max, plain_kernel_ms_max, _ = reduce_stats(dist, stats_dev, plain_wall, plain_kernel_ms)
 
     # same-run copy ceiling: the kernel's own access shape without the FFT (outside the timed region)
-    for _ in range(3):
-        sm.lib.smfft_copy_launch(d_in.data_ptr(), d_out.data_ptr(), nffts * n, sh)
-    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    c0.record(stream)
-    for _ in range(20):
-        sm.lib.smfft_copy_launch(d_in.data_ptr(), d_out.data_ptr(), nffts * n, sh)
-    c1.record(stream)
-    torch.cuda.synchronize(dev)
-    copy_ms = c0.elapsed_time(c1) / 20
+    def copy_ms(i_ptr, o_ptr):
+        for _ in range(3):
+            sm.lib.smfft_copy_launch(i_ptr, o_ptr, nffts * n, sh)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record(stream)
+        for _ in range(20):
+            sm.lib.smfft_copy_launch(i_ptr, o_ptr, nffts * n, sh)
+        c1.record(stream)
+        torch.cuda.synchronize(dev)
+        return c0.elapsed_time(c1) / 20
+    pair_copy_ms, plain_copy_ms = copy_ms(pa.value, pb.value), copy_ms(p_in.ptr, p_out.ptr)
 
-    # in-LDS `multiple` path on the same buffers (config 3's N=1024 point), informational
+    def median_ms(fn, reps=11, warm=3):
+        for _ in range(warm):
+            fn(None)
+        ts = []
+        for _ in range(reps):
+            t = ctypes.c_double(0.0)
+            fn(ctypes.byref(t))
+            ts.append(t.value)
+        return sorted(ts)[len(ts) // 2]
+
+    # in-LDS `multiple` path on the same buffers (config 3's N=1024 point) on every rank: whole-job figure
     mult = {}
     for reo in (0, 1):
-        tm = ctypes.c_double(0.0)
-        for _ in range(3):
-            sm.lib.smfft_ct_multiple_benchmark(d_in.data_ptr(), d_out.data_ptr(), n, nffts, 0, reo, None)
-        reps = 10
-        for _ in range(reps):
-            sm.lib.smfft_ct_multiple_benchmark(d_in.data_ptr(), d_out.data_ptr(), n, nffts, 0, reo, ctypes.byref(tm))
-        mult["reorder" if reo else "noreorder"] = tm.value / reps
-    # whole-job figure for the multiple path too: every rank ran it on its own shard at the same time
-    nr_max, re_max, _ = reduce_stats(dist, dev if backend == "nccl" else torch.device("cpu"), mult["noreorder"], mult["reorder"])
-    mult = {k: {"ms": ms, "FFT/s": world * (nffts // 100) * 100 / (ms * 1e-3), "ms_is": "max over ranks", "n_gpus": world}
+        mult[reo] = median_ms(lambda t, reo=reo: sm.lib.smfft_ct_multiple_benchmark(pa.value, pb.value, n, nffts, 0, reo, t))
+    nr_max, re_max, _ = reduce_stats(dist, stats_dev, mult[0], mult[1])
+    mult = {k: {"ms": ms, "FFT/s": world * (nffts // 100) * 100 / (ms * 1e-3), "ms_is": "median of 11 launches, max over ranks", "n_gpus": world}
             for k, ms in (("noreorder", nr_max), ("reorder", re_max))}
+
+    # configs 3 and 4 of BASELINE.json (N = 1 only; FFT_*_benchmark calls = one event-timed launch each, median of 11)
+    configs = None
+    if world == 1 and not args.no_configs:
+        import math
+        total = 1 << 29                  # README batches: 4 GiB of float2
+        c3 = {}
+        for fn_n in (32, 64, 128, 256, 512, 1024, 2048, 4096):
+            bn = min(total // fn_n, nffts * n // fn_n)
+            done = (bn // 400 * 400) if fn_n == 32 else (bn // 200 * 200) if fn_n == 64 else (bn // 100 * 100)
+            row = {"nFFTs": bn}
+            for name, reo in (("noreorder", 0), ("reorder", 1)):
+                ms = median_ms(lambda t, reo=reo: sm.lib.smfft_ct_multiple_benchmark(pa.value, pb.value, fn_n, bn, 0, reo, t))
+                tf = done * 5 * fn_n * math.log2(fn_n) / (ms * 1e-3) / 1e12
+                row[name] = {"ms": ms, "FFT/s": done / (ms * 1e-3), "TFLOP/s": tf, "frac_fp32_peak": tf / FP32_PEAK_TFLOPS}
+            c3[str(fn_n)] = row
+        # config 4: real N = 2048, 262144 FFTs: 2 GiB of reals <-> 2 GiB packed spectrum, first halves of the pair
+        rn, rnffts = 2048, min(262144, nffts * n * 2 // 2048 // 2)
+        rbytes = rn * rnffts * 4
+        c4 = {"nFFTs": rnffts, "real_N": rn, "algorithmic_bytes_per_launch": 2 * rbytes}
+        for name, inv, src, dst in (("r2c", 0, pa.value, pb.value), ("c2r", 1, pb.value, pa.value)):
+            ms = median_ms(lambda t, inv=inv, src=src, dst=dst: sm.lib.smfft_rc_external_benchmark(src, dst, rn, rnffts, inv, t))
+            gbps = 2 * rbytes / (ms * 1e-3) / 1e9
+            c4[name] = {"ms": ms, "TB/s": gbps / 1e3, "frac": gbps / HBM_PEAK_GBPS}
+        # the C2R above overwrote the pair's input with (N/2) * x; restore nothing: the batch is not used again
+        configs = {"timing": "median of 11 event-timed launches after 3 warm-ups, buffers of `roofline`",
+                   "config3_multiple": c3, "config4_r2c_c2r_external": c4}
 
     if rank == 0:
         ms_per_step = wall_max / args.steps * 1e3
         total_ffts = nffts * world
         alg_bytes = 2 * n * nffts * 8
-        achieved = alg_bytes / (kernel_ms_max * 1e-3) / 1e9
+
+        def roof(kms, cms):
+            achieved = alg_bytes / (kms * 1e-3) / 1e9
+            return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                    "traffic": measured_traffic(), "kernel": "SMFFT_DIT_external<FFT_1024_forward>", "kernel_ms": kms,
+                    "algorithmic_bytes_per_launch": alg_bytes, "copy_ceiling": alg_bytes / (cms * 1e-3) / 1e9, "frac_of_copy": cms / kms}
         out = {
             "metric": "batched_ffts_per_sec_N1024_c2c_fwd_4GiB_external",
             "value": total_ffts / (wall_max / args.steps),
@@ -339,24 +385,26 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"config 2: N={n} C2C forward, reorder, {nffts} FFTs per GPU ({alg_bytes // 2 >> 20} MiB in + out), external path",
-                       "fft_size": n, "nffts_per_gpu": nffts, "parallelism": f"batch-split x{world}"},
+                       "fft_size": n, "nffts_per_gpu": nffts, "parallelism": f"batch-split x{world}",
+                       "buffers": "smfft_malloc_pair (budget-bounded placement search); plain hipMalloc figures in roofline_plain / value_plain"},
             "hbm_GBps_per_gpu": alg_bytes / (ms_per_step * 1e-3) / 1e9,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": measured_traffic(), "kernel": "SMFFT_DIT_external<FFT_1024_forward>", "kernel_ms": kernel_ms_max,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "copy_ceiling": alg_bytes / (copy_ms * 1e-3) / 1e9, "frac_of_copy": copy_ms / kernel_ms_max},
+            "roofline": roof(kernel_ms_max, pair_copy_ms),
+            "roofline_plain": roof(plain_kernel_ms_max, plain_copy_ms),
+            "value_plain": total_ffts / (plain_wall_max / args.steps),
+            "pair_alloc_s": alloc_s,
             "multiple_path": mult,
+            "configs": configs,
             "comm_backend": (backend if world > 1 else None),
-            "buffer_placement_probe": placement,
+            "ranks_seen": ranks_seen,
             "spot_check_relL2": err,
             "device": device_info(torch, dev),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
-            out["cpu_baseline"] = cpu_baseline(n, 131072, threads)
+        if host_in is not None:
+            out["cpu_baseline"] = cpu_baseline(host_in, os.cpu_count() or 1)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+    sm.lib.smfft_free_pair(pa.value)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -65,19 +65,12 @@ int smfft_rc_multiple_benchmark(const float* d_input, float* d_output, int FFT_s
 
 /* ---- launch-only forms (no events, no synchronisation) on a caller-provided hipStream_t --------
  * family: 0 = CT, 1 = ST, 2 = RC.  path: 0 = external, 1 = multiple.  For family 2, FFT_size is
- * the REAL length.  Used by bench.py / graph capture; same kernels as the *_benchmark calls.
+ * the REAL length.  family 1 (the Stockham program, + sign only upstream, ST:76): inverse != 0 is the
+ * program's transform, inverse == 0 the forward extension; reorder is ignored (natural order).  Used by
+ * bench.py and smfft_host_transform; same kernels as the *_benchmark calls (capturable into a hipGraph by the caller).
  * Returns 0, a hipError_t, or -1 for an unsupported (family, FFT_size). */
 int smfft_launch(int family, int path, const void* d_input, void* d_output, int FFT_size, int nFFTs,
                  int inverse, int reorder, void* hip_stream);
-
-/* hipGraph form for launch-bound use (many small batches): captures `repeats` back-to-back launches
- * of one transform into a graph -- with pingpong != 0 the two buffers swap roles every launch (d_b is
- * the output of launch 0 and the input of launch 1, ...) -- and replays it with one host call per
- * smfft_graph_launch.  Arguments as for smfft_launch.  Returns NULL on failure. */
-void* smfft_graph_create(int family, int path, void* d_a, void* d_b, int FFT_size, int nFFTs, int inverse, int reorder,
-                         int repeats, int pingpong);
-int smfft_graph_launch(void* graph, void* hip_stream);
-int smfft_graph_destroy(void* graph);
 
 /* Calibration: streams n_float2 elements (a multiple of 4096) from d_input to d_output with exactly
  * the external kernels' global access shape and grid, no FFT: the same-run copy ceiling. */

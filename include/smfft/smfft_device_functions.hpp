@@ -106,8 +106,14 @@ __device__ __forceinline__ bool reference_shape_init(Engine<N, DIR, REORDER, PAD
 
 namespace tiled {
 
+// the tiled contract is 256 threads per workgroup: anything else would index other FFTs' regions
+__device__ __forceinline__ void require_tiled_block() {
+    if (blockDim.x != 256) __builtin_trap();
+}
+
 template <class const_params>
 __device__ void do_SMFFT_CT_DIT(float2* s_input) {
+    require_tiled_block();
     Engine<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder> eng;
     eng.init(threadIdx.x);
     fft_lds_inplace(s_input, eng);
@@ -115,18 +121,21 @@ __device__ void do_SMFFT_CT_DIT(float2* s_input) {
 // Stockham C2C program: un-normalised INVERSE (+i) transform, natural order (ST:76, :429).
 template <class const_params>
 __device__ void do_FFT_Stockham_mk6(float2* s_input) {
+    require_tiled_block();
     Engine<const_params::fft_length, 1, 1> eng;
     eng.init(threadIdx.x);
     fft_lds_inplace(s_input, eng);
 }
 template <class const_params, class const_direction>
 __device__ void do_FFT_Stockham_C2C(float2* s_input) {
+    require_tiled_block();
     Engine<const_params::fft_length, const_direction::fft_direction, 1> eng;
     eng.init(threadIdx.x);
     fft_lds_inplace(s_input, eng);
 }
 template <class const_params, class const_direction>
 __device__ void do_FFT_Stockham_R2C_C2R(float2* s_input) {
+    require_tiled_block();
     Engine<const_params::fft_length, const_direction::fft_direction, 1> eng;
     eng.init(threadIdx.x);
     r2c_c2r_lds_inplace<const_params::fft_length, const_direction::fft_direction, true>(s_input, eng);

@@ -39,9 +39,6 @@ _SIGS = {
     "smfft_rc_external_benchmark": (_i, [_vp, _vp, _i, _i, _i, _dp]),
     "smfft_rc_multiple_benchmark": (_i, [_vp, _vp, _i, _i, _dp]),
     "smfft_launch": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "smfft_graph_create": (_vp, [_i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i]),
-    "smfft_graph_launch": (_i, [_vp, _vp]),
-    "smfft_graph_destroy": (_i, [_vp]),
     "smfft_copy_launch": (_i, [_vp, _vp, ctypes.c_longlong, _vp]),
     "smfft_gpu_ct": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _dp, _dp]),
     "smfft_gpu_st": (_i, [_vp, _vp, _i, _i, _i, _dp, _dp]),
@@ -159,8 +156,11 @@ def FFT_multiple_benchmark(d_input, d_output, FFT_size, nFFTs, inverse=False, re
 _FAMILY = {"ct": 0, "st": 1, "rc": 2}
 
 
-def launch(family, path, d_input, d_output, FFT_size, nFFTs, inverse=False, reorder=True, stream=0):
-    """Launch-only form (no events, no sync) on a hipStream_t handle (int; 0 = null stream)."""
+def launch(family, path, d_input, d_output, FFT_size, nFFTs, inverse=None, reorder=True, stream=0):
+    """Launch-only form (no events, no sync) on a hipStream_t handle (int; 0 = null stream).
+    inverse=None: the program's own direction (Stockham: inverse, ST:76; otherwise forward)."""
+    if inverse is None:
+        inverse = (family == "st")
     rc = lib.smfft_launch(_FAMILY[family], 0 if path == "external" else 1, d_input, d_output, FFT_size, nFFTs, int(inverse), int(reorder), stream)
     if rc != 0:
         raise RuntimeError(f"smfft_launch({family},{path},N={FFT_size}) -> {rc}")
@@ -233,10 +233,14 @@ def pinned_empty(shape, dtype):
     return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
-def host_transform(x, out=None, family="ct", inverse=False, reorder=True, slab_ffts=0, lanes=0):
+def host_transform(x, out=None, family="ct", inverse=None, reorder=True, slab_ffts=0, lanes=0):
     """x: (nFFTs, N) host array (complex64; float32 for R2C) -> (result, elapsed_ms) streamed through the GPU in
-    slabs with H2D / FFT / D2H overlapped; x and out may be pageable or pinned (pinned_empty)."""
+    slabs with H2D / FFT / D2H overlapped; x and out may be pageable or pinned (pinned_empty).
+    inverse=None: the program's own direction -- the Stockham C2C program is the + sign (inverse) transform
+    (ST:76), everything else defaults to forward; family="st" with inverse=False is the forward extension."""
     fam = _FAMILY[family]
+    if inverse is None:
+        inverse = (family == "st")
     nffts, width = x.shape
     if fam == 2:
         n = width if not inverse else 2 * width          # R2C: reals in; C2R: N/2 packed complex in

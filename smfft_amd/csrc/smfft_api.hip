@@ -327,7 +327,12 @@ int smfft_launch(int family, int path, const void* d_input, void* d_output, int 
         int count = path ? ct_multiple_slots(FFT_size, nFFTs) : nFFTs;
         return dispatch_ct(in, out, FFT_size, count, inverse != 0, reorder != 0, path, st);
     }
-    if (family == 1) return dispatch_st(in, out, FFT_size, path ? nFFTs / SMFFT_NREUSES : nFFTs, path, st);
+    if (family == 1) {
+        // the Stockham program is the + sign transform (ST:76); inverse = 0 asks for the forward extension, which is
+        // the same autosort engine with the other sign = the natural-order CT variant (external and multiple alike)
+        if (!inverse) return dispatch_ct(in, out, FFT_size, path ? nFFTs / SMFFT_NREUSES : nFFTs, false, true, path, st);
+        return dispatch_st(in, out, FFT_size, path ? nFFTs / SMFFT_NREUSES : nFFTs, path, st);
+    }
     if (family == 2) return dispatch_rc(in, out, FFT_size, path ? nFFTs / SMFFT_NREUSES : nFFTs, inverse != 0, path, st);
     return -1;
 }
@@ -335,51 +340,6 @@ int smfft_launch(int family, int path, const void* d_input, void* d_output, int 
 int smfft_copy_launch(const void* d_input, void* d_output, long long n_float2, void* hip_stream) {
     read_env();
     return smfft::launch_stream_copy((const float2*)d_input, (float2*)d_output, (long)n_float2, g_grid_cap, (hipStream_t)hip_stream);
-}
-
-// ---- hipGraph form of a launch-bound loop -----------------------------------------------------------
-// Small batches are launch bound (a 4096-FFT N=1024 batch runs ~12 us, an eager launch costs 3-5 us of
-// host time plus a ~1.5 us kernel boundary).  smfft_graph_create captures `repeats` back-to-back
-// launches of one transform (ping-ponging the two buffers when `pingpong` is set: out becomes the
-// next launch's in) into one hipGraph; smfft_graph_launch replays it on a stream with ONE host call.
-struct GraphRec { hipGraph_t graph; hipGraphExec_t exec; };
-
-void* smfft_graph_create(int family, int path, void* d_a, void* d_b, int FFT_size, int nFFTs, int inverse, int reorder, int repeats, int pingpong) {
-    read_env();
-    if (repeats < 1) return nullptr;
-    hipStream_t cap;
-    if (hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    GraphRec* rec = new GraphRec{nullptr, nullptr};
-    bool ok = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) == hipSuccess;
-    for (int r = 0; ok && r < repeats; ++r) {
-        void* in = (pingpong && (r & 1)) ? d_b : d_a;
-        void* out = (pingpong && (r & 1)) ? d_a : d_b;
-        ok = smfft_launch(family, path, in, out, FFT_size, nFFTs, inverse, reorder, (void*)cap) == 0;
-    }
-    if (hipStreamEndCapture(cap, &rec->graph) != hipSuccess) ok = false;
-    if (ok && hipGraphInstantiate(&rec->exec, rec->graph, nullptr, nullptr, 0) != hipSuccess) ok = false;
-    (void)hipStreamDestroy(cap);
-    if (!ok) {
-        if (rec->graph) (void)hipGraphDestroy(rec->graph);
-        delete rec;
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    return rec;
-}
-
-int smfft_graph_launch(void* graph, void* hip_stream) {
-    if (!graph) return -1;
-    return (int)hipGraphLaunch(((GraphRec*)graph)->exec, (hipStream_t)hip_stream);
-}
-
-int smfft_graph_destroy(void* graph) {
-    if (!graph) return 0;
-    GraphRec* rec = (GraphRec*)graph;
-    int rc = (int)hipGraphExecDestroy(rec->exec);
-    rc |= (int)hipGraphDestroy(rec->graph);
-    delete rec;
-    return rc;
 }
 
 // ---- L3 wrappers ---------------------------------------------------------------------------------

@@ -574,43 +574,6 @@ def test_config3_full_batch_multiple_path(sm, oracle_lib, n):
     print(f"config3 N={n}: {ms:.3f} ms, {done / ms * 1e3:.3e} FFT/s (no-reorder, 100 applications)")
 
 
-def test_graph_replay_matches_eager(sm, oracle_lib):
-    """smfft_graph_create / smfft_graph_launch: ping-ponged launches captured once into a hipGraph and
-    replayed with one host call.  Four forward transforms (F^4 = N^2 I) give an exact expectation;
-    the timing of a launch-bound case (64 launches of a 256-FFT batch per graph) is informational."""
-    import time
-    n, nffts = 1024, 4096
-    rng = np.random.default_rng(11)
-    x = ((rng.random((nffts, n), dtype=np.float32) - 0.5) + 1j * (rng.random((nffts, n), dtype=np.float32) - 0.5)).astype(np.complex64)
-    a, b = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
-    g = sm.lib.smfft_graph_create(0, 0, a.ptr, b.ptr, n, nffts, 0, 1, 4, 1)
-    assert g
-    assert sm.lib.smfft_graph_launch(g, None) == 0
-    sm.lib.smfft_synchronize()
-    got = a.to_host(np.complex64, x.shape)          # 4 ping-pong launches end in buffer a
-    l2, mx = ref.fft_errors(got / np.float32(n) ** 2, x.astype(np.complex128))
-    assert l2 < 1e-6 and mx < 2e-6, (l2, mx)
-    assert sm.lib.smfft_graph_destroy(g) == 0
-    small = 256
-    g = sm.lib.smfft_graph_create(0, 0, a.ptr, b.ptr, n, small, 0, 1, 64, 1)
-    assert g
-    sm.lib.smfft_graph_launch(g, None)
-    sm.lib.smfft_synchronize()
-    t0 = time.perf_counter()
-    for _ in range(20):
-        sm.lib.smfft_graph_launch(g, None)
-    sm.lib.smfft_synchronize()
-    t_graph = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    for r in range(20 * 64):
-        i, o = (a.ptr, b.ptr) if r % 2 == 0 else (b.ptr, a.ptr)
-        sm.launch("ct", "external", i, o, n, small, False, True)
-    sm.lib.smfft_synchronize()
-    t_eager = time.perf_counter() - t0
-    print(f"1280 launches of a {small}-FFT batch: eager {t_eager * 1e3:.2f} ms, 20 replays of a 64-launch graph {t_graph * 1e3:.2f} ms")
-    assert sm.lib.smfft_graph_destroy(g) == 0
-
-
 # ------------------------------------------------- Stockham forward extension (SURVEY 8(f) item 3)
 @pytest.mark.parametrize("n", ST_SIZES)
 def test_stockham_forward_extension_golden(sm, golden, n):
@@ -641,8 +604,10 @@ def test_host_transform_matches_device_path_and_oracle(sm, oracle_lib, n, inv, r
 def test_host_transform_families_and_defaults(sm, golden):
     """Stockham and R2C/C2R through the host pipeline with the default slab / lane count; empty batch; bad length."""
     x = golden["c2c_in_u01_512"]
-    got, _ = sm.host_transform(x, family="st")
+    got, _ = sm.host_transform(x, family="st")                     # the Stockham program's own direction: + sign (ST:76)
     ref.assert_close_fp32(got, golden["ct_out_u01_512_inv1_reo1"], "host ST")
+    got, _ = sm.host_transform(x, family="st", inverse=False)      # the forward extension is honoured, not ignored
+    ref.assert_close_fp32(got, golden["ct_out_u01_512_inv0_reo1"], "host ST forward")
     got, _ = sm.host_transform(golden["r2c_in_2048"], family="rc", inverse=False)
     ref.assert_close_fp32(got, golden["r2c_out_2048"], "host R2C")
     got, _ = sm.host_transform(golden["c2r_in_2048"], family="rc", inverse=True)
@@ -698,3 +663,25 @@ def test_randomised_geometry_sweep(sm, oracle_lib):
                                       f"case {case}: CT N={n} nFFTs={nffts} inv={inv} reo={reo} cap={cap}")
     finally:
         sm.lib.smfft_set_grid_cap(old)
+
+
+# ----------------------------------------------------------------------------- bench.py, N > 1 path
+def test_bench_two_ranks_on_one_device(sm):
+    """`python bench.py --gpus 2` with no launcher starts two ranks itself; pinned to the one device of this box
+    (SMFFT_BENCH_DEVICE) with the timings reduced over gloo, both ranks allocate their pair concurrently (each within
+    its budget: neither starves the other), and rank 0 prints n_gpus = 2 with both ranks seen."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SMFFT_BENCH_DEVICE="0", SMFFT_BENCH_BACKEND="gloo", SMFFT_BENCH_PREWARM_S="0.2")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--nffts", "262144",
+                        "--no-cpu-baseline", "--no-configs"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["ranks_seen"] == 2 and doc["comm_backend"] == "gloo"
+    assert doc["value"] > 0 and doc["roofline"]["frac"] > 0 and doc["roofline_plain"]["frac"] > 0

@@ -53,3 +53,23 @@ def test_two_rank_batch_split(tmp_path):
     rng = np.random.default_rng(99)
     x = rng.standard_normal((nffts, n)) + 1j * rng.standard_normal((nffts, n))
     np.testing.assert_allclose(got, np.fft.fft(x, axis=-1), atol=1e-9)
+
+
+def _bench(args, env_extra=None, timeout=600):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_flag_never_silently_runs_one_rank():
+    """`bench.py --gpus N` either runs N ranks or fails: under a launcher with a different WORLD_SIZE it exits non-zero
+    before touching anything; without a launcher it spawns the N ranks itself from a parent that never initialises the
+    GPU (here, without a GPU, every child refuses to run -- twice for --gpus 2 -- and the parent reports the failure)."""
+    p = _bench(["--gpus", "8"], {"WORLD_SIZE": "2", "RANK": "0"})
+    assert p.returncode != 0 and "--gpus 8" in p.stderr and "WORLD_SIZE=2" in p.stderr and p.stdout.strip() == ""
+    if torch.cuda.is_available():
+        return   # the spawn path itself is exercised on the GPU box (tests/test_gpu_parity.py::test_bench_two_ranks_on_one_device)
+    p = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert p.returncode != 0 and p.stdout.strip() == ""
+    assert p.stderr.count("bench.py needs a GPU") == 2
