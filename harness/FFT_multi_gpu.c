@@ -36,55 +36,66 @@ typedef struct {
 	int status;
 } worker_t;
 
+// A worker that fails before the collectives must not leave the others waiting inside them: every worker reports its
+// local status, all meet at a host barrier, and the RCCL calls are made only if NOBODY failed.
+static pthread_barrier_t g_rendezvous;
+static int g_failures = 0;
+
 static void *worker(void *arg) {
 	worker_t *w = (worker_t *) arg;
 	w->status = 1;
-	if (hipSetDevice(w->gpu) != hipSuccess) return NULL;
 	const size_t count = (size_t) w->FFT_size*w->nFFTs, bytes = count*sizeof(float2);
-	float2 *h_in = (float2 *) malloc(bytes), *h_out = (float2 *) malloc(bytes);
-	float2 *d_in = NULL, *d_out = NULL;
+	float2 *h_in = NULL, *h_out = NULL, *d_in = NULL, *d_out = NULL, *d_all = NULL, *d_back = NULL;
 	float *d_stats = NULL;
-	hipStream_t stream;
-	if (!h_in || !h_out || smfft_malloc_pair(bytes, (void **) &d_in, (void **) &d_out) != 0
-	    || hipMalloc((void **) &d_stats, 4*sizeof(float)) != hipSuccess || hipStreamCreate(&stream) != hipSuccess) {
-		printf("GPU %d: allocation failed\n", w->gpu);
-		return NULL;
-	}
-	// per-slab reproducible data, U[0,1) like FFT.c:141-142: element i of slab g is counter g*2*count + i of the
-	// harness's counter-based generator (seed fixed in main), so the batch does not depend on the number of GPUs
-	for (size_t i = 0; i < 2*count; i++) ((float *) h_in)[i] = harness_uniform((unsigned long long) w->gpu*2*count + i);
-	if (hipMemcpy(d_in, h_in, bytes, hipMemcpyHostToDevice) != hipSuccess) return NULL;
-	FFT_init();
-	double total = 0;
-	FFT_external_benchmark(d_in, d_out, w->FFT_size, w->nFFTs, w->inverse, w->reorder, &total);   // warm-up
-	total = 0;
-	for (int r = 0; r < w->nRuns; r++) FFT_external_benchmark(d_in, d_out, w->FFT_size, w->nFFTs, w->inverse, w->reorder, &total);
-	w->kernel_ms = total/w->nRuns;
-	if (hipMemcpy(h_out, d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess) return NULL;
-
-	// slab self-check without a second library: Parseval, sum|X|^2 = N * sum|x|^2 per FFT (first 64 FFTs)
+	hipStream_t stream = NULL;
+	hipEvent_t e0 = NULL, e1 = NULL, e2 = NULL;
 	double errors = 0;
-	const int nCheck = w->nFFTs < 64 ? w->nFFTs : 64;
-	for (int f = 0; f < nCheck; f++) {
-		double ein = 0, eout = 0;
-		for (int i = 0; i < w->FFT_size; i++) {
-			float2 a = h_in[(size_t) f*w->FFT_size + i], b = h_out[(size_t) f*w->FFT_size + i];
-			ein += (double) a.x*a.x + (double) a.y*a.y;
-			eout += (double) b.x*b.x + (double) b.y*b.y;
-		}
-		if (fabs(eout/(w->FFT_size*ein) - 1.0) > 1e-5) { printf("GPU %d: FFT %d fails the Parseval check\n", w->gpu, f); errors += 1; }
+	bool ok = hipSetDevice(w->gpu) == hipSuccess;
+	if (ok) {
+		h_in = (float2 *) malloc(bytes);
+		h_out = (float2 *) malloc(bytes);
+		ok = h_in && h_out && smfft_malloc_pair(bytes, (void **) &d_in, (void **) &d_out) == 0
+		     && hipMalloc((void **) &d_stats, 4*sizeof(float)) == hipSuccess && hipStreamCreate(&stream) == hipSuccess;
+		if (ok && w->exchange)
+			ok = hipMalloc((void **) &d_all, bytes*w->nGPUs) == hipSuccess && hipMalloc((void **) &d_back, bytes) == hipSuccess
+			     && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && hipEventCreate(&e2) == hipSuccess;
+		if (!ok) printf("GPU %d: allocation failed\n", w->gpu);
 	}
+	if (ok) {
+		// per-slab reproducible data, U[0,1) like FFT.c:141-142: element i of slab g is counter g*2*count + i of the
+		// harness's counter-based generator (seed fixed in main), so the batch does not depend on the number of GPUs
+		for (size_t i = 0; i < 2*count; i++) ((float *) h_in)[i] = harness_uniform((unsigned long long) w->gpu*2*count + i);
+		ok = hipMemcpy(d_in, h_in, bytes, hipMemcpyHostToDevice) == hipSuccess;
+	}
+	if (ok) {
+		FFT_init();
+		double total = 0;
+		FFT_external_benchmark(d_in, d_out, w->FFT_size, w->nFFTs, w->inverse, w->reorder, &total);   // warm-up
+		total = 0;
+		for (int r = 0; r < w->nRuns; r++) FFT_external_benchmark(d_in, d_out, w->FFT_size, w->nFFTs, w->inverse, w->reorder, &total);
+		w->kernel_ms = total/w->nRuns;
+		ok = hipMemcpy(h_out, d_out, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+	}
+	if (ok) {
+		// slab self-check without a second library: Parseval, sum|X|^2 = N * sum|x|^2 per FFT (first 64 FFTs)
+		const int nCheck = w->nFFTs < 64 ? w->nFFTs : 64;
+		for (int f = 0; f < nCheck; f++) {
+			double ein = 0, eout = 0;
+			for (int i = 0; i < w->FFT_size; i++) {
+				float2 a = h_in[(size_t) f*w->FFT_size + i], b = h_out[(size_t) f*w->FFT_size + i];
+				ein += (double) a.x*a.x + (double) a.y*a.y;
+				eout += (double) b.x*b.x + (double) b.y*b.y;
+			}
+			if (fabs(eout/(w->FFT_size*ein) - 1.0) > 1e-5) { printf("GPU %d: FFT %d fails the Parseval check\n", w->gpu, f); errors += 1; }
+		}
+	}
+	if (!ok) __sync_fetch_and_add(&g_failures, 1);
+	pthread_barrier_wait(&g_rendezvous);
+	const bool everybody_ok = __sync_fetch_and_add(&g_failures, 0) == 0;
 
 	// optional payload movement over xGMI, never inside the timed transform
 	float gather_ms = 0, scatter_ms = 0;
-	if (w->exchange) {
-		float2 *d_all = NULL, *d_back = NULL;
-		hipEvent_t e0, e1, e2;
-		if (hipMalloc((void **) &d_all, bytes*w->nGPUs) != hipSuccess || hipMalloc((void **) &d_back, bytes) != hipSuccess
-		    || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) {
-			printf("GPU %d: exchange buffers: allocation failed\n", w->gpu);
-			return NULL;
-		}
+	if (everybody_ok && w->exchange) {
 		(void) hipMemsetAsync(d_back, 0, bytes, stream);
 		(void) hipEventRecord(e0, stream);
 		ncclAllGather(d_out, d_all, 2*count, ncclFloat, w->comm, stream);
@@ -110,32 +121,40 @@ static void *worker(void *arg) {
 		for (int k = 0; k < 2; k++) {
 			const size_t offs[2] = {0, bytes - probe};
 			for (int o = 0; o < 2; o++) {
-				if (hipMemcpy(t, srcs[k] + offs[o], probe, hipMemcpyDeviceToHost) != hipSuccess || memcmp(t, (const char *) h_out + offs[o], probe) != 0) {
+				if (!t || hipMemcpy(t, srcs[k] + offs[o], probe, hipMemcpyDeviceToHost) != hipSuccess || memcmp(t, (const char *) h_out + offs[o], probe) != 0) {
 					printf("GPU %d: %s differs from the GPU's own output at byte offset %zu\n", w->gpu, k == 0 ? "all-gather segment" : "scattered slab", offs[o]);
 					errors += 1;
 				}
 			}
 		}
 		free(t);
-		(void) hipFree(d_all); (void) hipFree(d_back);
-		(void) hipEventDestroy(e0); (void) hipEventDestroy(e1); (void) hipEventDestroy(e2);
 	}
 
 	// the only communication of the timed path: job-level statistics over RCCL
-	float h_stats[4] = {(float) w->kernel_ms, gather_ms, scatter_ms, (float) errors};
-	(void) hipMemcpy(d_stats, h_stats, sizeof(h_stats), hipMemcpyHostToDevice);
-	ncclAllReduce(d_stats, d_stats, 3, ncclFloat, ncclMax, w->comm, stream);
-	ncclAllReduce(d_stats + 3, d_stats + 3, 1, ncclFloat, ncclSum, w->comm, stream);
-	(void) hipStreamSynchronize(stream);
-	(void) hipMemcpy(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost);
-	w->job_ms = h_stats[0];
-	w->gather_ms = h_stats[1];
-	w->scatter_ms = h_stats[2];
-	w->job_errors = h_stats[3];
+	if (everybody_ok) {
+		float h_stats[4] = {(float) w->kernel_ms, gather_ms, scatter_ms, (float) errors};
+		(void) hipMemcpy(d_stats, h_stats, sizeof(h_stats), hipMemcpyHostToDevice);
+		ncclAllReduce(d_stats, d_stats, 3, ncclFloat, ncclMax, w->comm, stream);
+		ncclAllReduce(d_stats + 3, d_stats + 3, 1, ncclFloat, ncclSum, w->comm, stream);
+		(void) hipStreamSynchronize(stream);
+		(void) hipMemcpy(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost);
+		w->job_ms = h_stats[0];
+		w->gather_ms = h_stats[1];
+		w->scatter_ms = h_stats[2];
+		w->job_errors = h_stats[3];
+	}
 
-	(void) smfft_free_pair(d_in); (void) hipFree(d_stats); (void) hipStreamDestroy(stream);
+	// every path releases what it got
+	if (d_in) (void) smfft_free_pair(d_in);
+	if (d_stats) (void) hipFree(d_stats);
+	if (d_all) (void) hipFree(d_all);
+	if (d_back) (void) hipFree(d_back);
+	if (e0) (void) hipEventDestroy(e0);
+	if (e1) (void) hipEventDestroy(e1);
+	if (e2) (void) hipEventDestroy(e2);
+	if (stream) (void) hipStreamDestroy(stream);
 	free(h_in); free(h_out);
-	w->status = 0;
+	w->status = ok ? 0 : 1;
 	return NULL;
 }
 
@@ -161,6 +180,7 @@ int main(int argc, char *argv[]) {
 
 	worker_t *w = (worker_t *) calloc(nGPUs, sizeof(worker_t));
 	pthread_t *th = (pthread_t *) malloc(nGPUs*sizeof(pthread_t));
+	pthread_barrier_init(&g_rendezvous, NULL, nGPUs);
 	for (int g = 0; g < nGPUs; g++) {
 		w[g].gpu = g; w[g].nGPUs = nGPUs; w[g].FFT_size = FFT_size; w[g].nFFTs = nFFTs; w[g].nRuns = nRuns;
 		w[g].inverse = inverse; w[g].reorder = reorder; w[g].exchange = exchange; w[g].comm = comms[g];
