@@ -321,7 +321,10 @@ struct HermitianRegisters {
         partner_addr = 4 * ((lane - u) + ((T - u) % T));
         wu = twiddle<DIR>(u * (4096 / (2 * L)));
     }
-    __device__ __forceinline__ void apply(float2 (&r)[16]) const {
+    // out[i] = H1 + W^i * H2 with A = x[i], B = x[L - i]  (i = u + T*q):
+    //   H1 = ((A.x + B.x)/2, (A.y - B.y)/2),  H2 = (ohx * (A.y + B.y), ohy * (A.x - B.x))
+    template <int Q>
+    __device__ __forceinline__ float2 combine(float2 A, float2 B, float2 wu) const {
         constexpr float c32[16] = {1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f, 0.55557023301960229f,
                                    0.38268343236508984f, 0.19509032201612833f, 0.f, -0.19509032201612819f, -0.38268343236508973f, -0.55557023301960196f,
                                    -0.70710678118654746f, -0.83146961230254535f, -0.92387953251128674f, -0.98078528040323043f};
@@ -329,31 +332,60 @@ struct HermitianRegisters {
                                    0.92387953251128674f, 0.98078528040323043f, 1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254546f,
                                    0.70710678118654757f, 0.55557023301960218f, 0.38268343236508989f, 0.19509032201612861f};
         constexpr float ohx = DIR ? -0.5f : 0.5f, ohy = DIR ? 0.5f : -0.5f;
-        float2 B[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float2 src = r[15 - q];
-            const float bx = __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(src.x)));
-            const float by = __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(src.y)));
-            const float2 own = r[(16 - q) & 15];
-            B[q] = first ? own : make_float2(bx, by);
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float2 A = r[q];
-            const float2 H1 = make_float2(0.5f * (A.x + B[q].x), 0.5f * (A.y - B[q].y));
-            const float2 H2 = make_float2(ohx * (A.y + B[q].y), ohy * (A.x - B[q].x));
-            const float2 W = (q == 0) ? wu : cmul(wu, make_float2(c32[q], DIR ? s32[q] : -s32[q]));
-            const float2 WH = cmul(H2, W);
-            float2 out = make_float2(H1.x + WH.x, H1.y + WH.y);
-            if (q == 0) {   // element 0 of thread 0 packs DC and Nyquist (RC:280-286, 332-339)
-                const float2 packed = DIR ? make_float2(0.5f * (A.x + A.y), 0.5f * (A.x - A.y)) : make_float2(A.x + A.y, A.x - A.y);
-                out = first ? packed : out;
+        const float2 H1 = make_float2(0.5f * (A.x + B.x), 0.5f * (A.y - B.y));
+        const float2 H2 = make_float2(ohx * (A.y + B.y), ohy * (A.x - B.x));
+        const float2 W = (Q == 0) ? wu : cmul(wu, make_float2(c32[Q], DIR ? s32[Q] : -s32[Q]));
+        const float2 WH = cmul(H2, W);
+        return make_float2(H1.x + WH.x, H1.y + WH.y);
+    }
+    __device__ __forceinline__ float2 from_partner(float2 v) const {
+        return make_float2(__int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(v.x))),
+                           __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(v.y))));
+    }
+    // In place, two registers (q, 15 - q) at a time, so that only two fetched partner values are alive at once (the
+    // all-at-once form kept sixteen: 139-146 VGPRs, 3 waves per SIMD).  Thread u > 0 pairs register q with register
+    // 15 - q of thread T - u: both fetches of a step are made before either register is overwritten, and all lanes
+    // of a wave make them together.  Thread 0 pairs register q with its OWN register 16 - q: for q that is the
+    // register 15 - (q - 1) the previous step overwrote (its original is carried over in `carried`), for 15 - q it is
+    // register q + 1, still untouched.
+    template <int Q>
+    __device__ __forceinline__ void apply_pair(float2 (&r)[16], float2& carried) const {
+        if constexpr (Q < 8) {
+            const float2 a_lo = r[Q], a_hi = r[15 - Q];
+            const float2 p_lo = from_partner(a_hi);            // partner's register 15 - Q  -> B of register Q
+            const float2 p_hi = from_partner(a_lo);            // partner's register Q       -> B of register 15 - Q
+            const float2 b_lo = first ? carried : p_lo;        // thread 0: original register 16 - Q
+            const float2 b_hi = first ? r[(Q + 1) & 15] : p_hi;   // thread 0: register 16 - (15 - Q) = Q + 1 (Q = 7: register 8 itself)
+            carried = a_hi;
+            // W^i = W^u * W_32^q is the same for every tile, so the compiler would hoist all fifteen products out of the
+            // grid-stride loop and keep them in 30 registers (140 VGPRs, 3 waves per SIMD): the copy below is opaque to it
+            float2 w = wu;
+            asm volatile("" : "+v"(w.x), "+v"(w.y));
+            float2 o_lo = combine<Q>(a_lo, b_lo, w);
+            if constexpr (Q == 0) {   // element 0 of thread 0 packs DC and Nyquist (RC:280-286, 332-339)
+                const float2 packed = DIR ? make_float2(0.5f * (a_lo.x + a_lo.y), 0.5f * (a_lo.x - a_lo.y)) : make_float2(a_lo.x + a_lo.y, a_lo.x - a_lo.y);
+                o_lo = first ? packed : o_lo;
             }
-            r[q] = out;
+            const float2 o_hi = combine<15 - Q>(a_hi, b_hi, w);
+            r[Q] = o_lo;
+            r[15 - Q] = o_hi;
+            // Keep the steps apart: left alone, the compiler hoists all thirty-two fetches to the top to hide their
+            // latency and keeps their results in thirty-two registers (with four waves per SIMD the other waves cover
+            // the latency).  The empty asm makes this step's results and the next step's inputs its outputs, so the next
+            // fetches cannot start before this step's arithmetic is done.
+            if constexpr (Q < 7) {
+                asm volatile("" : "+v"(r[Q].x), "+v"(r[Q].y), "+v"(r[15 - Q].x), "+v"(r[15 - Q].y),
+                                  "+v"(r[Q + 1].x), "+v"(r[Q + 1].y), "+v"(r[14 - Q].x), "+v"(r[14 - Q].y));
+            }
+            apply_pair<Q + 1>(r, carried);
         }
     }
+    __device__ __forceinline__ void apply(float2 (&r)[16]) const {
+        float2 carried = make_float2(0.f, 0.f);   // step 0 of thread 0 does not use it (packed DC / Nyquist)
+        apply_pair<0>(r, carried);
+    }
 };
+
 
 template <int L, int DIR>
 __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nFFTs, float2* s) {
@@ -510,8 +542,14 @@ __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_length) FFT_GPU_multiple(
 }
 
 // R2C/C2R program.
+// compiled for 4 waves per SIMD (<= 128 VGPRs; real N = 4096, whose transform spans four waves, for 3): with the
+// in-place Hermitian step (HermitianRegisters::apply) the real N = 1024 / 2048 kernels need 89-112 registers, against
+// 139-146 (3 waves per SIMD) in round 1
+#ifndef SMFFT_RC_WAVES
+#define SMFFT_RC_WAVES 4
+#endif
 template <class const_params, class const_direction>
-__global__ void __launch_bounds__(256) FFT_GPU_R2C_C2R_external(const float2* d_input, float2* d_output, int nFFTs) {
+__global__ void __launch_bounds__(256, (const_params::fft_length <= 1024 ? SMFFT_RC_WAVES : 3)) FFT_GPU_R2C_C2R_external(const float2* d_input, float2* d_output, int nFFTs) {
     __shared__ float2 s_input[4352];
     smfft::r2c_c2r_external_body<const_params::fft_length, const_direction::fft_direction>(d_input, d_output, nFFTs, s_input);
 }
