@@ -19,8 +19,14 @@
 //         study_read<1..3> on 0 / S|X / F, study_write<1..3> likewise
 //         study_copy_paced<1..3>  the same three outputs with the 16-flat-load "VMEM throttle" of the external kernels
 //       Classification dispatches use tag 0.
+//   placement_study vmm [handle_MiB] [max_GiB]
+//       the hypothesis test: physical memory allocated through the VMM API in small handles (hipMemCreate), 1 GiB
+//       chunks classified as in `map`, then 4 GiB test buffers ASSEMBLED from chunks of chosen classes -- whole, or
+//       interleaved handle by handle -- and timed as copy targets: does an output interleaved over the classes
+//       reproduce the "fast write region"?
 // Build: hipcc -O3 --offload-arch=gfx950 placement_study.hip -o placement_study
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -151,6 +157,136 @@ static void dump_file(const char* path) {
     fclose(f);
 }
 
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static int vmm_mode(size_t handle_mib, size_t max_gib) {
+    const size_t G = 1ull << 30, H = handle_mib << 20, per_chunk = G / H;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    size_t gran = 0;
+    CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    size_t free_b = 0, total_b = 0;
+    CK(hipMemGetInfo(&free_b, &total_b));
+    size_t nchunks = std::min<size_t>(max_gib, (free_b - (24ull << 30)) / G);
+    printf("vmm: granularity %zu, handles of %zu MiB, %zu chunks of 1 GiB\n", gran, handle_mib, nchunks);
+    char* va = nullptr;
+    CK(hipMemAddressReserve((void**)&va, nchunks * G, 0, nullptr, 0));
+    std::vector<hipMemGenericAllocationHandle_t> handle(nchunks * per_chunk);
+    double t0 = now_s();
+    size_t made = 0;
+    for (; made < handle.size(); ++made)
+        if (hipMemCreate(&handle[made], H, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+    nchunks = made / per_chunk;
+    printf("hipMemCreate: %zu handles in %.3f s (%.1f us each, %.2f ms per GiB)\n", made, now_s() - t0, (now_s() - t0) / made * 1e6, (now_s() - t0) / (made * H / (double)G) * 1e3);
+    t0 = now_s();
+    for (size_t h = 0; h < nchunks * per_chunk; ++h) CK(hipMemMap(va + h * H, H, 0, handle[h], 0));
+    CK(hipMemSetAccess(va, nchunks * G, &acc, 1));
+    printf("hipMemMap + hipMemSetAccess: %.3f s\n", now_s() - t0);
+    g_ntiles = (long)(G / 8 / 4096);      // probes over 1 GiB windows
+    for (size_t j = 0; j < nchunks; ++j) study_write<0><<<g_grid, 256>>>((v2f*)(va + j * G), g_ntiles);
+    CK(hipDeviceSynchronize());
+    for (int k = 0; k < 300; ++k) study_copy<0><<<g_grid, 256>>>((const v2f*)va, (v2f*)(va + G), g_ntiles);
+    CK(hipDeviceSynchronize());
+    // classify against chunk 0: copy 0 -> j, and the pure write rate of j
+    std::vector<float> out0(nchunks, 0.f), wr(nchunks), rd(nchunks);
+    for (size_t j = 0; j < nchunks; ++j) {
+        if (j) out0[j] = t_copy<0>(va, va + j * G, 4);
+        wr[j] = t_write<0>(va + j * G, 4);
+        rd[j] = t_read<0>(va + j * G, va + (j ? 0 : G), 4);
+    }
+    printf("chunk: copy 0->j ms (1 GiB + 1 GiB), write ms, read ms\n");
+    for (size_t j = 0; j < nchunks; ++j) printf("%3zu %.3f %.3f %.3f\n", j, out0[j], wr[j], rd[j]);
+    // classes: A = like chunk 0 (slow output for input 0), B / C = the two other ordinary classes (told apart by timing
+    // chunks against the first B found), M = mixed (fast pure write)
+    std::vector<float> sorted_wr(wr);
+    std::sort(sorted_wr.begin(), sorted_wr.end());
+    const float wr_typ = sorted_wr[nchunks / 2];
+    std::vector<float> o(out0.begin() + 1, out0.end());
+    std::sort(o.begin(), o.end());
+    const float slow = o[o.size() - 1 - o.size() / 20], fastc = o[o.size() / 20];
+    const float cut = 0.5f * (slow + fastc);
+    std::vector<int> cls(nchunks, -1);   // 0 A, 1 B, 2 C, 3 mixed
+    cls[0] = 0;
+    int firstB = -1;
+    for (size_t j = 1; j < nchunks; ++j) {
+        if (wr[j] < 0.93f * wr_typ) { cls[j] = 3; continue; }
+        if (out0[j] > cut) { cls[j] = 0; continue; }
+        if (firstB < 0) { firstB = (int)j; cls[j] = 1; continue; }
+    }
+    if (firstB >= 0)
+        for (size_t j = 1; j < nchunks; ++j)
+            if (cls[j] < 0) cls[j] = (t_copy<0>(va + (size_t)firstB * G, va + j * G, 4) > cut) ? 1 : 2;
+    printf("classes (A = chunk 0's, M = mixed): ");
+    for (size_t j = 0; j < nchunks; ++j) printf("%c", "ABCM?"[cls[j] < 0 ? 4 : cls[j]]);
+    printf("\n");
+    std::vector<size_t> of[4];
+    for (size_t j = 0; j < nchunks; ++j) if (cls[j] >= 0) of[cls[j]].push_back(j);
+    printf("A %zu, B %zu, C %zu, mixed %zu chunks\n", of[0].size(), of[1].size(), of[2].size(), of[3].size());
+    if (of[0].size() < 15 || of[1].size() < 12) { printf("not enough classes inside the allocated range\n"); return 0; }
+    const bool haveC = of[2].size() >= 4;
+
+    // assemble 4 GiB test buffers in a second VA range out of the handles of chosen chunks (unmapped from `va` first)
+    g_ntiles = (long)(4 * G / 8 / 4096);
+    size_t cursor[3] = {1, 0, 0};          // next unused chunk of each class (A: chunk 0 stays the probe reference)
+    auto take = [&](int c) { return of[c][cursor[c]++]; };
+    auto assemble = [&](std::vector<std::vector<size_t>> sources, size_t gran_handles, const char* what) -> char* {
+        // sources[k] = the 1 GiB chunks of stream k; the buffer takes gran_handles handles from stream 0, then from stream 1, ...
+        char* t = nullptr;
+        CK(hipMemAddressReserve((void**)&t, 4 * G, 0, nullptr, 0));
+        std::vector<std::vector<size_t>> hs(sources.size());
+        for (size_t k = 0; k < sources.size(); ++k)
+            for (size_t ch : sources[k]) {
+                CK(hipMemUnmap(va + ch * G, G));
+                for (size_t h = 0; h < per_chunk; ++h) hs[k].push_back(ch * per_chunk + h);
+            }
+        std::vector<size_t> pos(sources.size(), 0);
+        size_t mapped = 0, k = 0;
+        while (mapped < 4 * G / H) {
+            for (size_t i = 0; i < gran_handles && mapped < 4 * G / H; ++i) {
+                CK(hipMemMap(t + mapped * H, H, 0, handle[hs[k][pos[k]++]], 0));
+                ++mapped;
+            }
+            k = (k + 1) % sources.size();
+        }
+        CK(hipMemSetAccess(t, 4 * G, &acc, 1));
+        study_write<0><<<g_grid, 256>>>((v2f*)t, g_ntiles);
+        CK(hipDeviceSynchronize());
+        printf("assembled %s\n", what);
+        return t;
+    };
+    auto four = [&](int c) { std::vector<size_t> v; for (int i = 0; i < 4; ++i) v.push_back(take(c)); return v; };
+    auto two = [&](int c) { std::vector<size_t> v; for (int i = 0; i < 2; ++i) v.push_back(take(c)); return v; };
+    char* inA = assemble({four(0)}, 1, "inA: 4 GiB of class A");
+    char* outA = assemble({four(0)}, 1, "outA: 4 GiB of class A");
+    char* outB = assemble({four(1)}, 1, "outB: 4 GiB of class B");
+    char* outAB = (of[1].size() - cursor[1] >= 2 && of[0].size() - cursor[0] >= 2) ? assemble({two(0), two(1)}, 1, "outAB: classes A and B interleaved handle by handle") : nullptr;
+    char *outBC = nullptr, *outABC = nullptr, *outBC64 = nullptr;
+    if (haveC && of[1].size() - cursor[1] >= 6 && of[2].size() - cursor[2] >= 6 && of[0].size() - cursor[0] >= 2) {
+        outBC = assemble({two(1), two(2)}, 1, "outBC: classes B and C interleaved handle by handle");
+        outABC = assemble({two(0), two(1), two(2)}, 1, "outABC: all three classes interleaved handle by handle");
+        outBC64 = assemble({two(1), two(2)}, (64ull << 20) / H ? (64ull << 20) / H : 1, "outBC64: classes B and C interleaved in 64 MiB pieces");
+    }
+    struct Case { const char* name; char* in; char* out; };
+    std::vector<Case> cases = {{"A -> A (same class)", inA, outA}, {"A -> B (other class)", inA, outB}};
+    if (outAB) cases.push_back({"A -> A+B interleaved", inA, outAB});
+    if (outBC) cases.push_back({"A -> B+C interleaved", inA, outBC});
+    if (outABC) cases.push_back({"A -> A+B+C interleaved", inA, outABC});
+    if (outBC64) cases.push_back({"A -> B+C in 64 MiB pieces", inA, outBC64});
+    if (outBC) cases.push_back({"B+C interleaved -> A", outBC, outA});
+    if (outAB) cases.push_back({"A+B interleaved -> A", outAB, outA});
+    for (int rep = 0; rep < 2; ++rep)
+        for (auto& c : cases)
+            printf("%-28s copy %.3f ms | write-only into the output %.3f ms | read-only from the input %.3f ms\n", c.name, t_copy<0>(c.in, c.out, 6),
+                   t_write<0>(c.out, 6), t_read<0>(c.in, c.out, 6));
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "map";
     const size_t chunk_gib = argc > 2 ? atol(argv[2]) : 4;
@@ -161,6 +297,7 @@ int main(int argc, char** argv) {
     CK(hipSetDevice(0));
     CK(hipEventCreate(&g_e0));
     CK(hipEventCreate(&g_e1));
+    if (mode == "vmm") return vmm_mode(argc > 2 ? atol(argv[2]) : 8, argc > 3 ? atol(argv[3]) : 140);
     size_t free_b = 0, total_b = 0;
     CK(hipMemGetInfo(&free_b, &total_b));
     printf("mode %s: chunk %zu GiB, free %.1f GiB of %.1f GiB\n", mode.c_str(), chunk_bytes >> 30, free_b / 1073741824.0, total_b / 1073741824.0);
