@@ -120,24 +120,34 @@ const char* smfft_version(void);
 
 /* ---- plain device-memory helpers so a C / ctypes caller needs no other HIP binding ----------- */
 void* smfft_malloc(unsigned long long bytes);
-/* Two buffers of `bytes` each for a kernel that READS the first and WRITES the second.  On MI355X the rate of
- * such a kernel depends on which physical memory the two buffers are: 1.31 ... 1.55 ms for the 4 GiB + 4 GiB N=1024
- * batch, i.e. 0.69 ... 0.82 of the HBM peak (profiles/r01_chunk_map.txt); two plain hipMalloc
- * calls land anywhere in that range.  For buffers of 1 to 16 GiB this call first tries a shortcut -- input from hipMalloc,
- * output from the stream-ordered allocator (hipMallocAsync), which on most boxes hands out the fast write region: one
- * copy probe, 0.1-0.3 s, accepted at 6.25 TB/s or more (SMFFT_NO_POOL_SHORTCUT disables it) -- and otherwise runs the
- * search: it allocates candidates (>= 4 GiB each) over
- * the free memory, times a stream copy from a reference candidate into every other one and then from every candidate
- * into the best target, keeps the fastest (input, output) and releases the rest.  Cost: 4-5 s on an empty 288 GB
- * device, nearly all of it hipMalloc / hipFree; SMFFT_PAIR_SEARCH_CHUNKS=k limits the search to k candidates (12:
- * 0.6 s, finds the common fast class but rarely the fast write region), SMFFT_NO_PAIR_PLACEMENT turns it off (two plain
- * allocations).  The L3 wrappers use it.  Release with smfft_free_pair(d_read). */
+/* Two buffers of `bytes` each for a kernel that READS the first and WRITES the second.  On MI355X the rate of such a
+ * kernel depends on which physical memory the two buffers are (profiles/r02_placement_*): the HBM
+ * falls into three classes of ~89 GiB; input and output in the same class -- what two hipMalloc calls in a row give --
+ * run the 4 GiB + 4 GiB N=1024 batch in 1.55-1.60 ms (0.69 of the HBM peak), in different classes in 1.48-1.52 ms, and
+ * with the output in a MIXED allocation (pages from several classes) in 1.30-1.35 ms (0.81).  This call takes the input
+ * from hipMalloc and picks the output among a BOUNDED set of candidates, each timed with a stream copy from the input:
+ * one block of the stream-ordered pool (hipMallocAsync; usually mixed), then ordinary blocks allocated one after the other.
+ * It stops at the first candidate whose copy time is within 2.3 x the input's pure read time (the device's own
+ * ceiling), or when the candidates reach a quarter of the free memory (SMFFT_PAIR_BUDGET_FRAC) or 2 s
+ * (SMFFT_PAIR_BUDGET_MS); the best candidate is kept, the others freed.  Buffers are exactly `bytes` long.
+ * SMFFT_PAIR_POLICY=plain: two plain allocations.  Nothing is kept after smfft_free_pair unless SMFFT_PAIR_CACHE=1.
+ * The L3 wrappers allocate plainly, like the reference (CT:850-853), unless SMFFT_WRAPPER_PLACEMENT=1.
+ * Release with smfft_free_pair(d_read) (an error for a pointer this call did not return). */
 int smfft_malloc_pair(unsigned long long bytes, void** d_read, void** d_written);
 int smfft_free_pair(void* d_read);
-/* smfft_free_pair keeps the most recently released SEARCHED pair (its two candidates, >= 8 GiB of device memory) for the
- * next smfft_malloc_pair on the same device that fits into it, because finding one costs seconds; this call (or
- * SMFFT_NO_PAIR_CACHE in the environment) gives the memory back. */
+/* gives back the pair SMFFT_PAIR_CACHE=1 keeps */
 int smfft_pair_cache_release(void);
+/* what the last smfft_malloc_pair of this process did (telemetry for bench.py and the tests) */
+typedef struct SmfftPairInfo {
+    unsigned long long bytes;            /* size of each buffer */
+    unsigned long long candidate_bytes;  /* bytes held by candidates at the end of the search (<= the byte budget + one buffer) */
+    int candidates;                      /* candidates probed (0: plain policy) */
+    int chosen;                          /* index of the candidate kept (0 = the pool block) */
+    int good_enough;                     /* 1: the search ended on the 2.3 x read-time criterion */
+    float read_ms, copy_ms, first_copy_ms;   /* probe window: pure read of the input; copy into the chosen / the first ordinary candidate */
+    double search_ms;
+} SmfftPairInfo;
+int smfft_last_pair_info(SmfftPairInfo* out);
 int smfft_free(void* d_ptr);
 int smfft_memcpy_h2d(void* d_dst, const void* h_src, unsigned long long bytes);
 int smfft_memcpy_d2h(void* h_dst, const void* d_src, unsigned long long bytes);

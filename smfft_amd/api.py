@@ -55,6 +55,7 @@ _SIGS = {
     "smfft_malloc_pair": (_i, [_ull, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "smfft_free_pair": (_i, [_vp]),
     "smfft_pair_cache_release": (_i, []),
+    "smfft_last_pair_info": (_i, [_vp]),
     "smfft_free": (_i, [_vp]),
     "smfft_memcpy_h2d": (_i, [_vp, _vp, _ull]),
     "smfft_memcpy_d2h": (_i, [_vp, _vp, _ull]),
@@ -87,6 +88,19 @@ EXPORTED_CXX_SYMBOLS = (
 def _ck(rc, what):
     if rc != 0:
         raise RuntimeError(f"{what} failed with HIP error {rc}")
+
+
+class SmfftPairInfo(ctypes.Structure):
+    """mirror of include/smfft.h SmfftPairInfo"""
+    _fields_ = [("bytes", ctypes.c_ulonglong), ("candidate_bytes", ctypes.c_ulonglong), ("candidates", ctypes.c_int), ("chosen", ctypes.c_int),
+                ("good_enough", ctypes.c_int), ("read_ms", ctypes.c_float), ("copy_ms", ctypes.c_float), ("first_copy_ms", ctypes.c_float),
+                ("search_ms", ctypes.c_double)]
+
+
+def last_pair_info():
+    info = SmfftPairInfo()
+    lib.smfft_last_pair_info(ctypes.byref(info))
+    return {name: getattr(info, name) for name, _ in SmfftPairInfo._fields_}
 
 
 class DeviceBuffer:

@@ -45,11 +45,16 @@ int launch_stream_copy(const float2* d_input, float2* d_output, long n_float2, i
     long ntiles = n_float2 / 4096;
     if (ntiles <= 0) return 0;
     long g = (grid_cap > 0 && ntiles > grid_cap) ? grid_cap : ntiles;
-    const char* e = getenv("SMFFT_COPY_TRIPS");   // 0 = the plain copy, for the comparison in tools/copy_trip_probe.py
-    const int trips = e ? atoi(e) : 1;
-    if (trips == 0)      SMFFT_stream_copy<0><<<dim3((unsigned)g), dim3(256), 0, stream>>>(d_input, d_output, ntiles);
-    else if (trips == 2) SMFFT_stream_copy<2><<<dim3((unsigned)g), dim3(256), 0, stream>>>(d_input, d_output, ntiles);
-    else                 SMFFT_stream_copy<1><<<dim3((unsigned)g), dim3(256), 0, stream>>>(d_input, d_output, ntiles);
+    const char* e = getenv("SMFFT_COPY_TRIPS");   // 1 = with the LDS round trip of lds_round_trip (smfft_kernels.hpp), an A/B switch
+    if (e && atoi(e) == 1) SMFFT_stream_copy<1><<<dim3((unsigned)g), dim3(256), 0, stream>>>(d_input, d_output, ntiles);
+    else                   SMFFT_stream_copy<0><<<dim3((unsigned)g), dim3(256), 0, stream>>>(d_input, d_output, ntiles);
+    return (int)hipGetLastError();
+}
+int launch_stream_read(const float2* d_input, long n_float2, int grid_cap, hipStream_t stream) {
+    long ntiles = n_float2 / 4096;
+    if (ntiles <= 0) return 0;
+    long g = (grid_cap > 0 && ntiles > grid_cap) ? grid_cap : ntiles;
+    SMFFT_stream_read<0><<<dim3((unsigned)g), dim3(256), 0, stream>>>(d_input, const_cast<float2*>(d_input), ntiles);
     return (int)hipGetLastError();
 }
 #endif

@@ -464,12 +464,12 @@ def test_beyond_32bit_element_index(sm, oracle_lib):
     print(f"2^21+5 FFTs of 1024: {ms:.3f} ms = {2 * nbytes / ms / 1e6:.0f} GB/s")
 
 
-def test_malloc_pair(sm, monkeypatch):
-    """smfft_malloc_pair: two usable, disjoint buffers (pool shortcut or placement search); the search releases its
-    other candidates; a released SEARCHED pair is kept for the next request that fits."""
+def test_malloc_pair_bounded_search(sm, monkeypatch):
+    """smfft_malloc_pair: two usable, disjoint buffers of exactly the requested size; the search stays inside its byte
+    and time budgets, frees every candidate it does not keep, and keeps nothing after smfft_free_pair by default."""
     import ctypes
     import time
-    nbytes = 1 << 30                       # >= 1 GiB: placement is active
+    nbytes = 1 << 30
     x = (np.random.default_rng(0).random((64, 1024, 2), dtype=np.float32)).view(np.complex64).reshape(64, 1024)
 
     def use(a, b):
@@ -480,52 +480,62 @@ def test_malloc_pair(sm, monkeypatch):
         sm.lib.smfft_memcpy_d2h(got.ctypes.data, b.value, x.nbytes)
         ref.assert_close_fp32(got, ref.ct_c2c(x, False, True), "paired buffers")
 
-    # default path (stream-ordered-pool shortcut when its copy probe is fast enough, else the search)
+    free0 = _free_bytes(sm)
     a, b = ctypes.c_void_p(), ctypes.c_void_p()
-    assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
-    use(a, b)
-    assert sm.lib.smfft_free_pair(a.value) == 0
-    assert sm.lib.smfft_pair_cache_release() == 0
-    # the search itself (shortcut off, a few candidates): everything but the pair is released, the pair is cached on free
-    monkeypatch.setenv("SMFFT_NO_POOL_SHORTCUT", "1")
-    monkeypatch.setenv("SMFFT_PAIR_SEARCH_CHUNKS", "6")
-    a, b = ctypes.c_void_p(), ctypes.c_void_p()
-    assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
-    use(a, b)
-    big = sm.DeviceBuffer(200 << 30)        # the other candidates are gone: most of the memory is allocatable
-    big.free()
-    assert sm.lib.smfft_free_pair(a.value) == 0
-    a2, b2 = ctypes.c_void_p(), ctypes.c_void_p()
     t0 = time.perf_counter()
-    assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(a2), ctypes.byref(b2)) == 0
-    assert time.perf_counter() - t0 < 0.5 and (a2.value, b2.value) == (a.value, b.value)   # same pair, no second search
-    assert sm.lib.smfft_free_pair(a2.value) == 0
+    assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
+    took = time.perf_counter() - t0
+    info = sm.last_pair_info()
+    use(a, b)
+    assert info["bytes"] == nbytes and info["candidates"] >= 1 and 0 <= info["chosen"] < info["candidates"]
+    assert info["candidate_bytes"] <= 0.25 * free0 + nbytes                 # the byte budget (a quarter of the free memory)
+    assert info["search_ms"] <= 2000 + 1500 and took < 6.0, (info, took)   # the time budget (+ the last candidate's allocation)
+    assert info["copy_ms"] <= info["first_copy_ms"] * 1.02                  # never worse than the first ordinary candidate
+    assert free0 - _free_bytes(sm) <= 2 * nbytes + (64 << 20)               # only the pair is still allocated
+    assert sm.lib.smfft_free_pair(a.value) == 0
+    assert free0 - _free_bytes(sm) <= (64 << 20)                             # nothing cached by default
+    assert sm.lib.smfft_free_pair(a.value) != 0                              # unknown pointer: an error, nothing freed twice
+    # a tight budget: exactly the pool block and one ordinary candidate at most
+    monkeypatch.setenv("SMFFT_PAIR_BUDGET_FRAC", "0.0")
+    assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
+    assert sm.last_pair_info()["candidates"] <= 2
+    use(a, b)
+    assert sm.lib.smfft_free_pair(a.value) == 0
+    monkeypatch.delenv("SMFFT_PAIR_BUDGET_FRAC")
+    # opt-in cache: the released pair is handed out again without a search
+    monkeypatch.setenv("SMFFT_PAIR_CACHE", "1")
+    assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
+    first = (a.value, b.value)
+    assert sm.lib.smfft_free_pair(a.value) == 0
+    t0 = time.perf_counter()
+    assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
+    assert time.perf_counter() - t0 < 0.2 and (a.value, b.value) == first
+    monkeypatch.delenv("SMFFT_PAIR_CACHE")
+    assert sm.lib.smfft_free_pair(a.value) == 0
     assert sm.lib.smfft_pair_cache_release() == 0
     assert sm.lib.smfft_pair_cache_release() == 0   # idempotent
+    assert free0 - _free_bytes(sm) <= (64 << 20)
 
 
-def test_malloc_pair_search_controls(sm, monkeypatch):
-    """SMFFT_PAIR_SEARCH_CHUNKS caps the placement search, SMFFT_NO_PAIR_PLACEMENT turns it off; either way the pair is
-    usable and freed cleanly (a second full-size pair can be made afterwards)."""
+def _free_bytes(sm):
+    import torch
+    return torch.cuda.mem_get_info()[0]
+
+
+def test_malloc_pair_plain_policy_and_many_pairs(sm, monkeypatch):
+    """SMFFT_PAIR_POLICY=plain: two plain allocations, no probing; the pair table grows as needed (more than the 64
+    slots round 1 had) and every pair is released by its read pointer."""
     import ctypes
-    import time
-    nbytes = 2 << 30
-    took = {}
-    for name, env in (("capped", {"SMFFT_PAIR_SEARCH_CHUNKS": "4"}), ("off", {"SMFFT_NO_PAIR_PLACEMENT": "1"})):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    monkeypatch.setenv("SMFFT_PAIR_POLICY", "plain")
+    pairs = []
+    for _ in range(100):
         a, b = ctypes.c_void_p(), ctypes.c_void_p()
-        t0 = time.perf_counter()
-        assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
-        took[name] = time.perf_counter() - t0
-        assert a.value and b.value and abs(b.value - a.value) >= nbytes
-        assert sm.lib.smfft_memset(a.value, 0, nbytes) == 0 and sm.lib.smfft_memset(b.value, 0, nbytes) == 0
-        rc, ms = sm.FFT_external_benchmark(a.value, b.value, 1024, nbytes // (1024 * 8))
-        assert rc == 0 and ms > 0
-        assert sm.lib.smfft_free_pair(a.value) == 0
-        for k in env:
-            monkeypatch.delenv(k)
-    assert took["off"] < 1.0 and took["capped"] < 3.0, took
+        assert sm.lib.smfft_malloc_pair(1 << 20, ctypes.byref(a), ctypes.byref(b)) == 0
+        pairs.append(a.value)
+    assert sm.last_pair_info()["candidates"] == 0
+    assert len(set(pairs)) == 100
+    for p in pairs:
+        assert sm.lib.smfft_free_pair(p) == 0
 
 
 @pytest.mark.parametrize("n", [32, 1024, 4096])
