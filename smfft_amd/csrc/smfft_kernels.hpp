@@ -387,6 +387,9 @@ struct HermitianRegisters {
 };
 
 
+#ifndef SMFFT_RC_PREFETCH
+#define SMFFT_RC_PREFETCH 0
+#endif
 template <int L, int DIR>
 __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nFFTs, float2* s) {
     using G = Geometry<L>;
@@ -396,16 +399,32 @@ __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__
     herm.init(threadIdx.x);
     float2* sf = s + eng.fft * G::SF;
     const int ntiles = (nFFTs + G::kFftsPerBlock - 1) / G::kFftsPerBlock;
+    float2 r[16];
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long f = (long)tile * G::kFftsPerBlock + eng.fft;
         const bool active = f < nFFTs;
-        float2 r[16];
         if constexpr (HermitianRegisters<L, DIR>::kEnabled) {
+#if SMFFT_RC_PREFETCH
+            // the next tile's loads are issued before this tile is transformed (they return in order, so waiting for this
+            // tile's data does not wait for them): two tiles per wave in flight
+            float2 nx[16];
+            if (tile == (int)blockIdx.x) eng.load_global(r, d_input + (active ? f : 0) * L);
+            const int nt = tile + gridDim.x;
+            const long fn = (long)nt * G::kFftsPerBlock + eng.fft;
+            if (nt < ntiles) eng.load_global(nx, d_input + (fn < nFFTs ? fn : 0) * L);
+            if (DIR == 1) herm.apply(r);
+            eng.transform(r, sf);
+            if (DIR == 0) herm.apply(r);
+            eng.store_global(r, d_output + f * L, active);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) r[c] = nx[c];
+#else
             eng.load_global(r, d_input + (active ? f : 0) * L);
             if (DIR == 1) herm.apply(r);
             eng.transform(r, sf);
             if (DIR == 0) herm.apply(r);
             eng.store_global(r, d_output + f * L, active);
+#endif
         } else if (DIR == 0) {
             eng.load_global(r, d_input + (active ? f : 0) * L);
             if (G::kMultiWave) __syncthreads();
