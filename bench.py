@@ -62,12 +62,15 @@ def cpu_baseline(x, threads):
         fb.fftw_baseline_c2c_sliced.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         # one single-threaded plan per batch slice, slices run concurrently (oracle/fftw_baseline.c);
         # a few thread counts are tried for a bounded time, `cores` = the count that won
-        cands = sorted({c for c in (8, 32, 64, 128, threads // 2, threads) if 1 <= c <= threads})
+        # (largest counts first: they are the ones that win on the GPU boxes' 128-256 hardware threads, and the budget may
+        # not reach the small ones on a 4 GiB input)
+        cands = sorted({c for c in (8, 32, 64, 128, threads // 2, threads) if 1 <= c <= threads}, reverse=True)
         best_all, best_thr = 1e30, 0
+        out.fill(0)                       # first touch of the output outside the timing
         t_start = time.time()
         if fb.fftw_baseline_init(1):
             for thr in cands:
-                if time.time() - t_start > 25.0:
+                if time.time() - t_start > 30.0:
                     break
                 t = fb.fftw_baseline_c2c_sliced(x.ctypes.data_as(fp), out.ctypes.data_as(fp), n, sample_ffts, 0, 3, thr)
                 if 0 < t < best_all:
@@ -110,6 +113,20 @@ def measured_traffic():
         return None
 
 
+def vram_used_bytes(torch, dev):
+    """mem_info_vram_used of the card that runs the bench (None if its sysfs node cannot be identified)."""
+    try:
+        import glob
+        p = torch.cuda.get_device_properties(dev)
+        want = "%04x:%02x:%02x." % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        for d in glob.glob("/sys/class/drm/card*/device"):
+            if os.path.basename(os.path.realpath(d)).startswith(want):
+                return int(open(os.path.join(d, "mem_info_vram_used")).read())
+    except Exception:
+        pass
+    return None
+
+
 def device_info(torch, dev):
     """Which part ran the numbers (runs on different boxes of the pool differ by up to 6 %)."""
     info = {}
@@ -134,8 +151,8 @@ def device_info(torch, dev):
             except OSError:
                 continue
             bdf = os.path.basename(os.path.realpath(d))
-            if want is not None and not bdf.startswith(want):
-                continue
+            if want is None or not bdf.startswith(want):
+                continue                  # only the card that ran the bench (other tenants' cards share the sysfs tree)
             sysfs = {}
             for name in ("current_memory_partition", "current_compute_partition", "pp_dpm_mclk", "pp_dpm_sclk", "pp_dpm_fclk",
                          "mem_info_vram_total", "mem_info_vram_used", "power_dpm_force_performance_level"):
@@ -225,6 +242,7 @@ def main():
     n, nffts = FFT_SIZE, args.nffts
     dev = torch.device("cuda", local_rank)
     stats_dev = dev if backend == "nccl" else torch.device("cpu")
+    vram = {"before_any_allocation": vram_used_bytes(torch, dev)}
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     # U[0,1) re/im like the reference harness (SMFFT_CooleyTukey_C2C/FFT.c:141-142); float2 = 2 floats
@@ -240,6 +258,8 @@ def main():
     if sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(pa), ctypes.byref(pb)) != 0:
         raise SystemExit("smfft_malloc_pair failed")
     alloc_s = time.perf_counter() - t_alloc
+    pair_info = sm.last_pair_info()
+    vram["after_smfft_malloc_pair"] = vram_used_bytes(torch, dev)
     p_in, p_out = sm.DeviceBuffer(nbytes), sm.DeviceBuffer(nbytes)
     sm.lib.smfft_memcpy_d2d(pa.value, t_in.data_ptr(), nbytes)
     sm.lib.smfft_memcpy_d2d(p_in.ptr, t_in.data_ptr(), nbytes)
@@ -353,14 +373,25 @@ def main():
         rn, rnffts = 2048, min(262144, nffts * n * 2 // 2048 // 2)
         rbytes = rn * rnffts * 4
         c4 = {"nFFTs": rnffts, "real_N": rn, "algorithmic_bytes_per_launch": 2 * rbytes}
-        for name, inv, src, dst in (("r2c", 0, pa.value, pb.value), ("c2r", 1, pb.value, pa.value)):
+        # R2C: first half of the read buffer -> first half of the written buffer; the packed spectra are then copied into the
+        # read buffer's second half so that C2R, too, READS the read buffer and WRITES the written one (second halves)
+        half = nbytes // 2
+        for name, inv, src, dst in (("r2c", 0, pa.value, pb.value), ("c2r", 1, pa.value + half, pb.value + half)):
+            if inv:
+                sm.lib.smfft_memcpy_d2d(src, pb.value, rbytes)
             ms = median_ms(lambda t, inv=inv, src=src, dst=dst: sm.lib.smfft_rc_external_benchmark(src, dst, rn, rnffts, inv, t))
             gbps = 2 * rbytes / (ms * 1e-3) / 1e9
             c4[name] = {"ms": ms, "TB/s": gbps / 1e3, "frac": gbps / HBM_PEAK_GBPS}
-        # the C2R above overwrote the pair's input with (N/2) * x; restore nothing: the batch is not used again
         configs = {"timing": "median of 11 event-timed launches after 3 warm-ups, buffers of `roofline`",
                    "config3_multiple": c3, "config4_r2c_c2r_external": c4}
 
+    # release everything, then look at the driver's accounting once more: freed VRAM is returned asynchronously
+    sm.lib.smfft_free_pair(pa.value)
+    p_in.free()
+    p_out.free()
+    vram["after_freeing_all_buffers"] = vram_used_bytes(torch, dev)
+    time.sleep(1.0)
+    vram["one_second_later"] = vram_used_bytes(torch, dev)
     if rank == 0:
         ms_per_step = wall_max / args.steps * 1e3
         total_ffts = nffts * world
@@ -392,6 +423,8 @@ def main():
             "roofline_plain": roof(plain_kernel_ms_max, plain_copy_ms),
             "value_plain": total_ffts / (plain_wall_max / args.steps),
             "pair_alloc_s": alloc_s,
+            "pair_search": pair_info,
+            "vram_used_bytes": vram,
             "multiple_path": mult,
             "configs": configs,
             "comm_backend": (backend if world > 1 else None),
@@ -404,7 +437,6 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    sm.lib.smfft_free_pair(pa.value)
     if dist is not None:
         dist.destroy_process_group()
 
