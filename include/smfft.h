@@ -121,16 +121,20 @@ const char* smfft_version(void);
 /* ---- plain device-memory helpers so a C / ctypes caller needs no other HIP binding ----------- */
 void* smfft_malloc(unsigned long long bytes);
 /* Two buffers of `bytes` each for a kernel that READS the first and WRITES the second.  On MI355X the rate of such a
- * kernel depends on which physical memory the two buffers are (profiles/r02_placement_*): the HBM
- * falls into three classes of ~89 GiB; input and output in the same class -- what two hipMalloc calls in a row give --
- * run the 4 GiB + 4 GiB N=1024 batch in 1.55-1.60 ms (0.69 of the HBM peak), in different classes in 1.48-1.52 ms, and
- * with the output in a MIXED allocation (pages from several classes) in 1.30-1.35 ms (0.81).  This call takes the input
- * from hipMalloc and picks the output among a BOUNDED set of candidates, each timed with a stream copy from the input:
- * one block of the stream-ordered pool (hipMallocAsync; usually mixed), then ordinary blocks allocated one after the other.
- * It stops at the first candidate whose copy time is within 2.3 x the input's pure read time (the device's own
- * ceiling), or when the candidates reach a quarter of the free memory (SMFFT_PAIR_BUDGET_FRAC) or 2 s
- * (SMFFT_PAIR_BUDGET_MS); the best candidate is kept, the others freed.  Buffers are exactly `bytes` long.
- * SMFFT_PAIR_POLICY=plain: two plain allocations.  Nothing is kept after smfft_free_pair unless SMFFT_PAIR_CACHE=1.
+ * kernel depends on which physical memory the two buffers are (profiles/r02_placement_*,
+ * profiles/r02_vmm_mixed_assembly.txt): the HBM falls into three classes of ~89 GiB, and about one physical GiB in seven
+ * is MIXED (pure writes 20 % faster, pure reads 7 % slower than ordinary memory).  Input and output ordinary and in the
+ * same class -- what two hipMalloc calls in a row give -- move the 4 GiB + 4 GiB N=1024 batch in 1.55-1.60 ms (0.69 of the
+ * HBM peak), in different classes in 1.48-1.53 ms, and with the output in mixed memory in 1.30-1.31 ms (0.82).
+ * This call takes the input from hipMalloc and BUILDS the output out of mixed memory with the virtual-memory API:
+ * physical memory is created in 8 MiB handles, 1 GiB at a time, each GiB is timed with one write-only pass and kept if it
+ * is mixed; the scan ends when the output is complete or at its budgets -- a quarter of the free memory
+ * (SMFFT_PAIR_BUDGET_FRAC), 2 s (SMFFT_PAIR_BUDGET_MS) -- and whatever is missing then comes from ordinary chunks.  The
+ * chosen handles are mapped back to back into one virtual range (an ordinary device pointer for the caller), the rest
+ * is released at once.  Buffers are exactly `bytes` long (the output's range is rounded up to 8 MiB).
+ * SMFFT_PAIR_POLICY=candidates: whole hipMallocAsync / hipMalloc blocks timed as copy targets inside the same budgets
+ * (also the fallback where the virtual-memory API is unavailable); =plain: two plain allocations.  Nothing is kept after
+ * smfft_free_pair unless SMFFT_PAIR_CACHE=1.  Requests below 256 MiB are served plainly.
  * The L3 wrappers allocate plainly, like the reference (CT:850-853), unless SMFFT_WRAPPER_PLACEMENT=1.
  * Release with smfft_free_pair(d_read) (an error for a pointer this call did not return). */
 int smfft_malloc_pair(unsigned long long bytes, void** d_read, void** d_written);
@@ -140,11 +144,11 @@ int smfft_pair_cache_release(void);
 /* what the last smfft_malloc_pair of this process did (telemetry for bench.py and the tests) */
 typedef struct SmfftPairInfo {
     unsigned long long bytes;            /* size of each buffer */
-    unsigned long long candidate_bytes;  /* bytes held by candidates at the end of the search (<= the byte budget + one buffer) */
-    int candidates;                      /* candidates probed (0: plain policy) */
-    int chosen;                          /* index of the candidate kept (0 = the pool block) */
-    int good_enough;                     /* 1: the search ended on the 2.3 x read-time criterion */
-    float read_ms, copy_ms, first_copy_ms;   /* probe window: pure read of the input; copy into the chosen / the first ordinary candidate */
+    unsigned long long candidate_bytes;  /* physical memory the scan held at its end (<= the byte budget + 1 GiB) */
+    int candidates;                      /* mixed policy: GiB chunks scanned; candidates policy: blocks probed; 0: plain */
+    int chosen;                          /* mixed policy: GiB of mixed memory in the output; candidates policy: index of the block kept */
+    int good_enough;                     /* 1: the output is all mixed memory (mixed) / met the 2.3 x read-time criterion (candidates) */
+    float read_ms, copy_ms, first_copy_ms;   /* over min(bytes, 1 GiB): pure read of the input; copy into the output; copy into the first chunk / block seen */
     double search_ms;
 } SmfftPairInfo;
 int smfft_last_pair_info(SmfftPairInfo* out);

@@ -14,6 +14,7 @@ from .api import (  # noqa: F401
     c2c,
     c2r,
     host_transform,
+    last_pair_info,
     launch,
     lib,
     pinned_empty,

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -99,41 +100,59 @@ int timed(F&& launch, double* FFT_time) {
 
 // ---- paired allocation ----------------------------------------------------------------------------
 // What round 2 measured on MI355X (tools/microbench/placement_study.hip; profiles/r02_placement_map.txt,
-// profiles/r02_placement_pmc.json): the 288 GB of HBM fall into THREE classes of ~89 GiB (the
-// three ranks of the 12-high stacks is the reading that fits); an ordinary allocation lies inside one class.  A
-// kernel that reads buffer A and writes buffer B runs the 4 GiB + 4 GiB batch in 1.55-1.60 ms when A and B are in the
-// same class, 1.48-1.52 ms in different classes, and 1.30-1.35 ms when B is a MIXED allocation (physical pages from
-// several classes: pure writes 18 % faster, pure reads 6 % slower than into / from one class).  Same request counts
-// in every case (TCC_EA0_RDREQ / WRREQ = the algorithmic bytes); what differs is the DRAM service time.  Nothing of it
-// shows in the virtual addresses, and two hipMalloc calls in a row land in the SAME class (the worst case).
-//
-// smfft_malloc_pair therefore takes the input from hipMalloc and looks for an output among a BOUNDED set of
-// candidates: first one block from the stream-ordered pool (hipMallocAsync memory is a mixed allocation on most
-// boxes), then ordinary blocks allocated one after the other (each pushes the allocator further through the
-// memory, towards another class) -- each timed with a stream copy from the input over a window of at most 1 GiB.
-// The search ends at the first candidate that is good enough (copy time <= kGoodRatio x the pure read time of the
-// same window: the device's own ceiling, not an absolute number), or when the candidates together reach the byte budget
-// (default a quarter of the free memory) or the time budget (default 2 s); the best candidate stays, the rest is
-// freed.  Buffers are exactly `bytes` long; nothing is cached between calls unless SMFFT_PAIR_CACHE=1.
-//   SMFFT_PAIR_POLICY=plain        two plain allocations, no probing (also: SMFFT_NO_PAIR_PLACEMENT)
-//   SMFFT_PAIR_BUDGET_FRAC=0.25    byte budget of the candidates as a fraction of the free memory
-//   SMFFT_PAIR_BUDGET_MS=2000      time budget
-struct PairRec { void* a = nullptr; void* b = nullptr; int device = -1; bool pool_b = false; size_t bytes = 0; bool searched = false; };
+// profiles/r02_placement_pmc.json, profiles/r02_vmm_mixed_assembly.txt):
+//  * The 288 GB of HBM fall into THREE classes of ~89 GiB (the three ranks of the 12-high stacks is the reading that
+//    fits).  An ordinary allocation lies inside one class; pure reads from it run at 7.2 TB/s, pure writes at 5.6 TB/s.
+//  * About one physical GiB in seven is MIXED: pure writes 20 % FASTER (6.9 TB/s), pure reads 7 % slower.
+//  * A kernel that reads buffer A and writes buffer B moves the 4 GiB + 4 GiB batch in 1.55-1.60 ms when A and B are
+//    ordinary and in the same class -- what two hipMalloc calls in a row give -- in 1.48-1.53 ms in different classes, and
+//    in 1.30-1.31 ms (0.82 of the HBM peak) when B consists of mixed memory; reading FROM mixed memory is the slowest case.
+//    Same request counts in every case (TCC_EA0_RDREQ / WRREQ = the algorithmic bytes): what differs is DRAM service time.
+//  * None of it shows in virtual addresses, but the pure write rate of a physical GiB tells mixed from ordinary at once.
+// smfft_malloc_pair ("mixed" policy, the default) therefore takes the input from hipMalloc and BUILDS the output with
+// the virtual-memory API: physical memory is created in 8 MiB handles, 1 GiB at a time; each GiB is mapped into a
+// scratch range, timed with one write-only pass (0.2 ms), and kept for the output if it is mixed; the scan ends when
+// the output is complete, or at the byte budget (default: a quarter of the free memory) or the time budget (default
+// 2 s), whatever is missing then coming from the last ordinary chunks scanned (the farthest from the input).  The
+// chosen handles are mapped back to back into one virtual range -- the caller sees an ordinary device pointer -- and
+// everything else is released.  Cost measured: 7-39 ms per scanned GiB (hipMemCreate), ~28 GiB scanned for a 4 GiB output
+// on average.
+//   SMFFT_PAIR_POLICY=mixed|candidates|plain   candidates: round-1 style, whole hipMalloc / hipMallocAsync blocks timed as
+//                                              copy targets inside the same budgets; plain: two plain allocations
+//   SMFFT_PAIR_BUDGET_FRAC=0.25                byte budget of the scan as a fraction of the free memory
+//   SMFFT_PAIR_BUDGET_MS=2000                  time budget
+//   SMFFT_PAIR_CACHE=1                         keep the last released pair for the next request of the same size
+struct PairRec {
+    void* a = nullptr;
+    void* b = nullptr;
+    int device = -1;
+    bool pool_b = false;      // b came from hipMallocAsync
+    size_t bytes = 0;
+    bool searched = false;
+    std::vector<hipMemGenericAllocationHandle_t> handles;   // b is a virtual range backed by these (mixed policy)
+    size_t va_bytes = 0;
+};
 std::map<void*, PairRec> g_pairs;      // keyed by the read buffer; grows as needed
 PairRec g_pair_cache;                  // SMFFT_PAIR_CACHE=1 only: the last searched pair that was released
 std::mutex g_pairs_mutex;              // shared by the per-GPU host threads of a multi-GPU driver
 SmfftPairInfo g_last_pair_info = {};
 
-constexpr double kGoodRatio = 2.30;    // mixed targets: 2.2-2.3 x the pure read time; other class: 2.5; same class: 2.6
+constexpr double kGoodRatio = 2.30;    // candidates policy: mixed targets copy in 2.2-2.3 x the pure read time; other class 2.5; same class 2.6
+constexpr float kMixedWriteRatio = 0.91f;   // mixed policy: a chunk is mixed if its write pass takes < 0.91 x the typical one (mixed: 0.79-0.88)
+constexpr size_t kHandleBytes = 8ull << 20, kChunkBytes = 1ull << 30;
 
-// mean ms of `launches` stream-copy launches (the external kernels' access shape) over the first `bytes` of the buffers;
-// out == nullptr: read-only pass
+// mean ms of `launches` passes in the external kernels' access shape over the first `bytes`: copy (in, out), pure read
+// (in, nullptr) or pure write (nullptr, out)
 float probe_ms(const void* in, void* out, size_t bytes, int launches) {
     const long n = (long)(bytes / 8 / 4096 * 4096);
     if (n <= 0) return 0.f;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 0.f;
-    auto launch = [&] { return out ? smfft::launch_stream_copy((const float2*)in, (float2*)out, n, 12288, 0) : smfft::launch_stream_read((const float2*)in, n, 12288, 0); };
+    auto launch = [&] {
+        if (in && out) return smfft::launch_stream_copy((const float2*)in, (float2*)out, n, 12288, 0);
+        if (in) return smfft::launch_stream_read((const float2*)in, n, 12288, 0);
+        return smfft::launch_stream_write((float2*)out, n, 12288, 0);
+    };
     launch();
     (void)hipEventRecord(e0, 0);
     for (int i = 0; i < launches; ++i) launch();
@@ -157,15 +176,174 @@ void free_buffer(void* p, bool pool) {
     else (void)hipFree(p);
 }
 
+void release_output(PairRec& rec) {
+    if (!rec.b) return;
+    if (rec.va_bytes) {
+        (void)hipMemUnmap(rec.b, rec.va_bytes);
+        for (auto h : rec.handles) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(rec.b, rec.va_bytes);
+        rec.handles.clear();
+        rec.va_bytes = 0;
+    } else {
+        free_buffer(rec.b, rec.pool_b);
+    }
+    rec.b = nullptr;
+}
+
+struct Budget {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    size_t bytes = 0;
+    double ms = 0;
+    double elapsed_ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+// "mixed" policy: the output as a virtual range over scanned physical chunks (see the comment above).  false: the VMM
+// API is not usable here (nothing is left allocated), the caller falls back to the candidates policy.
+bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& budget, PairRec& rec, SmfftPairInfo& info) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0 || kHandleBytes % gran) { (void)hipGetLastError(); return false; }
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    const size_t need = (bytes + kHandleBytes - 1) / kHandleBytes, per_chunk = kChunkBytes / kHandleBytes;
+    char *out = nullptr, *scratch = nullptr;
+    if (hipMemAddressReserve((void**)&out, need * kHandleBytes, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipMemAddressReserve((void**)&scratch, kChunkBytes, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemAddressFree(out, need * kHandleBytes); return false; }
+    struct Chunk { std::vector<hipMemGenericAllocationHandle_t> hs; float write_ms; };
+    std::vector<Chunk> chunks;
+    size_t created = 0;
+    bool api_ok = true;
+    auto typical = [&] {                 // the median write time: six chunks in seven are ordinary
+        std::vector<float> t;
+        for (auto& c : chunks) t.push_back(c.write_ms);
+        std::sort(t.begin(), t.end());
+        return t.size() < 3 ? t.back() : t[t.size() / 2];
+    };
+    auto mixed_handles = [&] {
+        const float typ = typical();
+        size_t n = 0;
+        for (auto& c : chunks) if (c.write_ms < kMixedWriteRatio * typ) n += c.hs.size();
+        return n;
+    };
+    while (true) {
+        if (!chunks.empty() && (mixed_handles() >= need || created + kChunkBytes > budget.bytes || budget.elapsed_ms() > budget.ms)) break;
+        Chunk c;
+        for (size_t h = 0; h < per_chunk; ++h) {
+            hipMemGenericAllocationHandle_t handle;
+            if (hipMemCreate(&handle, kHandleBytes, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+            c.hs.push_back(handle);
+        }
+        if (c.hs.size() < per_chunk) {      // out of memory (or no VMM): give the partial chunk back and stop scanning
+            for (auto h : c.hs) (void)hipMemRelease(h);
+            api_ok = !chunks.empty();
+            break;
+        }
+        created += kChunkBytes;
+        bool ok = true;
+        for (size_t h = 0; h < per_chunk && ok; ++h) ok = hipMemMap(scratch + h * kHandleBytes, kHandleBytes, 0, c.hs[h], 0) == hipSuccess;
+        ok = ok && hipMemSetAccess(scratch, kChunkBytes, &acc, 1) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); (void)hipMemUnmap(scratch, kChunkBytes); for (auto h : c.hs) (void)hipMemRelease(h); api_ok = !chunks.empty(); break; }
+        c.write_ms = probe_ms(nullptr, scratch, kChunkBytes, 3);
+        if (chunks.empty()) info.first_copy_ms = probe_ms(in, scratch, bytes < kChunkBytes ? bytes : kChunkBytes, 3);   // copy into the first (almost surely ordinary) chunk
+        (void)hipMemUnmap(scratch, kChunkBytes);
+        chunks.push_back(std::move(c));
+    }
+    (void)hipMemAddressFree(scratch, kChunkBytes);
+    if (!api_ok || chunks.empty()) {
+        for (auto& c : chunks) for (auto h : c.hs) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(out, need * kHandleBytes);
+        return false;
+    }
+    // mixed chunks first (fastest writes first), then the last ordinary chunks scanned
+    const float typ = typical();
+    std::vector<size_t> order;
+    for (size_t i = 0; i < chunks.size(); ++i) if (chunks[i].write_ms < kMixedWriteRatio * typ) order.push_back(i);
+    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return chunks[x].write_ms < chunks[y].write_ms; });
+    const size_t n_mixed = order.size();
+    for (size_t i = chunks.size(); i-- > 0;) if (!(chunks[i].write_ms < kMixedWriteRatio * typ)) order.push_back(i);
+    size_t mapped = 0, mixed_used = 0;
+    bool ok = true;
+    for (size_t k = 0; k < order.size() && ok; ++k) {
+        auto& hs = chunks[order[k]].hs;
+        while (!hs.empty() && mapped < need && ok) {
+            ok = hipMemMap(out + mapped * kHandleBytes, kHandleBytes, 0, hs.back(), 0) == hipSuccess;
+            if (ok) { rec.handles.push_back(hs.back()); hs.pop_back(); ++mapped; if (k < n_mixed) ++mixed_used; }
+        }
+    }
+    for (auto& c : chunks) for (auto h : c.hs) (void)hipMemRelease(h);      // everything that was not used
+    ok = ok && mapped == need && hipMemSetAccess(out, need * kHandleBytes, &acc, 1) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        if (mapped) (void)hipMemUnmap(out, mapped * kHandleBytes);
+        for (auto h : rec.handles) (void)hipMemRelease(h);
+        rec.handles.clear();
+        (void)hipMemAddressFree(out, need * kHandleBytes);
+        return false;
+    }
+    rec.b = out;
+    rec.va_bytes = need * kHandleBytes;
+    rec.searched = true;
+    info.candidates = (int)chunks.size();
+    info.candidate_bytes = created;
+    info.chosen = (int)((mixed_used * kHandleBytes + kChunkBytes - 1) / kChunkBytes);
+    info.good_enough = mixed_used == need ? 1 : 0;
+    return true;
+}
+
+// "candidates" policy: one block from the stream-ordered pool, then ordinary blocks one after the other, each timed as
+// a copy target; ends at the first candidate within kGoodRatio x the input's pure read time, or at the budgets.
+bool pick_candidate_output(size_t bytes, const void* in, const Budget& budget, float read_ms, PairRec& rec, SmfftPairInfo& info) {
+    const size_t window = bytes < kChunkBytes ? bytes : kChunkBytes;
+    struct Cand { void* p; bool pool; float ms; };
+    std::vector<Cand> cands;
+    size_t used = 0;
+    int best = -1;
+    bool good = false;
+    while (!good) {
+        const bool pool = cands.empty() && getenv("SMFFT_NO_POOL_SHORTCUT") == nullptr;
+        if (!cands.empty() && (used + bytes > budget.bytes || budget.elapsed_ms() > budget.ms)) break;
+        void* p = nullptr;
+        hipError_t rc = pool ? hipMallocAsync(&p, bytes, 0) : hipMalloc(&p, bytes);
+        if (rc == hipSuccess && pool) rc = hipStreamSynchronize(0);
+        if (rc != hipSuccess) {
+            (void)hipGetLastError();
+            if (pool) { cands.push_back({nullptr, true, 1e30f}); continue; }   // no pool on this runtime: go on with plain candidates
+            break;
+        }
+        used += bytes;
+        const float ms = probe_ms(in, p, window, 3);
+        cands.push_back({p, pool, ms > 0.f ? ms : 1e30f});
+        if (best < 0 || cands.back().ms < cands[best].ms) best = (int)cands.size() - 1;
+        good = read_ms > 0.f && cands[best].ms <= kGoodRatio * read_ms;
+    }
+    info.candidates = (int)cands.size();
+    info.candidate_bytes = used;
+    if (best < 0 || !cands[best].p) return false;
+    for (int i = 0; i < (int)cands.size(); ++i)
+        if (i != best) free_buffer(cands[i].p, cands[i].pool);
+    rec.b = cands[best].p;
+    rec.pool_b = cands[best].pool;
+    rec.searched = true;
+    info.first_copy_ms = cands.size() > 1 && cands[1].p ? cands[1].ms : cands[0].ms;
+    info.chosen = best;
+    info.good_enough = good ? 1 : 0;
+    return true;
+}
+
 int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search) {
     *d_a = *d_b = nullptr;
     int device = -1;
     (void)hipGetDevice(&device);
     const char* pol = getenv("SMFFT_PAIR_POLICY");
-    const bool want_search = allow_search && getenv("SMFFT_NO_PAIR_PLACEMENT") == nullptr && !(pol && strcmp(pol, "plain") == 0) && bytes >= (256ull << 20);
+    const bool plain = !allow_search || getenv("SMFFT_NO_PAIR_PLACEMENT") != nullptr || (pol && strcmp(pol, "plain") == 0) || bytes < (256ull << 20);
+    const bool candidates_only = pol && strcmp(pol, "candidates") == 0;
     SmfftPairInfo info = {};
     info.bytes = bytes;
-    if (want_search && getenv("SMFFT_PAIR_CACHE")) {
+    if (!plain && getenv("SMFFT_PAIR_CACHE")) {
         std::lock_guard<std::mutex> lock(g_pairs_mutex);
         if (g_pair_cache.a && g_pair_cache.device == device && g_pair_cache.bytes == bytes) {
             PairRec rec = g_pair_cache;
@@ -180,53 +358,18 @@ int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search) {
     if (hipMalloc(&in, bytes) != hipSuccess) { (void)hipGetLastError(); return 1; }
     PairRec rec;
     rec.a = in; rec.device = device; rec.bytes = bytes;
-    if (want_search) {
-        using clock = std::chrono::steady_clock;
-        const auto t_start = clock::now();
-        auto elapsed_ms = [&] { return std::chrono::duration<double, std::milli>(clock::now() - t_start).count(); };
+    if (!plain) {
+        Budget budget;
         size_t free_mem = 0, total_mem = 0;
         (void)hipMemGetInfo(&free_mem, &total_mem);
-        const double frac = env_double("SMFFT_PAIR_BUDGET_FRAC", 0.25), budget_ms = env_double("SMFFT_PAIR_BUDGET_MS", 2000.0);
-        const size_t byte_budget = (size_t)(frac * (double)free_mem);
-        const size_t window = bytes < (1ull << 30) ? bytes : (1ull << 30);
-        const float read_ms = probe_ms(in, nullptr, window, 3);
-        struct Cand { void* p; bool pool; float ms; };
-        std::vector<Cand> cands;
-        size_t used = 0;
-        int best = -1;
-        bool good = false;
-        while (!good) {
-            const bool pool = cands.empty() && getenv("SMFFT_NO_POOL_SHORTCUT") == nullptr;
-            if (!cands.empty() && (used + bytes > byte_budget || elapsed_ms() > budget_ms)) break;
-            void* p = nullptr;
-            hipError_t rc = pool ? hipMallocAsync(&p, bytes, 0) : hipMalloc(&p, bytes);
-            if (rc == hipSuccess && pool) rc = hipStreamSynchronize(0);
-            if (rc != hipSuccess) {
-                (void)hipGetLastError();
-                if (pool) { cands.push_back({nullptr, true, 1e30f}); continue; }   // no pool on this runtime: go on with plain candidates
-                break;
-            }
-            used += bytes;
-            const float ms = probe_ms(in, p, window, 3);
-            cands.push_back({p, pool, ms > 0.f ? ms : 1e30f});
-            if (best < 0 || cands.back().ms < cands[best].ms) best = (int)cands.size() - 1;
-            good = read_ms > 0.f && cands[best].ms <= kGoodRatio * read_ms;
-        }
-        info.candidates = (int)cands.size();
-        info.candidate_bytes = used;
-        info.read_ms = read_ms;
-        if (best >= 0 && cands[best].p) {
-            for (int i = 0; i < (int)cands.size(); ++i)
-                if (i != best) free_buffer(cands[i].p, cands[i].pool);
-            rec.b = cands[best].p;
-            rec.pool_b = cands[best].pool;
-            rec.searched = true;
-            info.copy_ms = cands[best].ms;
-            info.first_copy_ms = cands.size() > 1 && cands[1].p ? cands[1].ms : cands[0].ms;
-            info.chosen = best;
-            info.good_enough = good ? 1 : 0;
-        }
-        info.search_ms = elapsed_ms();
+        budget.bytes = (size_t)(env_double("SMFFT_PAIR_BUDGET_FRAC", 0.25) * (double)free_mem);
+        budget.ms = env_double("SMFFT_PAIR_BUDGET_MS", 2000.0);
+        const size_t window = bytes < kChunkBytes ? bytes : kChunkBytes;
+        info.read_ms = probe_ms(in, nullptr, window, 3);
+        bool done = !candidates_only && build_mixed_output(bytes, in, device, budget, rec, info);
+        if (!done) done = pick_candidate_output(bytes, in, budget, info.read_ms, rec, info);
+        if (done) info.copy_ms = probe_ms(in, rec.b, window, 3);
+        info.search_ms = budget.elapsed_ms();
     }
     if (!rec.b) {
         if (hipMalloc(&rec.b, bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(in); return 1; }
@@ -258,8 +401,7 @@ int free_pair(void* d_a) {
         }
     }
     int rc = (int)hipFree(rec.a);
-    if (rec.pool_b) { rc |= (int)hipFreeAsync(rec.b, 0); rc |= (int)hipStreamSynchronize(0); }
-    else rc |= (int)hipFree(rec.b);
+    release_output(rec);
     return rc;
 }
 
@@ -272,7 +414,7 @@ int release_pair_cache() {
     }
     if (!rec.a) return 0;
     (void)hipFree(rec.a);
-    free_buffer(rec.b, rec.pool_b);
+    release_output(rec);
     return 0;
 }
 

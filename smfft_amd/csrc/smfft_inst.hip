@@ -50,6 +50,13 @@ int launch_stream_copy(const float2* d_input, float2* d_output, long n_float2, i
     else                   SMFFT_stream_copy<0><<<dim3((unsigned)g), dim3(256), 0, stream>>>(d_input, d_output, ntiles);
     return (int)hipGetLastError();
 }
+int launch_stream_write(float2* d_output, long n_float2, int grid_cap, hipStream_t stream) {
+    long ntiles = n_float2 / 4096;
+    if (ntiles <= 0) return 0;
+    long g = (grid_cap > 0 && ntiles > grid_cap) ? grid_cap : ntiles;
+    SMFFT_stream_write<0><<<dim3((unsigned)g), dim3(256), 0, stream>>>(d_output, ntiles);
+    return (int)hipGetLastError();
+}
 int launch_stream_read(const float2* d_input, long n_float2, int grid_cap, hipStream_t stream) {
     long ntiles = n_float2 / 4096;
     if (ntiles <= 0) return 0;

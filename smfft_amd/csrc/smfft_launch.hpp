@@ -20,7 +20,8 @@ int launch_rc(const float2* d_input, float2* d_output, int count, int inverse, i
 
 // calibration copy of n_float2 elements (multiple of 4096) with the external kernels' access shape
 int launch_stream_copy(const float2* d_input, float2* d_output, long n_float2, int grid_cap, hipStream_t stream);
-// the same access shape, reads only
+// the same access shape, writes only / reads only
+int launch_stream_write(float2* d_output, long n_float2, int grid_cap, hipStream_t stream);
 int launch_stream_read(const float2* d_input, long n_float2, int grid_cap, hipStream_t stream);
 
 inline int grid_for(int count, int ffts_per_block, int grid_cap) {
