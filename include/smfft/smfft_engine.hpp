@@ -175,7 +175,7 @@ __device__ __forceinline__ void lds_read16(float2 (&r)[16], const float2* base) 
     static_assert(8 * STRIDE * 15 < 65536, "DS offset field is 16 bits");
     typedef __attribute__((address_space(3))) const float2 lds_float2;
     const unsigned a = (unsigned)(unsigned long)(lds_float2*)base;
-    v2f v[16];
+    unsigned long long v[16];   // 64-bit integers, not <2 x float>: vector-typed results invite v_pk_add_f32 (half rate) downstream
     asm volatile(
         "ds_read_b64 %0, %16 offset:%17\n\tds_read_b64 %1, %16 offset:%18\n\tds_read_b64 %2, %16 offset:%19\n\tds_read_b64 %3, %16 offset:%20\n\t"
         "ds_read_b64 %4, %16 offset:%21\n\tds_read_b64 %5, %16 offset:%22\n\tds_read_b64 %6, %16 offset:%23\n\tds_read_b64 %7, %16 offset:%24\n\t"
@@ -188,7 +188,7 @@ __device__ __forceinline__ void lds_read16(float2 (&r)[16], const float2* base) 
           "n"(64 * STRIDE), "n"(72 * STRIDE), "n"(80 * STRIDE), "n"(88 * STRIDE), "n"(96 * STRIDE), "n"(104 * STRIDE), "n"(112 * STRIDE), "n"(120 * STRIDE)
         : "memory");
 #pragma unroll
-    for (int i = 0; i < 16; ++i) r[i] = make_float2(v[i].x, v[i].y);
+    for (int i = 0; i < 16; ++i) r[i] = make_float2(__uint_as_float((unsigned)v[i]), __uint_as_float((unsigned)(v[i] >> 32)));
   } else {
 #pragma unroll
     for (int i = 0; i < 16; ++i) r[i] = base[STRIDE * i];
@@ -406,7 +406,7 @@ struct Engine {
         } else {
             typedef __attribute__((address_space(3))) const float2 lds_float2;
             const unsigned a = (unsigned)(unsigned long)(lds_float2*)row;
-            v2f v[16];
+            unsigned long long v[16];   // see lds_read16
             asm volatile(
                 "ds_read_b64 %0, %16 offset:%17\n\tds_read_b64 %1, %16 offset:%18\n\tds_read_b64 %2, %16 offset:%19\n\tds_read_b64 %3, %16 offset:%20\n\t"
                 "ds_read_b64 %4, %16 offset:%21\n\tds_read_b64 %5, %16 offset:%22\n\tds_read_b64 %6, %16 offset:%23\n\tds_read_b64 %7, %16 offset:%24\n\t"
@@ -421,7 +421,7 @@ struct Engine {
                   "n"(8 * slot_source(15))
                 : "memory");
 #pragma unroll
-            for (int i = 0; i < 16; ++i) r[i] = make_float2(v[i].x, v[i].y);
+            for (int i = 0; i < 16; ++i) r[i] = make_float2(__uint_as_float((unsigned)v[i]), __uint_as_float((unsigned)(v[i] >> 32)));
         }
     }
     // pass-1 slot i = b*R1 + r1 takes element rev_B1(b)*R1 + rev_R1(r1) of the thread's row
