@@ -321,7 +321,7 @@ struct Engine {
 #pragma unroll
         for (int c = 0; c < 16; ++c) r[c] = gload(g + u + T * c);
     }
-    __device__ __forceinline__ void load_lds(float2 (&r)[16], const float2* sf) const { lds_read16<T, false>(r, sf + u); }
+    __device__ __forceinline__ void load_lds(float2 (&r)[16], const float2* sf) const { lds_read16<T, (N == 128 || N == 256)>(r, sf + u); }   // single reads measured +4-7 % at the two-pass lengths (profiles/r02_ab_reads.txt)
 
     // ---- natural registers -> pass-1 slots r[b*R1 + r1] = x'[t1 + T1*r1], t1 = u + T*b ------------
     // REORDER: x' = x, and t1 + T1*r1 = u + T*(b + B1*r1): a compile-time renaming of registers.

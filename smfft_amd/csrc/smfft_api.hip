@@ -110,8 +110,8 @@ int timed(F&& launch, double* FFT_time) {
 //    Same request counts in every case (TCC_EA0_RDREQ / WRREQ = the algorithmic bytes): what differs is DRAM service time.
 //  * None of it shows in virtual addresses, but the pure write rate of a physical GiB tells mixed from ordinary at once.
 // smfft_malloc_pair ("mixed" policy, the default) therefore takes the input from hipMalloc and BUILDS the output with
-// the virtual-memory API: physical memory is created in 8 MiB handles, 1 GiB at a time; each GiB is mapped into a
-// scratch range, timed with one write-only pass (0.2 ms), and kept for the output if it is mixed; the scan ends when
+// the virtual-memory API: physical memory is created in 8 MiB handles, 1 GiB at a time; each GiB is mapped at a slot
+// of its own, timed with one write-only pass (0.2 ms), and kept for the output if it is mixed; the scan ends when
 // the output is complete, or at the byte budget (default: a quarter of the free memory) or the time budget (default
 // 2 s), whatever is missing then coming from the last ordinary chunks scanned (the farthest from the input).  The
 // chosen handles are mapped back to back into one virtual range -- the caller sees an ordinary device pointer -- and
@@ -176,13 +176,37 @@ void free_buffer(void* p, bool pool) {
     else (void)hipFree(p);
 }
 
+// Virtual ranges for the VMM-backed outputs come from an arena that is never recycled.  Measured on ROCm 7.2 / MI355X
+// (tools/microbench/placement_study.hip vmm7, profiles/r02_vmm_remap_check.txt): after hipMemUnmap, a hipMemMap of ANOTHER
+// handle at the same virtual address leaves the GPU translating to the OLD physical memory (the second fill of the test
+// lands in the first handle).  So a virtual address is used for one mapping only, ever: every scanned chunk gets its own
+// slot, every output its own range, and freed ranges are not handed out again.
+std::mutex g_arena_mutex;
+char* g_arena = nullptr;
+size_t g_arena_size = 0, g_arena_used = 0;
+char* arena_take(size_t bytes) {
+    const size_t align = 1ull << 30;
+    bytes = (bytes + align - 1) / align * align;
+    std::lock_guard<std::mutex> lock(g_arena_mutex);
+    if (!g_arena || g_arena_used + bytes > g_arena_size) {
+        const size_t want = std::max<size_t>(1ull << 40, 2 * bytes);     // 1 TiB of address space per arena (the GPU VM has 256 TiB)
+        char* p = nullptr;
+        if (hipMemAddressReserve((void**)&p, want, align, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        g_arena = p;
+        g_arena_size = want;
+        g_arena_used = 0;
+    }
+    char* r = g_arena + g_arena_used;
+    g_arena_used += bytes;
+    return r;
+}
+
 void release_output(PairRec& rec) {
     if (!rec.b) return;
     if (rec.va_bytes) {
         (void)hipMemUnmap(rec.b, rec.va_bytes);
         for (auto h : rec.handles) (void)hipMemRelease(h);
-        (void)hipMemAddressFree(rec.b, rec.va_bytes);
-        rec.handles.clear();
+        rec.handles.clear();               // the virtual range is retired with the mapping (see arena_take)
         rec.va_bytes = 0;
     } else {
         free_buffer(rec.b, rec.pool_b);
@@ -210,9 +234,8 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
     const size_t need = (bytes + kHandleBytes - 1) / kHandleBytes, per_chunk = kChunkBytes / kHandleBytes;
-    char *out = nullptr, *scratch = nullptr;
-    if (hipMemAddressReserve((void**)&out, need * kHandleBytes, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (hipMemAddressReserve((void**)&scratch, kChunkBytes, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemAddressFree(out, need * kHandleBytes); return false; }
+    char* out = arena_take(need * kHandleBytes);
+    if (!out) return false;
     struct Chunk { std::vector<hipMemGenericAllocationHandle_t> hs; float write_ms; };
     std::vector<Chunk> chunks;
     size_t created = 0;
@@ -243,19 +266,23 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
             break;
         }
         created += kChunkBytes;
-        bool ok = true;
+        char* scratch = arena_take(kChunkBytes);      // a slot of its own: virtual addresses are never re-used (see arena_take)
+        bool ok = scratch != nullptr;
         for (size_t h = 0; h < per_chunk && ok; ++h) ok = hipMemMap(scratch + h * kHandleBytes, kHandleBytes, 0, c.hs[h], 0) == hipSuccess;
         ok = ok && hipMemSetAccess(scratch, kChunkBytes, &acc, 1) == hipSuccess;
-        if (!ok) { (void)hipGetLastError(); (void)hipMemUnmap(scratch, kChunkBytes); for (auto h : c.hs) (void)hipMemRelease(h); api_ok = !chunks.empty(); break; }
+        if (!ok) { (void)hipGetLastError(); if (scratch) (void)hipMemUnmap(scratch, kChunkBytes); for (auto h : c.hs) (void)hipMemRelease(h); api_ok = !chunks.empty(); break; }
         c.write_ms = probe_ms(nullptr, scratch, kChunkBytes, 3);
         if (chunks.empty()) info.first_copy_ms = probe_ms(in, scratch, bytes < kChunkBytes ? bytes : kChunkBytes, 3);   // copy into the first (almost surely ordinary) chunk
         (void)hipMemUnmap(scratch, kChunkBytes);
         chunks.push_back(std::move(c));
     }
-    (void)hipMemAddressFree(scratch, kChunkBytes);
+    if (getenv("SMFFT_PAIR_DEBUG")) {
+        printf("smfft_malloc_pair scan: %zu chunks, write ms per GiB:", chunks.size());
+        for (auto& c : chunks) printf(" %.3f", c.write_ms);
+        printf("\n");
+    }
     if (!api_ok || chunks.empty()) {
         for (auto& c : chunks) for (auto h : c.hs) (void)hipMemRelease(h);
-        (void)hipMemAddressFree(out, need * kHandleBytes);
         return false;
     }
     // mixed chunks first (fastest writes first), then the last ordinary chunks scanned
@@ -281,7 +308,6 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
         if (mapped) (void)hipMemUnmap(out, mapped * kHandleBytes);
         for (auto h : rec.handles) (void)hipMemRelease(h);
         rec.handles.clear();
-        (void)hipMemAddressFree(out, need * kHandleBytes);
         return false;
     }
     rec.b = out;

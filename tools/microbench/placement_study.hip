@@ -24,9 +24,14 @@
 //       chunks classified as in `map`, then 4 GiB test buffers ASSEMBLED from chunks of chosen classes -- whole, or
 //       interleaved handle by handle -- and timed as copy targets: does an output interleaved over the classes
 //       reproduce the "fast write region"?
+//   placement_study vmm7
+//       remap check: after hipMemUnmap, does hipMemMap of ANOTHER handle at the same virtual address take effect?
+//       (ROCm 7.2 / MI355X: no -- the GPU keeps translating to the first handle; profiles/r02_vmm_remap_check.txt.  Every
+//       mode of this tool, and the library's allocator, therefore use a virtual address for ONE mapping only.)
 // Build: hipcc -O3 --offload-arch=gfx950 placement_study.hip -o placement_study
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <cmath>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -249,6 +254,59 @@ static int vmm_mode(size_t handle_mib, size_t max_gib) {
     return 0;
 }
 
+// vmm7: does re-using a virtual range for ANOTHER handle (hipMemUnmap, then hipMemMap) really redirect the accesses?
+// X and Y are two physical 8 MiB handles.  X mapped at S, filled with 1.0; unmapped; Y mapped at S, filled with 2.0;
+// then X and Y are mapped at two FRESH ranges and read back.  Correct: X holds 1.0, Y holds 2.0.
+__global__ void fill_kernel(float* p, float v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+static int vmm7_mode() {
+    const size_t H = 8ull << 20;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    hipMemGenericAllocationHandle_t X, Y;
+    CK(hipMemCreate(&X, H, &prop, 0));
+    CK(hipMemCreate(&Y, H, &prop, 0));
+    char *S = nullptr, *FX = nullptr, *FY = nullptr;
+    CK(hipMemAddressReserve((void**)&S, H, 0, nullptr, 0));
+    CK(hipMemAddressReserve((void**)&FX, H, 0, nullptr, 0));
+    CK(hipMemAddressReserve((void**)&FY, H, 0, nullptr, 0));
+    const size_t n = H / 4;
+    for (int variant = 0; variant < 2; ++variant) {
+        CK(hipMemMap(S, H, 0, X, 0));
+        CK(hipMemSetAccess(S, H, &acc, 1));
+        fill_kernel<<<1024, 256>>>((float*)S, 1.0f, n);
+        CK(hipDeviceSynchronize());
+        CK(hipMemUnmap(S, H));
+        if (variant == 1) CK(hipDeviceSynchronize());
+        CK(hipMemMap(S, H, 0, Y, 0));
+        CK(hipMemSetAccess(S, H, &acc, 1));
+        fill_kernel<<<1024, 256>>>((float*)S, 2.0f, n);
+        CK(hipDeviceSynchronize());
+        CK(hipMemUnmap(S, H));
+        CK(hipMemMap(FX, H, 0, X, 0));
+        CK(hipMemSetAccess(FX, H, &acc, 1));
+        CK(hipMemMap(FY, H, 0, Y, 0));
+        CK(hipMemSetAccess(FY, H, &acc, 1));
+        float hx[4], hy[4];
+        CK(hipMemcpy(hx, FX + H / 2, sizeof hx, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hy, FY + H / 2, sizeof hy, hipMemcpyDeviceToHost));
+        printf("variant %d: X holds %.1f (expected 1.0), Y holds %.1f (expected 2.0)  -> %s\n", variant, hx[0], hy[0],
+               (hx[0] == 1.0f && hy[0] == 2.0f) ? "remapping works" : "STALE TRANSLATION: the second fill went to the first handle");
+        fill_kernel<<<1024, 256>>>((float*)FX, 0.0f, n);
+        fill_kernel<<<1024, 256>>>((float*)FY, 0.0f, n);
+        CK(hipDeviceSynchronize());
+        CK(hipMemUnmap(FX, H));
+        CK(hipMemUnmap(FY, H));
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "map";
     const size_t chunk_gib = argc > 2 ? atol(argv[2]) : 4;
@@ -259,6 +317,7 @@ int main(int argc, char** argv) {
     CK(hipSetDevice(0));
     CK(hipEventCreate(&g_e0));
     CK(hipEventCreate(&g_e1));
+    if (mode == "vmm7") return vmm7_mode();
     if (mode == "vmm") return vmm_mode(argc > 2 ? atol(argv[2]) : 8, argc > 3 ? atol(argv[3]) : 140);
     size_t free_b = 0, total_b = 0;
     CK(hipMemGetInfo(&free_b, &total_b));
