@@ -240,11 +240,16 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
     std::vector<Chunk> chunks;
     size_t created = 0;
     bool api_ok = true;
-    auto typical = [&] {                 // the median write time: six chunks in seven are ordinary
+    // the reference a chunk's write pass is judged against: the median chunk (six chunks in seven are ordinary), but not
+    // less than the write pass over the input buffer itself (an ordinary hipMalloc block), so that a run of mixed chunks
+    // at the start of the scan is recognised as such
+    const float in_write_ms = probe_ms(nullptr, const_cast<void*>(in), bytes < kChunkBytes ? bytes : kChunkBytes, 3) * (float)((double)kChunkBytes / (double)(bytes < kChunkBytes ? bytes : kChunkBytes));
+    auto typical = [&] {
         std::vector<float> t;
         for (auto& c : chunks) t.push_back(c.write_ms);
         std::sort(t.begin(), t.end());
-        return t.size() < 3 ? t.back() : t[t.size() / 2];
+        const float med = t.size() < 3 ? t.back() : t[t.size() / 2];
+        return med > in_write_ms ? med : in_write_ms;
     };
     auto mixed_handles = [&] {
         const float typ = typical();
@@ -253,7 +258,8 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
         return n;
     };
     while (true) {
-        if (!chunks.empty() && (mixed_handles() >= need || created + kChunkBytes > budget.bytes || budget.elapsed_ms() > budget.ms)) break;
+        // two mixed GiB more than needed (when the budgets allow): the output then takes the fastest of them
+        if (!chunks.empty() && (mixed_handles() >= need + 2 * per_chunk || created + kChunkBytes > budget.bytes || budget.elapsed_ms() > budget.ms)) break;
         Chunk c;
         for (size_t h = 0; h < per_chunk; ++h) {
             hipMemGenericAllocationHandle_t handle;

@@ -149,6 +149,10 @@ __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_i
     constexpr bool kPacedReads = SMFFT_EXTRA_TRIP && !REORDER && !G::kRegTwoPass && kStaged;
     // direct-I/O lengths: the bare throttle instead of the trip (see vmem_throttle)
     constexpr int kThrottle = (!SMFFT_EXTRA_TRIP || kStaged || N == 1024 || N == 4096 || kPacedReads) ? 0 : (N == 2048 ? 6 : 8);
+#ifndef SMFFT_PACING_FORM
+#define SMFFT_PACING_FORM 0
+#endif
+    constexpr int kStagedThrottle = (SMFFT_PACING_FORM == 1 && SMFFT_EXTRA_TRIP && kStaged) ? 16 : 0;   // A/B: the throttle in place of the trip / the volatile read-back
     constexpr int kFftsPerWave = (N <= 1024) ? 1024 / N : 1;
     Engine<N, DIR, REORDER> eng;
     eng.init(threadIdx.x);
@@ -166,8 +170,13 @@ __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_i
             fft_sync<false>();
             eng.load_lds(r, sf);
             fft_sync<false>();
-            if constexpr (kExtraTrip) lds_round_trip<N>(r, sf, eng.u);
-            eng.template transform<kPacedReads>(r, sf);
+            if constexpr (kStagedThrottle > 0) {
+                vmem_throttle<kStagedThrottle>(swave, r);
+                eng.transform(r, sf);
+            } else {
+                if constexpr (kExtraTrip) lds_round_trip<N>(r, sf, eng.u);
+                eng.template transform<kPacedReads>(r, sf);
+            }
             fft_sync<false>();
             eng.store_lds(r, sf);
             fft_sync<false>();

@@ -491,10 +491,10 @@ def test_malloc_pair_bounded_search(sm, monkeypatch):
     assert info["candidate_bytes"] <= 0.25 * free0 + (1 << 30)              # the byte budget (a quarter of the free memory) + one chunk
     assert info["search_ms"] <= 2000 + 1500 and took < 6.0, (info, took)   # the time budget (+ the last chunk's creation)
     assert info["copy_ms"] <= info["first_copy_ms"] * 1.03                  # never worse than the first chunk seen
-    assert free0 - _free_bytes(sm) <= 2 * nbytes + (64 << 20)               # only the pair is still allocated
+    assert _settled_usage(sm, free0, 2 * nbytes + (256 << 20)) <= 2 * nbytes + (256 << 20)   # only the pair (+ page tables) is still allocated
     print("smfft_malloc_pair:", info)
     assert sm.lib.smfft_free_pair(a.value) == 0
-    assert free0 - _free_bytes(sm) <= (64 << 20)                             # nothing cached by default
+    assert _settled_usage(sm, free0, 256 << 20) <= (256 << 20)               # nothing cached by default
     assert sm.lib.smfft_free_pair(a.value) != 0                              # unknown pointer: an error, nothing freed twice
     # a zero budget: exactly one chunk is scanned; the round-1 style candidates policy: the pool block + one block at most
     monkeypatch.setenv("SMFFT_PAIR_BUDGET_FRAC", "0.0")
@@ -504,7 +504,7 @@ def test_malloc_pair_bounded_search(sm, monkeypatch):
         assert 1 <= sm.last_pair_info()["candidates"] <= limit
         use(a, b)
         assert sm.lib.smfft_free_pair(a.value) == 0
-        assert free0 - _free_bytes(sm) <= (64 << 20)
+        assert _settled_usage(sm, free0, 256 << 20) <= (256 << 20)
     monkeypatch.delenv("SMFFT_PAIR_BUDGET_FRAC")
     monkeypatch.delenv("SMFFT_PAIR_POLICY")
     # an odd size (not a multiple of the 8 MiB handles): the whole range is usable up to the last byte
@@ -524,12 +524,24 @@ def test_malloc_pair_bounded_search(sm, monkeypatch):
     assert sm.lib.smfft_free_pair(a.value) == 0
     assert sm.lib.smfft_pair_cache_release() == 0
     assert sm.lib.smfft_pair_cache_release() == 0   # idempotent
-    assert free0 - _free_bytes(sm) <= (64 << 20)
+    assert _settled_usage(sm, free0, 256 << 20) <= (256 << 20)
 
 
 def _free_bytes(sm):
     import torch
     return torch.cuda.mem_get_info()[0]
+
+
+def _settled_usage(sm, free0, limit):
+    """bytes in use relative to free0 once the driver has caught up (released VRAM is returned asynchronously)"""
+    import time
+    used = free0 - _free_bytes(sm)
+    for _ in range(20):
+        if used <= limit:
+            break
+        time.sleep(0.1)
+        used = free0 - _free_bytes(sm)
+    return used
 
 
 def test_malloc_pair_plain_policy_and_many_pairs(sm, monkeypatch):
