@@ -149,14 +149,6 @@ __device__ __forceinline__ void fft_sync() {
     }
 }
 
-// One ds_read_b64 that the compiler cannot pair with a neighbour into ds_read2_b64: the element index passes
-// through an empty asm, so every read has its own address register.  (A `volatile` access would do the same but
-// is compiled to a FLAT load followed by s_waitcnt vmcnt(0): sixteen fully serialised round trips.)
-__device__ __forceinline__ float2 lds_read_single(const float2* region, int index) {
-    asm volatile("" : "+v"(index));
-    return region[index];
-}
-
 // Sixteen reads base[STRIDE * i].  SINGLE = false: plain C++, which hipcc merges pairwise into ds_read2_b64 -- half
 // the instructions, and measured faster wherever the merged accesses are conflict free (the natural-order loads and the
 // t-major last layout: N = 32, 64, 512, 1024 in-LDS path 10-20 % faster than single reads, profiles/r02_ab_mult.txt).
@@ -331,11 +323,6 @@ struct Engine {
     // elements (position p at p + p/16), which makes both the write (consecutive lanes ->
     // consecutive p) and the read (lane -> its own row of 17) bank-conflict free.
     // Precondition: the region is free (earlier accesses ordered by fft_sync).
-    // PACED (external no-reorder kernel of N = 128 only): the read-back uses volatile generic-pointer loads, which the
-    // compiler turns into sixteen FLAT loads each followed by s_waitcnt vmcnt(0).  Slower as LDS code, but on the
-    // HBM-bound kernels this write + serialised flat read-back is exactly the "LDS trip" that raises the streaming
-    // rate by 3-8 % (smfft_kernels.hpp, lds_round_trip), so the transposition doubles as that trip.
-    template <bool PACED = false>
     __device__ __forceinline__ void to_pass1_layout(float2 (&r)[16], float2* sf) const {
         if constexpr (REORDER) {
             if constexpr (B1 > 1) {
@@ -368,7 +355,7 @@ struct Engine {
         } else {
             bitrev_write(r, sf);
             fft_sync<G::kMultiWave>();
-            bitrev_read<PACED>(r, sf);
+            bitrev_read(r, sf);
             fft_sync<G::kMultiWave>();
         }
     }
@@ -390,20 +377,11 @@ struct Engine {
     // is served in 16-lane groups over 32 banks -- half the rate of ds_read_b64 (MI355X_MICROARCH.md, LDS table) and,
     // here, with the rows of bit-reversed neighbours colliding (measured 0.14 conflict cycles per LDS cycle in round 1).
     // The compiler does not count inline-assembly DS operations, so the block ends with its own s_waitcnt.
-    // PACED: volatile generic-pointer loads instead (flat_load + s_waitcnt vmcnt(0) each): the "LDS trip" of the
-    // external N = 128 no-reorder kernel, smfft_kernels.hpp.
-    template <bool PACED = false>
     __device__ __forceinline__ void bitrev_read(float2 (&r)[16], const float2* sf) const {
         constexpr int PS = G::kPadShift;
         const int g16 = 16 * (int)(__brev((unsigned)t1) >> (32 - T_BITS));
         const float2* row = sf + g16 + (g16 >> PS);
-        if constexpr (PACED) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const v2f t = *reinterpret_cast<const volatile v2f*>(&row[slot_source(i)]);
-                r[i] = make_float2(t.x, t.y);
-            }
-        } else {
+        {
             typedef __attribute__((address_space(3))) const float2 lds_float2;
             const unsigned a = (unsigned)(unsigned long)(lds_float2*)row;
             unsigned long long v[16];   // see lds_read16
@@ -610,9 +588,8 @@ struct Engine {
     // registers (natural order, r[c] = x[u + T*c]) -> registers (r[q] = X[u + T*q]) through the
     // FFT's LDS region.
     // Precondition: every earlier LDS access of this FFT's region has been ordered by fft_sync.
-    template <bool PACED = false>
     __device__ __forceinline__ void transform(float2 (&r)[16], float2* sf) const {
-        to_pass1_layout<PACED>(r, sf);
+        to_pass1_layout(r, sf);
         transform_from_pass1_slots(r, sf);
     }
     // the transform of registers that already hold the pass-1 slots (after to_pass1_layout or bitrev_read)

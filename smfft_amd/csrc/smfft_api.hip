@@ -42,34 +42,39 @@ int ct_multiple_slots(int FFT_size, int nFFTs) {
     return nFFTs / SMFFT_NREUSES;
 }
 
+// 1: the external kernels run their rate limiter for this output buffer (defined below, next to the pair table)
+int pacing_for(const void* d_output);
+
 using smfft::launch_ct;
 using smfft::launch_rc;
 using smfft::launch_st;
 
 // returns -1 for an unsupported length (nothing launched), else the launch status
 int dispatch_ct(const float2* in, float2* out, int N, int count, int inverse, int reorder, int path, hipStream_t st) {
+    const int pace = pacing_for(out);
     switch (N) {
-        case 32:   return launch_ct<32>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, st);
-        case 64:   return launch_ct<64>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, st);
-        case 128:  return launch_ct<128>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, st);
-        case 256:  return launch_ct<256>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, st);
-        case 512:  return launch_ct<512>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, st);
-        case 1024: return launch_ct<1024>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, st);
-        case 2048: return launch_ct<2048>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, st);
-        case 4096: return launch_ct<4096>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, st);
+        case 32:   return launch_ct<32>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, pace, st);
+        case 64:   return launch_ct<64>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, pace, st);
+        case 128:  return launch_ct<128>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, pace, st);
+        case 256:  return launch_ct<256>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, pace, st);
+        case 512:  return launch_ct<512>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, pace, st);
+        case 1024: return launch_ct<1024>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, pace, st);
+        case 2048: return launch_ct<2048>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, pace, st);
+        case 4096: return launch_ct<4096>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, pace, st);
         default:   return -1;
     }
 }
 int dispatch_st(const float2* in, float2* out, int N, int count, int path, hipStream_t st) {
+    const int pace = pacing_for(out);
     switch (N) {
-        case 32:   return launch_st<32>(in, out, count, path, g_grid_cap, g_nreuses, st);
-        case 64:   return launch_st<64>(in, out, count, path, g_grid_cap, g_nreuses, st);
-        case 128:  return launch_st<128>(in, out, count, path, g_grid_cap, g_nreuses, st);
-        case 256:  return launch_st<256>(in, out, count, path, g_grid_cap, g_nreuses, st);
-        case 512:  return launch_st<512>(in, out, count, path, g_grid_cap, g_nreuses, st);
-        case 1024: return launch_st<1024>(in, out, count, path, g_grid_cap, g_nreuses, st);
-        case 2048: return launch_st<2048>(in, out, count, path, g_grid_cap, g_nreuses, st);
-        case 4096: return launch_st<4096>(in, out, count, path, g_grid_cap, g_nreuses, st);
+        case 32:   return launch_st<32>(in, out, count, path, g_grid_cap, g_nreuses, pace, st);
+        case 64:   return launch_st<64>(in, out, count, path, g_grid_cap, g_nreuses, pace, st);
+        case 128:  return launch_st<128>(in, out, count, path, g_grid_cap, g_nreuses, pace, st);
+        case 256:  return launch_st<256>(in, out, count, path, g_grid_cap, g_nreuses, pace, st);
+        case 512:  return launch_st<512>(in, out, count, path, g_grid_cap, g_nreuses, pace, st);
+        case 1024: return launch_st<1024>(in, out, count, path, g_grid_cap, g_nreuses, pace, st);
+        case 2048: return launch_st<2048>(in, out, count, path, g_grid_cap, g_nreuses, pace, st);
+        case 4096: return launch_st<4096>(in, out, count, path, g_grid_cap, g_nreuses, pace, st);
         default:   return -1;
     }
 }
@@ -131,11 +136,26 @@ struct PairRec {
     bool searched = false;
     std::vector<hipMemGenericAllocationHandle_t> handles;   // b is a virtual range backed by these (mixed policy)
     size_t va_bytes = 0;
+    bool mixed = false;       // at least half of b is mixed memory
 };
 std::map<void*, PairRec> g_pairs;      // keyed by the read buffer; grows as needed
 PairRec g_pair_cache;                  // SMFFT_PAIR_CACHE=1 only: the last searched pair that was released
 std::mutex g_pairs_mutex;              // shared by the per-GPU host threads of a multi-GPU driver
 SmfftPairInfo g_last_pair_info = {};
+
+// Pacing per launch (smfft_kernels.hpp, vmem_throttle): on when the kernel writes into ordinary memory, off when the
+// output is one of the mixed buffers smfft_malloc_pair built (the paced kernels are 1-2.5 % faster into the former and
+// 1-3.5 % slower into the latter, profiles/r02_ab_pacing_*.txt).  SMFFT_PACING=0 / 1 forces it.
+int pacing_for(const void* d_output) {
+    static const int forced = [] { const char* e = getenv("SMFFT_PACING"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+    if (forced >= 0) return forced;
+    std::lock_guard<std::mutex> lock(g_pairs_mutex);
+    for (auto& kv : g_pairs) {
+        const PairRec& r = kv.second;
+        if (r.va_bytes && (const char*)d_output >= (const char*)r.b && (const char*)d_output < (const char*)r.b + r.va_bytes) return r.mixed ? 0 : 1;
+    }
+    return 1;
+}
 
 constexpr double kGoodRatio = 2.30;    // candidates policy: mixed targets copy in 2.2-2.3 x the pure read time; other class 2.5; same class 2.6
 constexpr float kMixedWriteRatio = 0.91f;   // mixed policy: a chunk is mixed if its write pass takes < 0.91 x the typical one (mixed: 0.79-0.88)
@@ -149,7 +169,7 @@ float probe_ms(const void* in, void* out, size_t bytes, int launches) {
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 0.f;
     auto launch = [&] {
-        if (in && out) return smfft::launch_stream_copy((const float2*)in, (float2*)out, n, 12288, 0);
+        if (in && out) return smfft::launch_stream_copy((const float2*)in, (float2*)out, n, 12288, 0, 0);
         if (in) return smfft::launch_stream_read((const float2*)in, n, 12288, 0);
         return smfft::launch_stream_write((float2*)out, n, 12288, 0);
     };
@@ -238,7 +258,7 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
     if (!out) return false;
     struct Chunk { std::vector<hipMemGenericAllocationHandle_t> hs; float write_ms; };
     std::vector<Chunk> chunks;
-    size_t created = 0;
+    size_t created = 0, extra_after_enough = 0;
     bool api_ok = true;
     // the reference a chunk's write pass is judged against: the median chunk (six chunks in seven are ordinary), but not
     // less than the write pass over the input buffer itself (an ordinary hipMalloc block), so that a run of mixed chunks
@@ -258,8 +278,12 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
         return n;
     };
     while (true) {
-        // two mixed GiB more than needed (when the budgets allow): the output then takes the fastest of them
-        if (!chunks.empty() && (mixed_handles() >= need + 2 * per_chunk || created + kChunkBytes > budget.bytes || budget.elapsed_ms() > budget.ms)) break;
+        // once the output is covered, at most four more chunks are scanned for up to two spare mixed GiB (the output
+        // then takes the fastest ones); otherwise the scan runs to its budgets
+        const size_t have = chunks.empty() ? 0 : mixed_handles();
+        if (have >= need && extra_after_enough == 0) extra_after_enough = chunks.size() + 4;
+        if (!chunks.empty() && (have >= need + 2 * per_chunk || (extra_after_enough && chunks.size() >= extra_after_enough)
+                                || created + kChunkBytes > budget.bytes || budget.elapsed_ms() > budget.ms)) break;
         Chunk c;
         for (size_t h = 0; h < per_chunk; ++h) {
             hipMemGenericAllocationHandle_t handle;
@@ -319,6 +343,7 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
     rec.b = out;
     rec.va_bytes = need * kHandleBytes;
     rec.searched = true;
+    rec.mixed = 2 * mixed_used >= need;
     info.candidates = (int)chunks.size();
     info.candidate_bytes = created;
     info.chosen = (int)((mixed_used * kHandleBytes + kChunkBytes - 1) / kChunkBytes);
@@ -531,7 +556,7 @@ int smfft_launch(int family, int path, const void* d_input, void* d_output, int 
 
 int smfft_copy_launch(const void* d_input, void* d_output, long long n_float2, void* hip_stream) {
     read_env();
-    return smfft::launch_stream_copy((const float2*)d_input, (float2*)d_output, (long)n_float2, g_grid_cap, (hipStream_t)hip_stream);
+    return smfft::launch_stream_copy((const float2*)d_input, (float2*)d_output, (long)n_float2, g_grid_cap, pacing_for(d_output), (hipStream_t)hip_stream);
 }
 
 // ---- L3 wrappers ---------------------------------------------------------------------------------

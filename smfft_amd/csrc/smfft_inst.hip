@@ -15,7 +15,7 @@
 namespace smfft {
 
 template <>
-int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, int grid_cap, int nreuses, hipStream_t stream) {
+int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, int grid_cap, int nreuses, int pace, hipStream_t stream) {
     if (count <= 0) return 0;
     dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
     if (path == 0) {
@@ -24,10 +24,10 @@ int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int i
 #else
 #define SMFFT_EXTERNAL_REORDER_KERNEL SMFFT_DIT_external
 #endif
-        if (!inverse && reorder)  SMFFT_EXTERNAL_REORDER_KERNEL<CT_CLASS(_forward)><<<grid, block, 0, stream>>>(d_input, d_output, count);
-        if (!inverse && !reorder) SMFFT_DIT_external<CT_CLASS(_forward_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count);
-        if (inverse && reorder)   SMFFT_EXTERNAL_REORDER_KERNEL<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count);
-        if (inverse && !reorder)  SMFFT_DIT_external<CT_CLASS(_inverse_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count);
+        if (!inverse && reorder)  SMFFT_EXTERNAL_REORDER_KERNEL<CT_CLASS(_forward)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
+        if (!inverse && !reorder) SMFFT_DIT_external<CT_CLASS(_forward_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
+        if (inverse && reorder)   SMFFT_EXTERNAL_REORDER_KERNEL<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
+        if (inverse && !reorder)  SMFFT_DIT_external<CT_CLASS(_inverse_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
     } else {
         // in-LDS path: compact workgroups (one wave per 1024 elements for N <= 1024, one FFT per workgroup above)
         grid = dim3(grid_for(count, Geometry<SMFFT_N>::kCompactFfts, grid_cap));
@@ -41,13 +41,11 @@ int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int i
 }
 
 #if SMFFT_N == 1024
-int launch_stream_copy(const float2* d_input, float2* d_output, long n_float2, int grid_cap, hipStream_t stream) {
+int launch_stream_copy(const float2* d_input, float2* d_output, long n_float2, int grid_cap, int pace, hipStream_t stream) {
     long ntiles = n_float2 / 4096;
     if (ntiles <= 0) return 0;
     long g = (grid_cap > 0 && ntiles > grid_cap) ? grid_cap : ntiles;
-    const char* e = getenv("SMFFT_COPY_TRIPS");   // 1 = with the LDS round trip of lds_round_trip (smfft_kernels.hpp), an A/B switch
-    if (e && atoi(e) == 1) SMFFT_stream_copy<1><<<dim3((unsigned)g), dim3(256), 0, stream>>>(d_input, d_output, ntiles);
-    else                   SMFFT_stream_copy<0><<<dim3((unsigned)g), dim3(256), 0, stream>>>(d_input, d_output, ntiles);
+    SMFFT_stream_copy<0><<<dim3((unsigned)g), dim3(256), 0, stream>>>(d_input, d_output, ntiles, pace);
     return (int)hipGetLastError();
 }
 int launch_stream_write(float2* d_output, long n_float2, int grid_cap, hipStream_t stream) {
@@ -68,14 +66,14 @@ int launch_stream_read(const float2* d_input, long n_float2, int grid_cap, hipSt
 
 #define ST_CLASS SMFFT_PASTE3(FFT_, SMFFT_N, )
 template <>
-int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int path, int grid_cap, int nreuses, hipStream_t stream) {
+int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int path, int grid_cap, int nreuses, int pace, hipStream_t stream) {
     if (count <= 0) return 0;
     dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
 #if SMFFT_N == 4096
     // same transform (Engine<4096, inverse, reorder>) through the occupancy-3 build, see SMFFT_DIT_external_occ3
-    if (path == 0) SMFFT_DIT_external_occ3<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count);
+    if (path == 0) SMFFT_DIT_external_occ3<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
 #else
-    if (path == 0) FFT_GPU_external<ST_CLASS><<<grid, block, 0, stream>>>(d_input, d_output, count);
+    if (path == 0) FFT_GPU_external<ST_CLASS><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
 #endif
     else           FFT_GPU_multiple<ST_CLASS><<<dim3(grid_for(count, Geometry<SMFFT_N>::kCompactFfts, grid_cap)), dim3(Geometry<SMFFT_N>::kCompactThreads), 0, stream>>>(d_input, d_output, count, nreuses);
     return (int)hipGetLastError();

@@ -11,10 +11,9 @@
 // straight from global memory into registers (each wave instruction reads 512 contiguous bytes
 // for N >= 1024) and the last pass stores straight from registers, so the only LDS traffic is the
 // exchanges; N <= 128 (an FFT is at most 8 threads) moves wave-sized chunks through the LDS regions
-// with 512-byte instructions.  Per length, one of three pacing forms sits between a tile's loads
-// and its stores (lds_round_trip, vmem_throttle, Engine::to_pass1_layout<PACED>; DESIGN.md
-// section 5).  Grids are grid-strided over tiles so a capped ("persistent") grid keeps twiddles in
-// registers.
+// with 512-byte instructions.  Between a tile's loads and its stores sits a run-time-switched rate
+// limiter (vmem_throttle below).  Grids are grid-strided over tiles so a capped ("persistent") grid
+// keeps twiddles in registers.
 #pragma once
 #include "smfft/smfft_device_functions.hpp"
 
@@ -81,50 +80,23 @@ __device__ __forceinline__ void lds_to_wave_chunk(float2* __restrict__ gwave, co
     }
 }
 
-// An empirical lever of the HBM-bound external kernels.  Writing the freshly loaded tile
-// to LDS in natural order and reading it back with VOLATILE generic-pointer loads -- which hipcc compiles to
-// sixteen flat_load_dwordx2, each followed by s_waitcnt vmcnt(0) -- before the transform makes the reorder kernels
-// 3-8 % FASTER at every length except 1024 and 4096 (same buffers, interleaved A/B, tools/ab_probe.py:
-// N=32 5.64 -> 6.11 TB/s, 64: 5.63 -> 5.99, 128: 5.60 -> 5.95, 256: 5.63 -> 5.91, 512: 5.67 -> 5.89,
-// 2048: 5.73 -> 5.90; 1024: -0.5 %, 4096: +0.8 %), and it does the same for a plain copy (SMFFT_stream_copy:
-// 5.73 -> 6.11).  What was separated on the copy kernel (tools/microbench/pacing.hip, profiles/r01_pacing.txt):
-// the same trip read back with ordinary ds_read_b64 (SMFFT_TRIP_FORM=1): nothing; serialised flat LDS loads
-// without the preceding writes: nothing; the trip over only K of the 16 registers: K=8 a third of the gain, K=12
-// most, K=16 all; all loads held before the first store, s_sleep of 512 ... 65000 cycles, the LDS allocation alone,
-// a second trip: nothing or worse.  The mechanism is not pinned down, so this is a per-length tuning switch like
-// the grid cap, not a principle.  vmem_throttle below is the isolated ingredient; the N = 128 no-reorder kernel gets
-// the same effect from a volatile read-back of its LDS transposition (Engine::to_pass1_layout<PACED>).
-#ifndef SMFFT_TRIP_FORM
-#define SMFFT_TRIP_FORM 0
-#endif
-#ifndef SMFFT_EXTRA_TRIP
-#define SMFFT_EXTRA_TRIP 1
-#endif
-template <int N>
-__device__ __forceinline__ void lds_round_trip(float2 (&r)[16], float2* sf, int u) {
-    using G = Geometry<N>;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) sf[u + G::T * c] = r[c];
-    fft_sync<G::kMultiWave>();
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-#if SMFFT_TRIP_FORM == 1
-        r[c] = lds_read_single(sf, u + G::T * c);
-#else
-        const v2f t = *reinterpret_cast<const volatile v2f*>(&sf[u + G::T * c]);
-        r[c] = make_float2(t.x, t.y);
-#endif
-    }
-    fft_sync<G::kMultiWave>();
-}
-
-// The ingredient of lds_round_trip that matters, alone: after the tile's global loads have arrived, K serialised
-// FLAT loads of 8 B/lane from the wave's own LDS rows, results discarded -- no LDS writes, the data registers are
-// not touched.  On the copy kernel 16 of them reproduce the whole gain (6.13 TB/s; 12: 5.98, 20: 6.05, 24: 5.94;
-// the same sixteen issued back to back with one wait: 6.0; any s_sleep: none), i.e. what helps is VMEM
-// instructions that occupy the CU's address path between a wave's loads and its stores without going to memory.
-// The FFT kernels, which already spend time between the two, want fewer: K = 8 beats the full trip by 1.3-2 % at
-// N = 256 / 512, K = 6 by 2.3 % at N = 2048 (tools/ab_all.py); N = 1024 and 4096 want none.
+// Pacing of the HBM-bound external kernels: a RATE LIMITER AT THE SOURCE, chosen per launch.
+// After a wave's global loads have arrived, K serialised FLAT loads of 8 B/lane from the wave's own LDS rows (results
+// discarded; no LDS writes, the data registers untouched; each waits for the previous one) occupy the CU's vector-memory
+// address path between the wave's loads and its stores without going to memory.  What the counters say it does
+// (profiles/r02_placement_pmc.json, study_copy vs study_copy_paced, same buffers): L2 -> DRAM credit stalls fall 8-10 x
+// (TCC_EA0_WRREQ_DRAM_CREDIT_STALL 1.8e7 -> 1.7e6, RDREQ 6.1e6 -> 0.8e6 per launch), TCC_TAG_STALL 6 x, the write queue
+// depth (TCC_EA0_WRREQ_LEVEL) 25 %, the L1 -> L2 read / write latencies 15 % / 27 %: the bursts each wave sends are
+// spread out, the queues in front of the DRAM stop overflowing.  Whether that PAYS depends on the write target
+// (profiles/r02_ab_pacing_*.txt): into ordinary memory (a caller's plain hipMalloc buffer: writes 5.6 TB/s at best)
+// the paced kernels are 1-2.5 % faster; into the mixed memory smfft_malloc_pair builds its outputs from (6.9 TB/s)
+// they are 1-3.5 % slower.  So the launcher decides per launch: paced unless the output buffer is one of the library's
+// mixed outputs (SMFFT_PACING=0 / 1 forces it).  K per length as measured in round 1 on ordinary placements (tools/
+// microbench/pacing.hip, profiles/r01_pacing.txt: 16 for a bare copy; the FFT kernels, which already spend time between
+// their loads and stores, want fewer): 16 for the LDS-staged lengths N <= 128, 8 for N = 256 / 512, 6 for N = 2048, none
+// for N = 1024 / 4096 (every K measured equal or worse there).
+// (Round 1 had two more forms that did the same thing through `volatile` generic-pointer reads of LDS -- i.e. through
+//  how hipcc happens to lower them; they measured equal to this explicit one, profiles/r02_ab_pacing_plain.txt, and are gone.)
 template <int K>
 __device__ __forceinline__ void vmem_throttle(const float2* rows, float2 (&r)[16]) {
 #pragma unroll
@@ -136,23 +108,14 @@ __device__ __forceinline__ void vmem_throttle(const float2* rows, float2 (&r)[16
         asm volatile("flat_load_dwordx2 %0, %1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" : "=v"(d) : "v"(q) : "memory");
     }
 }
+template <int N>
+constexpr int throttle_loads() { return N <= SMFFT_STAGED_MAX_N ? 16 : (N == 256 || N == 512) ? 8 : N == 2048 ? 6 : 0; }
+
 template <int N, int DIR, int REORDER>
-__device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nFFTs, float2* s) {
+__device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nFFTs, int pace, float2* s) {
     using G = Geometry<N>;
     constexpr bool kStaged = (N <= SMFFT_STAGED_MAX_N);
-    // see lds_round_trip: on for the reorder kernels of every length except 1024 and 4096
-    // (no-reorder kernels: N = 128 gets the same effect from a volatile read-back of its LDS transposition,
-    //  kPacedReads; where the transposition is done in registers they make the explicit trip; the others throttle)
-    constexpr bool kExtraTrip = SMFFT_EXTRA_TRIP && (REORDER || G::kRegTwoPass) && N != 1024 && N != 4096;   // staged lengths use the full trip
-    // N = 128 only.  (N = 1024 no-reorder: +1 % with it on ordinary placements, -5 % on a smfft_malloc_pair placement,
-    //  where none of the pacing forms matters any more: off.)
-    constexpr bool kPacedReads = SMFFT_EXTRA_TRIP && !REORDER && !G::kRegTwoPass && kStaged;
-    // direct-I/O lengths: the bare throttle instead of the trip (see vmem_throttle)
-    constexpr int kThrottle = (!SMFFT_EXTRA_TRIP || kStaged || N == 1024 || N == 4096 || kPacedReads) ? 0 : (N == 2048 ? 6 : 8);
-#ifndef SMFFT_PACING_FORM
-#define SMFFT_PACING_FORM 0
-#endif
-    constexpr int kStagedThrottle = (SMFFT_PACING_FORM == 1 && SMFFT_EXTRA_TRIP && kStaged) ? 16 : 0;   // A/B: the throttle in place of the trip / the volatile read-back
+    constexpr int kThrottle = throttle_loads<N>();
     constexpr int kFftsPerWave = (N <= 1024) ? 1024 / N : 1;
     Engine<N, DIR, REORDER> eng;
     eng.init(threadIdx.x);
@@ -170,13 +133,8 @@ __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_i
             fft_sync<false>();
             eng.load_lds(r, sf);
             fft_sync<false>();
-            if constexpr (kStagedThrottle > 0) {
-                vmem_throttle<kStagedThrottle>(swave, r);
-                eng.transform(r, sf);
-            } else {
-                if constexpr (kExtraTrip) lds_round_trip<N>(r, sf, eng.u);
-                eng.template transform<kPacedReads>(r, sf);
-            }
+            if constexpr (kThrottle > 0) { if (pace) vmem_throttle<kThrottle>(swave, r); }   // kernel argument: wave-uniform branch
+            eng.transform(r, sf);
             fft_sync<false>();
             eng.store_lds(r, sf);
             fft_sync<false>();
@@ -185,8 +143,8 @@ __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_i
         } else {
             eng.load_global(r, d_input + (active ? f : 0) * N);
             if (G::kMultiWave) __syncthreads();   // the previous tile's exchange reads are complete
-            if constexpr (kThrottle > 0) vmem_throttle<kThrottle>(s + (threadIdx.x >> 6) * 1088, r);
-            eng.template transform<kPacedReads>(r, sf);
+            if constexpr (kThrottle > 0) { if (pace) vmem_throttle<kThrottle>(s + (threadIdx.x >> 6) * 1088, r); }
+            eng.transform(r, sf);
             eng.store_global(r, d_output + f * N, active);
         }
     }
@@ -351,20 +309,26 @@ struct HermitianRegisters {
         return make_float2(__int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(v.x))),
                            __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(v.y))));
     }
-    // In place, two registers (q, 15 - q) at a time, so that only two fetched partner values are alive at once (the
-    // all-at-once form kept sixteen: 139-146 VGPRs, 3 waves per SIMD).  Thread u > 0 pairs register q with register
-    // 15 - q of thread T - u: both fetches of a step are made before either register is overwritten, and all lanes
-    // of a wave make them together.  Thread 0 pairs register q with its OWN register 16 - q: for q that is the
-    // register 15 - (q - 1) the previous step overwrote (its original is carried over in `carried`), for 15 - q it is
-    // register q + 1, still untouched.
+    // In place, two registers (q, 15 - q) at a time, so that only a few fetched partner values are alive at once (the
+    // all-at-once form kept thirty-two: 139-146 VGPRs, 3 waves per SIMD).  Thread u > 0 pairs register q with register
+    // 15 - q of thread T - u: both fetches of a step are made before either register is overwritten, and all lanes of a
+    // wave make them together.  Thread 0 pairs register q with its OWN register 16 - q: for q that is the register
+    // 15 - (q - 1) the previous step overwrote (its original is carried over in `carried`), for 15 - q it is register
+    // q + 1, still untouched.  The steps are software-pipelined: the fetches of step q + 1 are issued before the
+    // arithmetic of step q, so their latency overlaps it, and an empty asm keeps step q + 2 from starting earlier.
+    struct Fetched { float2 lo, hi; };
     template <int Q>
-    __device__ __forceinline__ void apply_pair(float2 (&r)[16], float2& carried) const {
+    __device__ __forceinline__ Fetched fetch(const float2 (&r)[16]) const {
+        return {from_partner(r[15 - Q]), from_partner(r[Q])};   // partner's register 15 - Q -> B of register Q; its register Q -> B of 15 - Q
+    }
+    template <int Q>
+    __device__ __forceinline__ void apply_pair(float2 (&r)[16], float2& carried, Fetched cur) const {
         if constexpr (Q < 8) {
+            Fetched next = cur;
+            if constexpr (Q < 7) next = fetch<Q + 1>(r);
             const float2 a_lo = r[Q], a_hi = r[15 - Q];
-            const float2 p_lo = from_partner(a_hi);            // partner's register 15 - Q  -> B of register Q
-            const float2 p_hi = from_partner(a_lo);            // partner's register Q       -> B of register 15 - Q
-            const float2 b_lo = first ? carried : p_lo;        // thread 0: original register 16 - Q
-            const float2 b_hi = first ? r[(Q + 1) & 15] : p_hi;   // thread 0: register 16 - (15 - Q) = Q + 1 (Q = 7: register 8 itself)
+            const float2 b_lo = first ? carried : cur.lo;        // thread 0: original register 16 - Q
+            const float2 b_hi = first ? r[(Q + 1) & 15] : cur.hi;   // thread 0: register 16 - (15 - Q) = Q + 1 (Q = 7: register 8 itself)
             carried = a_hi;
             // W^i = W^u * W_32^q is the same for every tile, so the compiler would hoist all fifteen products out of the
             // grid-stride loop and keep them in 30 registers (140 VGPRs, 3 waves per SIMD): the copy below is opaque to it
@@ -378,22 +342,22 @@ struct HermitianRegisters {
             const float2 o_hi = combine<15 - Q>(a_hi, b_hi, w);
             r[Q] = o_lo;
             r[15 - Q] = o_hi;
-            // Keep the steps apart: left alone, the compiler hoists all thirty-two fetches to the top to hide their
-            // latency and keeps their results in thirty-two registers (with four waves per SIMD the other waves cover
-            // the latency).  The empty asm makes this step's results and the next step's inputs its outputs, so the next
-            // fetches cannot start before this step's arithmetic is done.
-            if constexpr (Q < 7) {
+            // this step's results and the inputs of the step after next are outputs of the empty asm: the fetches of
+            // step Q + 2 cannot be issued before this step's arithmetic is done (left alone, the compiler hoists all
+            // thirty-two fetches to the top and keeps their results in thirty-two registers)
+            if constexpr (Q < 6) {
                 asm volatile("" : "+v"(r[Q].x), "+v"(r[Q].y), "+v"(r[15 - Q].x), "+v"(r[15 - Q].y),
-                                  "+v"(r[Q + 1].x), "+v"(r[Q + 1].y), "+v"(r[14 - Q].x), "+v"(r[14 - Q].y));
+                                  "+v"(r[Q + 2].x), "+v"(r[Q + 2].y), "+v"(r[13 - Q].x), "+v"(r[13 - Q].y));
             }
-            apply_pair<Q + 1>(r, carried);
+            apply_pair<Q + 1>(r, carried, next);
         }
     }
     __device__ __forceinline__ void apply(float2 (&r)[16]) const {
         float2 carried = make_float2(0.f, 0.f);   // step 0 of thread 0 does not use it (packed DC / Nyquist)
-        apply_pair<0>(r, carried);
+        apply_pair<0>(r, carried, fetch<0>(r));
     }
 };
+
 
 
 #ifndef SMFFT_RC_PREFETCH
@@ -487,38 +451,18 @@ __device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__
 // tiles) with no FFT in between.  bench.py times it next to the FFT so the HBM-bound kernels are
 // reported against a same-run, same-shape copy ceiling as well as against the 8 TB/s datasheet peak.
 // ------------------------------------------------------------------------------------------------
-template <int kTrips>
-__global__ void __launch_bounds__(256) SMFFT_stream_copy(const float2* __restrict__ d_input, float2* __restrict__ d_output, long ntiles) {
+template <int kUnused = 0>
+__global__ void __launch_bounds__(256) SMFFT_stream_copy(const float2* __restrict__ d_input, float2* __restrict__ d_output, long ntiles, int pace) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ float2 s_trip[kTrips > 0 ? 4352 : 1];
-    // (a contiguous run of tiles per workgroup instead of this grid stride measured the same:
-    //  5.6-5.9 TB/s either way, tools/copy_probe.py)
-    const long first = blockIdx.x, step = gridDim.x, last = ntiles;
-    for (long tile = first; tile < last; tile += step) {
+    __shared__ float2 s_rows[4352];
+    // (a contiguous run of tiles per workgroup instead of this grid stride measured the same, round 1)
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const float2* g = d_input + tile * 4096 + wave * 1024 + lane;
         float2* o = d_output + tile * 4096 + wave * 1024 + lane;
         float2 r[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) r[c] = smfft::gload(g + 64 * c);
-        // kTrips = 1 is the default: ONE round trip of the wave's chunk through LDS between the loads and
-        // the stores makes this copy 7 % faster than the plain one (6.11 vs 5.73 TB/s, tools/copy_trip_probe.py;
-        // two trips: 5.64).  See lds_round_trip above.
-        for (int k = 0; k < kTrips; ++k) {
-            float2* sw = s_trip + wave * 1088;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) sw[lane + 64 * c] = r[c];
-            smfft::fft_sync<false>();
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-#if SMFFT_TRIP_FORM == 1
-                r[c] = smfft::lds_read_single(sw, lane + 64 * c);
-#else
-                const smfft::v2f t = *reinterpret_cast<const volatile smfft::v2f*>(&sw[lane + 64 * c]);
-                r[c] = make_float2(t.x, t.y);
-#endif
-            }
-            smfft::fft_sync<false>();
-        }
+        if (pace) smfft::vmem_throttle<16>(s_rows + wave * 1088, r);   // the same rate limiter as the FFT kernels (16 for a bare copy)
 #pragma unroll
         for (int c = 0; c < 16; ++c) smfft::gstore(o + 64 * c, r[c]);
     }
@@ -559,9 +503,9 @@ __global__ void __launch_bounds__(256) SMFFT_stream_write(float2* __restrict__ d
 // capped and grid-strided).  The reference-shaped two-argument forms are in smfft/smfft_device_functions.hpp.
 // ------------------------------------------------------------------------------------------------
 template <class const_params>
-__global__ void __launch_bounds__(256) SMFFT_DIT_external(const float2* d_input, float2* d_output, int nFFTs) {
+__global__ void __launch_bounds__(256) SMFFT_DIT_external(const float2* d_input, float2* d_output, int nFFTs, int pace) {
     __shared__ float2 s_input[const_params::tile_sm_required];
-    smfft::c2c_external_body<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nFFTs, s_input);
+    smfft::c2c_external_body<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nFFTs, pace, s_input);
 }
 // The same kernel compiled for exactly 3 waves per SIMD.  The launcher uses it for the N = 4096 reorder
 // transforms: their 134 VGPRs give 3 waves per SIMD either way, but with the target stated the scheduler
@@ -569,9 +513,9 @@ __global__ void __launch_bounds__(256) SMFFT_DIT_external(const float2* d_input,
 // (tools/ab_probe.py).  Every other length measured equal or worse with a stated target.
 template <class const_params>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
-SMFFT_DIT_external_occ3(const float2* d_input, float2* d_output, int nFFTs) {
+SMFFT_DIT_external_occ3(const float2* d_input, float2* d_output, int nFFTs, int pace) {
     __shared__ float2 s_input[const_params::tile_sm_required];
-    smfft::c2c_external_body<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nFFTs, s_input);
+    smfft::c2c_external_body<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nFFTs, pace, s_input);
 }
 
 // SMFFT_MULT_MINWAVES (experiment switch): minimum waves per SIMD the compact kernels are compiled for
@@ -589,9 +533,9 @@ __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_size) SMFFT_DIT_multiple(
 
 // Stockham C2C program: un-normalised INVERSE (+i) transform, natural order (ST:76, :429).
 template <class const_params>
-__global__ void __launch_bounds__(256) FFT_GPU_external(const float2* d_input, float2* d_output, int nFFTs) {
+__global__ void __launch_bounds__(256) FFT_GPU_external(const float2* d_input, float2* d_output, int nFFTs, int pace) {
     __shared__ float2 s_input[4352];
-    smfft::c2c_external_body<const_params::fft_length, 1, 1>(d_input, d_output, nFFTs, s_input);
+    smfft::c2c_external_body<const_params::fft_length, 1, 1>(d_input, d_output, nFFTs, pace, s_input);
 }
 template <class const_params>
 __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_length) FFT_GPU_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {

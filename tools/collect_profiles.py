@@ -46,7 +46,7 @@ for sub, key in (("pmc_calib_fetch", "FETCH_SIZE"), ("pmc_calib_write", "WRITE_S
             out["calibration"].setdefault(k, {})[key + "_KiB_mean"] = sum(v) / len(v)
 for sub, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     for (k, c), v in counters(sub).items():
-        if "SMFFT" in k and c == key:
+        if ("SMFFT" in k or "FFT_GPU" in k) and c == key:
             out["kernels"].setdefault(k, {})[key + "_KiB_mean"] = sum(v) / len(v)
             out["kernels"][k][key + "_launches"] = len(v)
 k = "void SMFFT_DIT_external<FFT_1024_forward>"
@@ -55,13 +55,20 @@ if k in out["kernels"] and len(out["kernels"][k]) >= 4:
     e["hbm_bytes_per_launch"] = (2 * e["FETCH_SIZE_KiB_mean"] + e["WRITE_SIZE_KiB_mean"]) * 1024
     e["algorithmic_bytes_per_launch"] = 2 * 1024 * 524288 * 8
     e["traffic_over_algorithmic"] = e["hbm_bytes_per_launch"] / e["algorithmic_bytes_per_launch"]
+    for rk, e2 in out["kernels"].items():       # config 4: real N = 2048, 262144 FFTs: 2 GiB in, 2 GiB out per launch
+        if "FFT_GPU_R2C_C2R_external<FFT_1024" in rk and len(e2) >= 4:
+            e2["hbm_bytes_per_launch"] = (2 * e2["FETCH_SIZE_KiB_mean"] + e2["WRITE_SIZE_KiB_mean"]) * 1024
+            e2["algorithmic_bytes_per_launch"] = 2 * 2048 * 262144 * 4
+            e2["traffic_over_algorithmic"] = e2["hbm_bytes_per_launch"] / e2["algorithmic_bytes_per_launch"]
     json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
     print("traffic/algorithmic =", e["traffic_over_algorithmic"])
 
-# 3. LDS counters of the sweep
+# 3. LDS and wave-state counters of the sweep
 rows = {}
 total = 1 << 29
-for (k, c), v in counters("pmc_lds").items():
+both = dict(counters("pmc_lds"))
+both.update(counters("pmc_wait"))
+for (k, c), v in both.items():
     m = re.search(r"(SMFFT_DIT_\w+)<FFT_(\d+)_forward(_noreorder)?>", k)
     if not m:
         continue
@@ -73,7 +80,11 @@ for (k, c), v in counters("pmc_lds").items():
 for name, r in rows.items():
     if "SQ_LDS_IDX_ACTIVE" in r and r["SQ_LDS_IDX_ACTIVE"]:
         r["bank_conflict_ratio"] = r.get("SQ_LDS_BANK_CONFLICT", 0.0) / r["SQ_LDS_IDX_ACTIVE"]
-json.dump({"command": "rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES -- python3 tools/sweep.py --sizes 32..4096 --paths multiple,external --variants f0,f1",
+for name, r in rows.items():
+    # SQ_ACTIVE_INST_VALU counts quad-cycles per wave; a SIMD serves two waves' VALU instructions in those four cycles
+    if "SQ_ACTIVE_INST_VALU" in r and r.get("SQ_WAVE_CYCLES"):
+        r["valu_active_fraction_of_wave_time"] = r["SQ_ACTIVE_INST_VALU"] / r["SQ_WAVE_CYCLES"]
+json.dump({"command": "rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES (pass 1), SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES (pass 2) -- python3 tools/sweep.py --sizes 32..4096 --paths multiple[,external] --variants f0,f1",
            "unit": "counter value per FFT (README batch: 2^29/N FFTs; multiple path: floor(nFFTs/100)*100 FFT executions)",
            "per_fft": dict(sorted(rows.items()))}, open(f"profiles/{tag}_pmc_lds.json", "w"), indent=1)
 print("wrote profiles/ for", tag, ":", sorted(os.listdir("profiles")))
