@@ -313,7 +313,11 @@ struct Engine {
 #pragma unroll
         for (int c = 0; c < 16; ++c) r[c] = gload(g + u + T * c);
     }
-    __device__ __forceinline__ void load_lds(float2 (&r)[16], const float2* sf) const { lds_read16<T, (N == 128 || N == 256)>(r, sf + u); }   // single reads measured +4-7 % at the two-pass lengths (profiles/r02_ab_reads.txt)
+    // SINGLE_OK: the caller is an in-LDS kernel, where single reads measured +4-10 % at the two-pass lengths N = 128 / 256
+    // (profiles/r02_ab_reads.txt); the HBM-bound external kernels keep the merged reads (their R2C form of real N = 512
+    // lost 4.6 % with single ones, profiles/r02_ab_ext_pair.txt)
+    template <bool SINGLE_OK = false>
+    __device__ __forceinline__ void load_lds(float2 (&r)[16], const float2* sf) const { lds_read16<T, SINGLE_OK && (N == 128 || N == 256)>(r, sf + u); }
 
     // ---- natural registers -> pass-1 slots r[b*R1 + r1] = x'[t1 + T1*r1], t1 = u + T*b ------------
     // REORDER: x' = x, and t1 + T1*r1 = u + T*(b + B1*r1): a compile-time renaming of registers.
@@ -566,10 +570,11 @@ struct Engine {
     }
 
     // ---- last pass: one radix-16 butterfly per thread; r[q3] = X[u + T*q3] -----------------------
+    template <bool SINGLE_OK = false>
     __device__ __forceinline__ void last(float2 (&r)[16], const float2* sf) const {
         float2 x[16];
         if constexpr (RM > 1) lds_read16<S2, false>(x, sf + u);
-        else lds_read16<1, true>(x, sf + u * S0);
+        else lds_read16<1, SINGLE_OK>(x, sf + u * S0);
         SmallDft<16, 1, DIR>::run(x, r);
     }
 
@@ -588,11 +593,13 @@ struct Engine {
     // registers (natural order, r[c] = x[u + T*c]) -> registers (r[q] = X[u + T*q]) through the
     // FFT's LDS region.
     // Precondition: every earlier LDS access of this FFT's region has been ordered by fft_sync.
+    template <bool SINGLE_OK = false>
     __device__ __forceinline__ void transform(float2 (&r)[16], float2* sf) const {
         to_pass1_layout(r, sf);
-        transform_from_pass1_slots(r, sf);
+        transform_from_pass1_slots<SINGLE_OK>(r, sf);
     }
     // the transform of registers that already hold the pass-1 slots (after to_pass1_layout or bitrev_read)
+    template <bool SINGLE_OK = false>
     __device__ __forceinline__ void transform_from_pass1_slots(float2 (&r)[16], float2* sf) const {
         pass1(r);
         if constexpr (G::kRegTwoPass) {
@@ -608,7 +615,7 @@ struct Engine {
             fft_sync<G::kMultiWave>();
         }
         middle(r, sf);
-        last(r, sf);
+        last<SINGLE_OK>(r, sf);
     }
 };
 

@@ -244,13 +244,13 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_i
             if constexpr (kPaddedImage) {
                 eng.bitrev_read(r, sf);
                 fft_sync<G::kMultiWave>();          // all inputs are in registers before the region is reused
-                eng.transform_from_pass1_slots(r, sf);
+                eng.template transform_from_pass1_slots<true>(r, sf);
                 fft_sync<G::kMultiWave>();          // all exchange reads done before the results overwrite them
                 eng.bitrev_write(r, sf);
             } else {
-                eng.load_lds(r, sf);
+                eng.template load_lds<true>(r, sf);
                 fft_sync<G::kMultiWave>();
-                eng.transform(r, sf);
+                eng.template transform<true>(r, sf);
                 fft_sync<G::kMultiWave>();
                 eng.store_lds(r, sf);
             }
@@ -272,6 +272,9 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_i
 // external kernels where that measured faster.
 #ifndef SMFFT_RC_REGISTERS
 #define SMFFT_RC_REGISTERS 1
+#endif
+#ifndef SMFFT_RC_INPLACE
+#define SMFFT_RC_INPLACE 0
 #endif
 template <int L, int DIR>
 struct HermitianRegisters {
@@ -352,11 +355,52 @@ struct HermitianRegisters {
             apply_pair<Q + 1>(r, carried, next);
         }
     }
+#if SMFFT_RC_INPLACE
     __device__ __forceinline__ void apply(float2 (&r)[16]) const {
         float2 carried = make_float2(0.f, 0.f);   // step 0 of thread 0 does not use it (packed DC / Nyquist)
         apply_pair<0>(r, carried, fetch<0>(r));
     }
+#else
+    // All sixteen partner values fetched at once: thirty-two ds_bpermute back to back, their latencies overlapped, at the
+    // price of 139-146 VGPRs (3 waves per SIMD).  Measured against the in-place, software-pipelined form above
+    // (SMFFT_RC_INPLACE=1: 93-113 VGPRs, 4 waves per SIMD) on the same buffers, profiles/r02_ab_rc.txt / r02_ab_ext_pair.txt:
+    // this form is 0.6-2 % FASTER (config 4: R2C 0.692 vs 0.697 ms, C2R 0.679 vs 0.693 ms) -- these kernels are bound by
+    // what one wave keeps in flight, not by how many waves there are.
+    __device__ __forceinline__ void apply(float2 (&r)[16]) const {
+        constexpr float c32[16] = {1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f, 0.55557023301960229f,
+                                   0.38268343236508984f, 0.19509032201612833f, 0.f, -0.19509032201612819f, -0.38268343236508973f, -0.55557023301960196f,
+                                   -0.70710678118654746f, -0.83146961230254535f, -0.92387953251128674f, -0.98078528040323043f};
+        constexpr float s32[16] = {0.f, 0.19509032201612825f, 0.38268343236508978f, 0.55557023301960218f, 0.70710678118654746f, 0.83146961230254524f,
+                                   0.92387953251128674f, 0.98078528040323043f, 1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254546f,
+                                   0.70710678118654757f, 0.55557023301960218f, 0.38268343236508989f, 0.19509032201612861f};
+        constexpr float ohx = DIR ? -0.5f : 0.5f, ohy = DIR ? 0.5f : -0.5f;
+        float2 B[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float2 src = r[15 - q];
+            const float bx = __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(src.x)));
+            const float by = __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(src.y)));
+            const float2 own = r[(16 - q) & 15];
+            B[q] = first ? own : make_float2(bx, by);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float2 A = r[q];
+            const float2 H1 = make_float2(0.5f * (A.x + B[q].x), 0.5f * (A.y - B[q].y));
+            const float2 H2 = make_float2(ohx * (A.y + B[q].y), ohy * (A.x - B[q].x));
+            const float2 W = (q == 0) ? wu : cmul(wu, make_float2(c32[q], DIR ? s32[q] : -s32[q]));
+            const float2 WH = cmul(H2, W);
+            float2 out = make_float2(H1.x + WH.x, H1.y + WH.y);
+            if (q == 0) {   // element 0 of thread 0 packs DC and Nyquist (RC:280-286, 332-339)
+                const float2 packed = DIR ? make_float2(0.5f * (A.x + A.y), 0.5f * (A.x - A.y)) : make_float2(A.x + A.y, A.x - A.y);
+                out = first ? packed : out;
+            }
+            r[q] = out;
+        }
+    }
+#endif
 };
+
 
 
 
@@ -544,14 +588,17 @@ __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_length) FFT_GPU_multiple(
 }
 
 // R2C/C2R program.
-// compiled for 4 waves per SIMD (<= 128 VGPRs; real N = 4096, whose transform spans four waves, for 3): with the
-// in-place Hermitian step (HermitianRegisters::apply) the real N = 1024 / 2048 kernels need 89-112 registers, against
-// 139-146 (3 waves per SIMD) in round 1
-#ifndef SMFFT_RC_WAVES
-#define SMFFT_RC_WAVES 4
+// SMFFT_RC_INPLACE=1 (A/B switch): the in-place Hermitian step, compiled for 4 waves per SIMD (<= 128 VGPRs)
+#ifndef SMFFT_RC_INPLACE
+#define SMFFT_RC_INPLACE 0
+#endif
+#if SMFFT_RC_INPLACE
+#define SMFFT_RC_BOUNDS(L) __launch_bounds__(256, ((L) <= 1024 ? 4 : 3))
+#else
+#define SMFFT_RC_BOUNDS(L) __launch_bounds__(256)
 #endif
 template <class const_params, class const_direction>
-__global__ void __launch_bounds__(256, (const_params::fft_length <= 1024 ? SMFFT_RC_WAVES : 3)) FFT_GPU_R2C_C2R_external(const float2* d_input, float2* d_output, int nFFTs) {
+__global__ void SMFFT_RC_BOUNDS(const_params::fft_length) FFT_GPU_R2C_C2R_external(const float2* d_input, float2* d_output, int nFFTs) {
     __shared__ float2 s_input[4352];
     smfft::r2c_c2r_external_body<const_params::fft_length, const_direction::fft_direction>(d_input, d_output, nFFTs, s_input);
 }
