@@ -282,31 +282,32 @@ struct HermitianRegisters {
     // used by the external kernels of real N = 1024 and 2048 (measured: 2048 R2C +2.6 %, C2R +3.0 %; 1024 0 / +1.8 %;
     // 512 -1.8 / -0.7 %: LDS form there; in-LDS path 1-5 % slower with it: LDS form there too)
     static constexpr bool kEnabled = SMFFT_RC_REGISTERS && (L == 512 || L == 1024);
-    float2 wu;          // W_{2L}^u (conjugated for DIR = 1)
+    float2 wu;          // (-+i / 2) * W_{2L}^u (W conjugated, +i, for DIR = 1): see combine
     int partner_addr;   // byte address of the partner lane for ds_bpermute
     bool first;         // u == 0
     __device__ __forceinline__ void init(int tid) {
         const int u = tid % T, lane = tid & 63;
         first = (u == 0);
         partner_addr = 4 * ((lane - u) + ((T - u) % T));
-        wu = twiddle<DIR>(u * (4096 / (2 * L)));
+        const float2 w = twiddle<DIR>(u * (4096 / (2 * L)));
+        wu = DIR ? make_float2(-0.5f * w.y, 0.5f * w.x) : make_float2(0.5f * w.y, -0.5f * w.x);
     }
-    // out[i] = H1 + W^i * H2 with A = x[i], B = x[L - i]  (i = u + T*q):
-    //   H1 = ((A.x + B.x)/2, (A.y - B.y)/2),  H2 = (ohx * (A.y + B.y), ohy * (A.x - B.x))
+    // out[i] = H1 + W^i * H2 with A = x[i], B = x[L - i]  (i = u + T*q) and, as upstream (RC:289-328),
+    //   H1 = ((A.x + B.x)/2, (A.y - B.y)/2),  H2 = (ohx * (A.y + B.y), ohy * (A.x - B.x)),  (ohx, ohy) = (1/2, -1/2) forward, (-1/2, 1/2) inverse.
+    // With S = A + conj(B) and D = A - conj(B): H1 = S/2 and H2 = (-+i/2) * D, so out = S/2 + V * D, V = (-+i/2) * W^u * W_32^q:
+    // 4 additions + 6 multiply-adds per element once V is there (`wu` holds (-+i/2) * W^u).
     template <int Q>
-    __device__ __forceinline__ float2 combine(float2 A, float2 B, float2 wu) const {
+    __device__ __forceinline__ float2 combine(float2 A, float2 B, float2 vu) const {
         constexpr float c32[16] = {1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f, 0.55557023301960229f,
                                    0.38268343236508984f, 0.19509032201612833f, 0.f, -0.19509032201612819f, -0.38268343236508973f, -0.55557023301960196f,
                                    -0.70710678118654746f, -0.83146961230254535f, -0.92387953251128674f, -0.98078528040323043f};
         constexpr float s32[16] = {0.f, 0.19509032201612825f, 0.38268343236508978f, 0.55557023301960218f, 0.70710678118654746f, 0.83146961230254524f,
                                    0.92387953251128674f, 0.98078528040323043f, 1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254546f,
                                    0.70710678118654757f, 0.55557023301960218f, 0.38268343236508989f, 0.19509032201612861f};
-        constexpr float ohx = DIR ? -0.5f : 0.5f, ohy = DIR ? 0.5f : -0.5f;
-        const float2 H1 = make_float2(0.5f * (A.x + B.x), 0.5f * (A.y - B.y));
-        const float2 H2 = make_float2(ohx * (A.y + B.y), ohy * (A.x - B.x));
-        const float2 W = (Q == 0) ? wu : cmul(wu, make_float2(c32[Q], DIR ? s32[Q] : -s32[Q]));
-        const float2 WH = cmul(H2, W);
-        return make_float2(H1.x + WH.x, H1.y + WH.y);
+        const float2 S = make_float2(A.x + B.x, A.y - B.y);
+        const float2 D = make_float2(A.x - B.x, A.y + B.y);
+        const float2 V = (Q == 0) ? vu : cmul(vu, make_float2(c32[Q], DIR ? s32[Q] : -s32[Q]));
+        return make_float2(fmaf(V.x, D.x, fmaf(-V.y, D.y, 0.5f * S.x)), fmaf(V.x, D.y, fmaf(V.y, D.x, 0.5f * S.y)));
     }
     __device__ __forceinline__ float2 from_partner(float2 v) const {
         return make_float2(__int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(v.x))),
@@ -373,7 +374,6 @@ struct HermitianRegisters {
         constexpr float s32[16] = {0.f, 0.19509032201612825f, 0.38268343236508978f, 0.55557023301960218f, 0.70710678118654746f, 0.83146961230254524f,
                                    0.92387953251128674f, 0.98078528040323043f, 1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254546f,
                                    0.70710678118654757f, 0.55557023301960218f, 0.38268343236508989f, 0.19509032201612861f};
-        constexpr float ohx = DIR ? -0.5f : 0.5f, ohy = DIR ? 0.5f : -0.5f;
         float2 B[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -386,11 +386,10 @@ struct HermitianRegisters {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const float2 A = r[q];
-            const float2 H1 = make_float2(0.5f * (A.x + B[q].x), 0.5f * (A.y - B[q].y));
-            const float2 H2 = make_float2(ohx * (A.y + B[q].y), ohy * (A.x - B[q].x));
-            const float2 W = (q == 0) ? wu : cmul(wu, make_float2(c32[q], DIR ? s32[q] : -s32[q]));
-            const float2 WH = cmul(H2, W);
-            float2 out = make_float2(H1.x + WH.x, H1.y + WH.y);
+            const float2 S = make_float2(A.x + B[q].x, A.y - B[q].y);       // A + conj(B)
+            const float2 D = make_float2(A.x - B[q].x, A.y + B[q].y);       // A - conj(B)
+            const float2 V = (q == 0) ? wu : cmul(wu, make_float2(c32[q], DIR ? s32[q] : -s32[q]));   // (-+i/2) * W^i, see combine
+            float2 out = make_float2(fmaf(V.x, D.x, fmaf(-V.y, D.y, 0.5f * S.x)), fmaf(V.x, D.y, fmaf(V.y, D.x, 0.5f * S.y)));
             if (q == 0) {   // element 0 of thread 0 packs DC and Nyquist (RC:280-286, 332-339)
                 const float2 packed = DIR ? make_float2(0.5f * (A.x + A.y), 0.5f * (A.x - A.y)) : make_float2(A.x + A.y, A.x - A.y);
                 out = first ? packed : out;
