@@ -180,7 +180,7 @@ template <int N, bool PADDED>
 __device__ __forceinline__ void tile_to_lds(const float2* __restrict__ g, float2* s, long first_fft, long limit_fft) {
     using G = Geometry<N>;
     constexpr int C = G::kCompactTile / G::kCompactThreads;
-    static_assert(!PADDED || N >= G::kCompactThreads, "the padded image exists for N >= 128 only");
+    static_assert(N >= G::kCompactThreads || G::kCompactThreads % N == 0, "see compact_lds_base");
     float2 v[C];
     if (first_fft + G::kCompactFfts <= limit_fft) {      // whole tile inside the batch: loads back to back, no predicate
 #pragma unroll
@@ -222,14 +222,15 @@ __device__ __forceinline__ void lds_to_tile(float2* __restrict__ g, const float2
 // benchmark; a kernel argument so the tests can run 1, 2 and 4 applications) times in LDS, stored once.
 // Every application reads its input from LDS and writes its result to LDS (the device function's contract);
 // what the kernel chooses is the IMAGE the data are kept in between applications: natural order for the reorder
-// variants (and for N <= 64, whose bit-reversal is a register transposition), the padded image of
-// Engine::bitrev_write for the no-reorder variants of N >= 128 -- a result is stored straight into the layout the
-// next application's bit-reversed read wants, instead of natural order + a second write and read (round 1: 64 LDS
-// instructions per N = 1024 FFT against 32 for reorder; now 32 + 32 either way).
+// variants, the padded image of Engine::bitrev_write for the no-reorder variants -- a result is stored straight into
+// the layout the next application's bit-reversed read wants, instead of natural order + a second write and read
+// (round 1: 64 LDS instructions per N = 1024 FFT against 32 for reorder; now 32 + 32 either way; for N <= 64, whose
+// device-function form does the bit reversal as a DPP register transposition, the read from the padded image replaces
+// that transposition too).
 template <int N, int DIR, int REORDER>
 __device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, float2* s) {
     using G = Geometry<N>;
-    constexpr bool kPaddedImage = !REORDER && !G::kRegTwoPass;
+    constexpr bool kPaddedImage = !REORDER;
     Engine<N, DIR, REORDER> eng;
     eng.init(threadIdx.x);
     float2* sf = s + eng.fft * G::SF;
