@@ -120,8 +120,8 @@ int timed(F&& launch, double* FFT_time) {
 // the output is complete, or at the byte budget (default: a quarter of the free memory) or the time budget (default
 // 2 s), whatever is missing then coming from the last ordinary chunks scanned (the farthest from the input).  The
 // chosen handles are mapped back to back into one virtual range -- the caller sees an ordinary device pointer -- and
-// everything else is released.  Cost measured: 7-39 ms per scanned GiB (hipMemCreate), ~28 GiB scanned for a 4 GiB output
-// on average.
+// everything else is released.  Cost measured on six boxes: 4-40 ms per scanned GiB (hipMemCreate); 8-14 GiB scanned in
+// 40-230 ms for a 4 GiB output on five of them, the byte budget (69 GiB) in 1.6 s on the sixth; output all mixed every time.
 //   SMFFT_PAIR_POLICY=mixed|candidates|plain   candidates: round-1 style, whole hipMalloc / hipMallocAsync blocks timed as
 //                                              copy targets inside the same budgets; plain: two plain allocations
 //   SMFFT_PAIR_BUDGET_FRAC=0.25                byte budget of the scan as a fraction of the free memory
