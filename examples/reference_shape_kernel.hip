@@ -74,3 +74,13 @@ extern "C" int smfft_example_reference_shape_rc(void* d_in, void* d_out, int FFT
     }
     return (int)hipGetLastError();
 }
+
+// the two `multiple` kernels of the Stockham programs in the reference's shape (compile check; NREUSES applications overflow
+// fp32 by design, as upstream, so only the launch is exercised)
+extern "C" int smfft_example_reference_shape_multiple(void* d_in, void* d_out, int nFFTs, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    FFT_GPU_multiple<FFT_1024><<<dim3(nFFTs), dim3(256), 1024 * 8, st>>>((float2*)d_in, (float2*)d_out);
+    FFT_GPU_R2C_C2R_multiple<FFT_1024, FFT_forward><<<dim3(nFFTs), dim3(256), 0, st>>>((float2*)d_in, (float2*)d_out);
+    SMFFT_DIT_multiple<FFT_1024_forward><<<dim3(nFFTs), dim3(256), 0, st>>>((float2*)d_in, (float2*)d_out);
+    return (int)hipGetLastError();
+}

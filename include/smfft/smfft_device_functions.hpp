@@ -232,6 +232,19 @@ __global__ void FFT_GPU_external(float2* d_input, float2* d_output) {
     for (int k = 0; k < 4; ++k) d_output[base + k * const_params::fft_quarter] = s_input[threadIdx.x + k * const_params::fft_quarter];
 }
 
+template <class const_params>
+__global__ void FFT_GPU_multiple(float2* d_input, float2* d_output) {   // ST:260-278
+    extern __shared__ float2 s_input_dynamic[];
+    float2* s_input = s_input_dynamic;
+    const int base = threadIdx.x + blockIdx.x * const_params::fft_length;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_input[threadIdx.x + k * const_params::fft_quarter] = d_input[base + k * const_params::fft_quarter];
+    __syncthreads();
+    for (int f = 0; f < NREUSES; f++) do_FFT_Stockham_mk6<const_params>(s_input);   // the function ends with a barrier
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d_output[base + k * const_params::fft_quarter] = s_input[threadIdx.x + k * const_params::fft_quarter];
+}
+
 // R2C / C2R program, RC:349-365: L + 1 float2 of LDS, blockDim.x = L / 4, L = const_params::fft_length = real length / 2
 template <class const_params, class const_direction>
 __global__ void FFT_GPU_R2C_C2R_external(float2* d_input, float2* d_output) {
@@ -241,6 +254,18 @@ __global__ void FFT_GPU_R2C_C2R_external(float2* d_input, float2* d_output) {
     for (int k = 0; k < 4; ++k) s_input[threadIdx.x + k * const_params::fft_quarter] = d_input[base + k * const_params::fft_quarter];
     __syncthreads();
     do_FFT_Stockham_R2C_C2R<const_params, const_direction>(s_input);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d_output[base + k * const_params::fft_quarter] = s_input[threadIdx.x + k * const_params::fft_quarter];
+}
+
+template <class const_params, class const_direction>
+__global__ void FFT_GPU_R2C_C2R_multiple(float2* d_input, float2* d_output) {   // RC:367-384
+    __shared__ float2 s_input[const_params::fft_length + 1];
+    const int base = threadIdx.x + blockIdx.x * const_params::fft_length;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_input[threadIdx.x + k * const_params::fft_quarter] = d_input[base + k * const_params::fft_quarter];
+    __syncthreads();
+    for (int f = 0; f < NREUSES; f++) do_FFT_Stockham_R2C_C2R<const_params, const_direction>(s_input);   // ends with a barrier
 #pragma unroll
     for (int k = 0; k < 4; ++k) d_output[base + k * const_params::fft_quarter] = s_input[threadIdx.x + k * const_params::fft_quarter];
 }

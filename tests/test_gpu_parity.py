@@ -362,6 +362,34 @@ def test_reference_shaped_r2c_c2r_kernel(sm, oracle_lib, n):
     ref.assert_close_fp32(back, oa.c2r(oracle_lib, packed, "f64"), f"reference-shaped C2R N={n}")
 
 
+def test_reference_shaped_multiple_kernels_launch(sm):
+    """SMFFT_DIT_multiple<P>(in, out), FFT_GPU_multiple<P>(in, out), FFT_GPU_R2C_C2R_multiple<P,D>(in, out) in the reference's
+    launch shape (CT:553-572, ST:260-278, RC:367-384): they launch and finish (their 100 applications overflow fp32 by design)."""
+    import ctypes
+    ex = _examples(sm)
+    fn = ex.smfft_example_reference_shape_multiple
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    x = np.zeros((3, 1024), np.complex64)
+    x[:, 1] = 1e-30
+    dx, dy = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
+    assert fn(dx.ptr, dy.ptr, 3, None) == 0
+    assert sm.lib.smfft_synchronize() == 0
+
+
+def test_harness_with_wrapper_placement(sm):
+    """SMFFT_WRAPPER_PLACEMENT=1: the L3 wrapper and the hipFFT comparator both take their buffers from smfft_malloc_pair
+    (the output a VMM-backed range): the harness still passes."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "harness", "FFT_CooleyTukey_C2C.exe")
+    if not os.path.exists(exe):
+        pytest.skip("harness not built")
+    env = dict(os.environ, SMFFT_WRAPPER_PLACEMENT="1", SMFFT_PAIR_BUDGET_FRAC="0.05")
+    p = subprocess.run([exe, "1024", "262144", "3", "0", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "PASSED" in p.stdout and "FAILED" not in p.stdout, p.stdout + p.stderr
+
+
 # --------------------------------------------------------------------- API conventions (8(b))
 def test_time_accumulates_and_launch_on_stream(sm, oracle_lib):
     """`*FFT_time += elapsed` (CT:598,660-662): two calls on one accumulator add up; the launch-only
