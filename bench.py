@@ -113,6 +113,37 @@ def measured_traffic():
         return None
 
 
+def hipfft_ms(torch, dev, stream, i_ptr, o_ptr, n, nffts, reps=10):
+    """hipFFT (rocFFT) on the same device buffers, same events: the vendor library as a same-run yardstick (the harness's
+    GPU_cuFFT analogue, smfft_vendor.hip).  None if the library cannot be loaded."""
+    try:
+        lib = ctypes.CDLL("libhipfft.so")
+    except OSError:
+        try:
+            lib = ctypes.CDLL("/opt/rocm/lib/libhipfft.so")
+        except OSError:
+            return None
+    plan = ctypes.c_void_p()
+    HIPFFT_C2C, HIPFFT_FORWARD = 0x29, -1
+    lib.hipfftPlan1d.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.hipfftSetStream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.hipfftExecC2C.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    lib.hipfftDestroy.argtypes = [ctypes.c_void_p]
+    if lib.hipfftPlan1d(ctypes.byref(plan), n, HIPFFT_C2C, nffts) != 0:
+        return None
+    lib.hipfftSetStream(plan, ctypes.c_void_p(stream.cuda_stream))
+    for _ in range(3):
+        lib.hipfftExecC2C(plan, i_ptr, o_ptr, HIPFFT_FORWARD)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        lib.hipfftExecC2C(plan, i_ptr, o_ptr, HIPFFT_FORWARD)
+    e1.record(stream)
+    torch.cuda.synchronize(dev)
+    lib.hipfftDestroy(plan)
+    return e0.elapsed_time(e1) / reps
+
+
 def vram_used_bytes(torch, dev):
     """mem_info_vram_used of the card that runs the bench (None if its sysfs node cannot be identified)."""
     try:
@@ -341,6 +372,15 @@ def main():
     pair_copy_ms = copy_ms(pa.value, pb.value)
     plain_copy_ms = copy_ms(p_in.ptr, p_out.ptr) if p_in else float("nan")
 
+    # the vendor library on the same buffers (N = 1 only; informational)
+    vendor = None
+    if world == 1 and not args.no_configs:
+        v_pair = hipfft_ms(torch, dev, stream, pa.value, pb.value, n, nffts)
+        v_plain = hipfft_ms(torch, dev, stream, p_in.ptr, p_out.ptr, n, nffts) if p_in else None
+        if v_pair:
+            vendor = {"library": "hipFFT (rocFFT) hipfftExecC2C, batched plan, same device buffers, 10 launches after 3 warm-ups",
+                      "ms_on_pair": v_pair, "ms_on_plain": v_plain}
+
     def median_ms(fn, reps=11, warm=3):
         for _ in range(warm):
             fn(None)
@@ -431,6 +471,7 @@ def main():
             "pair_alloc_s": alloc_s,
             "pair_search": pair_info,
             "vram_used_bytes": vram,
+            "vendor_hipfft": vendor,
             "multiple_path": mult,
             "configs": configs,
             "comm_backend": (backend if world > 1 else None),
