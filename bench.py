@@ -292,6 +292,20 @@ def main():
         raise SystemExit("smfft_malloc_pair failed")
     alloc_s = time.perf_counter() - t_alloc
     pair_info = sm.last_pair_info()
+    pair_info["budget"] = "default: a quarter of the free memory, 2 s"
+    pair_attempts = [pair_info]
+    # The default budget does not reach mixed memory on every box (on about one box in four the first quarter of the
+    # memory holds none).  This process owns its device, so it may ask once more with a patient budget; both attempts
+    # are reported, `value` / `roofline` are measured on the pair that was kept.
+    if not pair_info["good_enough"] and os.environ.get("SMFFT_BENCH_PATIENT", "1") != "0":
+        sm.lib.smfft_free_pair(pa.value)
+        t_alloc = time.perf_counter()
+        if sm.lib.smfft_malloc_pair_budget(nbytes, ctypes.byref(pa), ctypes.byref(pb), 0.9, 20000.0) != 0:
+            raise SystemExit("smfft_malloc_pair_budget failed")
+        alloc_s += time.perf_counter() - t_alloc
+        pair_info = sm.last_pair_info()
+        pair_info["budget"] = "patient: 90 % of the free memory, 20 s (second attempt: the default budget found no mixed memory)"
+        pair_attempts.append(pair_info)
     vram["after_smfft_malloc_pair"] = vram_used_bytes(torch, dev)
     p_in = p_out = None
     if not args.no_plain:
@@ -463,13 +477,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"config 2: N={n} C2C forward, reorder, {nffts} FFTs per GPU ({alg_bytes // 2 >> 20} MiB in + out), external path",
                        "fft_size": n, "nffts_per_gpu": nffts, "parallelism": f"batch-split x{world}",
-                       "buffers": "smfft_malloc_pair (budget-bounded placement search); plain hipMalloc figures in roofline_plain / value_plain"},
+                       "buffers": "smfft_malloc_pair (output built from mixed memory; budget: " + pair_info["budget"] + "); plain hipMalloc figures in roofline_plain / value_plain"},
             "hbm_GBps_per_gpu": alg_bytes / (ms_per_step * 1e-3) / 1e9,
             "roofline": roof(kernel_ms_max, pair_copy_ms),
             "roofline_plain": roof(plain_kernel_ms_max, plain_copy_ms) if p_in else None,
             "value_plain": total_ffts / (plain_wall_max / args.steps) if p_in else None,
             "pair_alloc_s": alloc_s,
             "pair_search": pair_info,
+            "pair_attempts": pair_attempts,
             "vram_used_bytes": vram,
             "vendor_hipfft": vendor,
             "multiple_path": mult,

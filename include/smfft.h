@@ -138,6 +138,9 @@ void* smfft_malloc(unsigned long long bytes);
  * The L3 wrappers allocate plainly, like the reference (CT:850-853), unless SMFFT_WRAPPER_PLACEMENT=1.
  * Release with smfft_free_pair(d_read) (an error for a pointer this call did not return). */
 int smfft_malloc_pair(unsigned long long bytes, void** d_read, void** d_written);
+/* the same with explicit budgets for this call (a negative value = the default / the environment's): for a process that owns
+ * the device and prefers a longer scan to an output that is only partly mixed (bench.py's second attempt) */
+int smfft_malloc_pair_budget(unsigned long long bytes, void** d_read, void** d_written, double budget_frac, double budget_ms);
 int smfft_free_pair(void* d_read);
 /* gives back the pair SMFFT_PAIR_CACHE=1 keeps */
 int smfft_pair_cache_release(void);

@@ -53,6 +53,7 @@ _SIGS = {
     "smfft_version": (ctypes.c_char_p, []),
     "smfft_malloc": (_vp, [_ull]),
     "smfft_malloc_pair": (_i, [_ull, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    "smfft_malloc_pair_budget": (_i, [_ull, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_double, ctypes.c_double]),
     "smfft_free_pair": (_i, [_vp]),
     "smfft_pair_cache_release": (_i, []),
     "smfft_last_pair_info": (_i, [_vp]),

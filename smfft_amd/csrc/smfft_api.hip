@@ -391,7 +391,7 @@ bool pick_candidate_output(size_t bytes, const void* in, const Budget& budget, f
     return true;
 }
 
-int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search) {
+int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search, double budget_frac = -1.0, double budget_ms = -1.0) {
     *d_a = *d_b = nullptr;
     int device = -1;
     (void)hipGetDevice(&device);
@@ -419,8 +419,8 @@ int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search) {
         Budget budget;
         size_t free_mem = 0, total_mem = 0;
         (void)hipMemGetInfo(&free_mem, &total_mem);
-        budget.bytes = (size_t)(env_double("SMFFT_PAIR_BUDGET_FRAC", 0.25) * (double)free_mem);
-        budget.ms = env_double("SMFFT_PAIR_BUDGET_MS", 2000.0);
+        budget.bytes = (size_t)((budget_frac >= 0.0 ? budget_frac : env_double("SMFFT_PAIR_BUDGET_FRAC", 0.25)) * (double)free_mem);
+        budget.ms = budget_ms >= 0.0 ? budget_ms : env_double("SMFFT_PAIR_BUDGET_MS", 2000.0);
         const size_t window = bytes < kChunkBytes ? bytes : kChunkBytes;
         info.read_ms = probe_ms(in, nullptr, window, 3);
         bool done = !candidates_only && build_mixed_output(bytes, in, device, budget, rec, info);
@@ -723,6 +723,10 @@ int smfft_set_device(int device) { read_env(); g_device = device; return (int)hi
 const char* smfft_version(void) { return "smfft_amd 0.1 (gfx950)"; }
 
 int smfft_malloc_pair(unsigned long long bytes, void** d_read, void** d_written) { read_env(); return alloc_pair((size_t)bytes, d_read, d_written, true); }
+int smfft_malloc_pair_budget(unsigned long long bytes, void** d_read, void** d_written, double budget_frac, double budget_ms) {
+    read_env();
+    return alloc_pair((size_t)bytes, d_read, d_written, true, budget_frac, budget_ms);
+}
 int smfft_last_pair_info(SmfftPairInfo* out) {
     if (!out) return 1;
     std::lock_guard<std::mutex> lock(g_pairs_mutex);
