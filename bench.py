@@ -297,7 +297,9 @@ def main():
     # The default budget does not reach mixed memory on every box (on about one box in four the first quarter of the
     # memory holds none).  This process owns its device, so it may ask once more with a patient budget; both attempts
     # are reported, `value` / `roofline` are measured on the pair that was kept.
-    if not pair_info["good_enough"] and os.environ.get("SMFFT_BENCH_PATIENT", "1") != "0":
+    # (not when several ranks were pinned to ONE device by the test hook: a patient scan would starve the other rank)
+    patient_default = "0" if "SMFFT_BENCH_DEVICE" in os.environ else "1"
+    if not pair_info["good_enough"] and os.environ.get("SMFFT_BENCH_PATIENT", patient_default) != "0":
         sm.lib.smfft_free_pair(pa.value)
         t_alloc = time.perf_counter()
         if sm.lib.smfft_malloc_pair_budget(nbytes, ctypes.byref(pa), ctypes.byref(pb), 0.9, 20000.0) != 0:
