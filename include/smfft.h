@@ -147,7 +147,7 @@ int smfft_pair_cache_release(void);
 /* what the last smfft_malloc_pair of this process did (telemetry for bench.py and the tests) */
 typedef struct SmfftPairInfo {
     unsigned long long bytes;            /* size of each buffer */
-    unsigned long long candidate_bytes;  /* physical memory the scan held at its end (<= the byte budget + 1 GiB) */
+    unsigned long long candidate_bytes;  /* physical memory the scan held at its end (<= max(byte budget + 1 GiB, bytes)) */
     int candidates;                      /* mixed policy: GiB chunks scanned; candidates policy: blocks probed; 0: plain */
     int chosen;                          /* mixed policy: GiB of mixed memory in the output; candidates policy: index of the block kept */
     int good_enough;                     /* 1: the output is all mixed memory (mixed) / met the 2.3 x read-time criterion (candidates) */
@@ -161,6 +161,8 @@ int smfft_memcpy_d2h(void* h_dst, const void* d_src, unsigned long long bytes);
 int smfft_memcpy_d2d(void* d_dst, const void* d_src, unsigned long long bytes);
 int smfft_memset(void* d_ptr, int value, unsigned long long bytes);
 int smfft_synchronize(void);
+/* free and total device memory of the current device as hipMemGetInfo reports them (what FFT_init prints, CT/FFT-GPU-32bit.cu:766, 839) */
+int smfft_mem_info(unsigned long long* free_bytes, unsigned long long* total_bytes);
 
 #ifdef __cplusplus
 }

@@ -38,6 +38,11 @@ namespace smfft {
 static __device__ const float2 twiddle_4096[4096] = {
 #include "smfft_twiddles.inc"
 };
+// the same values for compile-time use (TwiddleRows below)
+struct alignas(8) TwiddleValue { float x, y; };
+static constexpr TwiddleValue twiddle_values[4096] = {
+#include "smfft_twiddles.inc"
+};
 
 // ------------------------------------------------------------------------------------------------
 // PAD = false: the exchange layouts without their bank-conflict padding, so that a transform fits
@@ -233,12 +238,40 @@ struct SmallDft<1, STRIDE, DIR> {
 // ------------------------------------------------------------------------------------------------
 // Twiddles a thread keeps in registers.  u = thread index inside its FFT (0 .. T-1).
 // ------------------------------------------------------------------------------------------------
+// The register twiddles of Engine<N> as ROWS: one row of T values per register slot, so that the threads of an FFT
+// read consecutive addresses.  Picked straight out of twiddle_4096, slot s of thread u is element u * q1 * 4096/N: a
+// gather that touches 30-60 cache lines per load instruction -- ten times the requests of the tile a wave then moves,
+// on the path every global access takes.  With 12288 workgroups per launch (12 generations per workgroup slot) that
+// was a FIXED 45-55 us per launch of the external kernels, whatever the batch (N = 1024, 4 / 2 / 1 GiB each way:
+// 0.80 / 0.78 / 0.71 of the HBM peak before, 0.815 / 0.82 / 0.82 after; tools/size_effect.py).
+// Same values, same rounding: the rows are built at compile time from the table.
+template <int N>
+struct TwiddleRows {
+    using G = Geometry<N>;
+    TwiddleValue w1[16 * G::T];                        // [b*R1 + q1][u] = W_N^{(u + T*b) * q1}
+    TwiddleValue wm[(G::RM > 1 ? G::RM : 1) * 16];     // [q2][t2]       = W_{T1}^{t2 * q2}
+    constexpr TwiddleRows() : w1{}, wm{} {
+        for (int b = 0; b < G::B1; ++b)
+            for (int q1 = 0; q1 < G::R1; ++q1)
+                for (int u = 0; u < G::T; ++u) w1[(b * G::R1 + q1) * G::T + u] = twiddle_values[((u + G::T * b) * q1 * (4096 / N)) & 4095];
+        for (int q2 = 0; q2 < (G::RM > 1 ? G::RM : 1); ++q2)
+            for (int t2 = 0; t2 < 16; ++t2) wm[q2 * 16 + t2] = twiddle_values[(t2 * q2 * (4096 / G::T1)) & 4095];
+    }
+};
+template <int N>
+static __device__ const TwiddleRows<N> twiddle_rows = TwiddleRows<N>();
+
 template <int N, int DIR>
 struct Twiddles {
     using G = Geometry<N>;
     float2 w1[16];                         // [b*R1 + q1] = W_N^{(u + T*b) * q1}
     float2 wm[G::RM > 1 ? G::RM : 1];      // [q2] = W_{T1}^{t2 * q2}
+    __device__ static __forceinline__ float2 from_row(const TwiddleValue* p) {
+        const TwiddleValue v = *p;
+        return make_float2(v.x, DIR ? -v.y : v.y);
+    }
     __device__ __forceinline__ void init(int u, int t2) {
+#if SMFFT_TW_HW
 #pragma unroll
         for (int b = 0; b < G::B1; ++b)
 #pragma unroll
@@ -247,6 +280,16 @@ struct Twiddles {
 #pragma unroll
             for (int q2 = 1; q2 < G::RM; ++q2) wm[q2] = twiddle<DIR>(t2 * q2 * (4096 / G::T1));
         }
+#else
+#pragma unroll
+        for (int b = 0; b < G::B1; ++b)
+#pragma unroll
+            for (int q1 = 1; q1 < G::R1; ++q1) w1[b * G::R1 + q1] = from_row(&twiddle_rows<N>.w1[(b * G::R1 + q1) * G::T + u]);
+        if constexpr (G::RM > 1) {
+#pragma unroll
+            for (int q2 = 1; q2 < G::RM; ++q2) wm[q2] = from_row(&twiddle_rows<N>.wm[q2 * 16 + t2]);
+        }
+#endif
     }
 };
 

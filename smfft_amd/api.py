@@ -63,6 +63,7 @@ _SIGS = {
     "smfft_memcpy_d2d": (_i, [_vp, _vp, _ull]),
     "smfft_memset": (_i, [_vp, _i, _ull]),
     "smfft_synchronize": (_i, []),
+    "smfft_mem_info": (_i, [ctypes.POINTER(_ull), ctypes.POINTER(_ull)]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _f = getattr(lib, _name)  # AttributeError here = the library does not export what smfft.h declares

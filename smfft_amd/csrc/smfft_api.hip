@@ -266,9 +266,9 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
     const float in_write_ms = probe_ms(nullptr, const_cast<void*>(in), bytes < kChunkBytes ? bytes : kChunkBytes, 3) * (float)((double)kChunkBytes / (double)(bytes < kChunkBytes ? bytes : kChunkBytes));
     auto typical = [&] {
         std::vector<float> t;
-        for (auto& c : chunks) t.push_back(c.write_ms);
+        for (auto& c : chunks) if (c.write_ms < 1e29f) t.push_back(c.write_ms);
         std::sort(t.begin(), t.end());
-        const float med = t.size() < 3 ? t.back() : t[t.size() / 2];
+        const float med = t.empty() ? 0.f : (t.size() < 3 ? t.back() : t[t.size() / 2]);
         return med > in_write_ms ? med : in_write_ms;
     };
     auto mixed_handles = [&] {
@@ -314,6 +314,22 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
     if (!api_ok || chunks.empty()) {
         for (auto& c : chunks) for (auto h : c.hs) (void)hipMemRelease(h);
         return false;
+    }
+    // a scan that ended on its budget may hold less memory than the output needs: the rest is created unprobed
+    {
+        size_t total = 0;
+        for (auto& c : chunks) total += c.hs.size();
+        if (total < need) {
+            Chunk c;
+            c.write_ms = 1e30f;                                    // counts as ordinary, used last
+            for (size_t h = total; h < need; ++h) {
+                hipMemGenericAllocationHandle_t handle;
+                if (hipMemCreate(&handle, kHandleBytes, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+                c.hs.push_back(handle);
+            }
+            created += c.hs.size() * kHandleBytes;
+            chunks.push_back(std::move(c));
+        }
     }
     // mixed chunks first (fastest writes first), then the last ordinary chunks scanned
     const float typ = typical();
@@ -742,6 +758,13 @@ int smfft_memcpy_d2h(void* h_dst, const void* d_src, unsigned long long bytes) {
 int smfft_memcpy_d2d(void* d_dst, const void* d_src, unsigned long long bytes) { return (int)hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice); }
 int smfft_memset(void* d_ptr, int value, unsigned long long bytes) { return (int)hipMemset(d_ptr, value, bytes); }
 int smfft_synchronize(void) { return (int)hipDeviceSynchronize(); }
+int smfft_mem_info(unsigned long long* free_bytes, unsigned long long* total_bytes) {
+    size_t f = 0, t = 0;
+    const hipError_t rc = hipMemGetInfo(&f, &t);
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return (int)rc;
+}
 
 }  // extern "C"
 

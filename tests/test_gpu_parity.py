@@ -533,6 +533,15 @@ def test_malloc_pair_bounded_search(sm, monkeypatch):
         use(a, b)
         assert sm.lib.smfft_free_pair(a.value) == 0
         assert _settled_usage(sm, free0, 256 << 20) <= (256 << 20)
+    # a budget smaller than the output: the scan's one chunk + the rest created unprobed, still one VMM-assembled buffer
+    monkeypatch.setenv("SMFFT_PAIR_POLICY", "mixed")
+    assert sm.lib.smfft_malloc_pair(3 * nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
+    info = sm.last_pair_info()
+    assert info["candidates"] == 2 and info["candidate_bytes"] == 3 * nbytes, info
+    sm.lib.smfft_memset(b.value + 3 * nbytes - 4096, 0, 4096)                  # the last page is mapped
+    use(a, b)
+    assert sm.lib.smfft_free_pair(a.value) == 0
+    assert _settled_usage(sm, free0, 256 << 20) <= (256 << 20)
     monkeypatch.delenv("SMFFT_PAIR_BUDGET_FRAC")
     monkeypatch.delenv("SMFFT_PAIR_POLICY")
     # an odd size (not a multiple of the 8 MiB handles): the whole range is usable up to the last byte
@@ -556,8 +565,10 @@ def test_malloc_pair_bounded_search(sm, monkeypatch):
 
 
 def _free_bytes(sm):
-    import torch
-    return torch.cuda.mem_get_info()[0]
+    import ctypes
+    free, total = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+    assert sm.lib.smfft_mem_info(ctypes.byref(free), ctypes.byref(total)) == 0
+    return free.value
 
 
 def _settled_usage(sm, free0, limit):
