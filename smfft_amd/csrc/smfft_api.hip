@@ -42,8 +42,14 @@ int ct_multiple_slots(int FFT_size, int nFFTs) {
     return nFFTs / SMFFT_NREUSES;
 }
 
-// 1: the external kernels run their rate limiter for this output buffer (defined below, next to the pair table)
-int pacing_for(const void* d_output);
+// K > 0: the external kernels run their rate limiter with K loads for this output buffer: k_ordinary when it is ordinary
+// memory, k_mixed when it is one of the mixed outputs smfft_malloc_pair built (defined below, next to the pair table)
+int pacing_for(const void* d_output, int k_ordinary, int k_mixed);
+// serialised LDS loads between a wave's loads and stores, by transform length (sweeps on the same buffers:
+// tools/pacing_sweep.py, profiles/r02_pacing_sweep_plain.txt / _pair.txt)
+struct Pacing { int ordinary, mixed; };
+Pacing c2c_pacing(int N) { return {N <= 1024 ? 12 : 8, N <= 2048 ? 4 : 0}; }
+Pacing rc_pacing(int L) { return {L == 512 ? 6 : L == 1024 ? 8 : 0, 0}; }
 
 using smfft::launch_ct;
 using smfft::launch_rc;
@@ -51,7 +57,7 @@ using smfft::launch_st;
 
 // returns -1 for an unsupported length (nothing launched), else the launch status
 int dispatch_ct(const float2* in, float2* out, int N, int count, int inverse, int reorder, int path, hipStream_t st) {
-    const int pace = pacing_for(out);
+    const int pace = pacing_for(out, c2c_pacing(N).ordinary, c2c_pacing(N).mixed);
     switch (N) {
         case 32:   return launch_ct<32>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, pace, st);
         case 64:   return launch_ct<64>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, pace, st);
@@ -65,7 +71,7 @@ int dispatch_ct(const float2* in, float2* out, int N, int count, int inverse, in
     }
 }
 int dispatch_st(const float2* in, float2* out, int N, int count, int path, hipStream_t st) {
-    const int pace = pacing_for(out);
+    const int pace = pacing_for(out, c2c_pacing(N).ordinary, c2c_pacing(N).mixed);
     switch (N) {
         case 32:   return launch_st<32>(in, out, count, path, g_grid_cap, g_nreuses, pace, st);
         case 64:   return launch_st<64>(in, out, count, path, g_grid_cap, g_nreuses, pace, st);
@@ -80,11 +86,12 @@ int dispatch_st(const float2* in, float2* out, int N, int count, int path, hipSt
 }
 // FFT_size is the REAL length; the kernels are instantiated on the complex length L = FFT_size/2 (RC:404-428)
 int dispatch_rc(const float2* in, float2* out, int FFT_size, int count, int inverse, int path, hipStream_t st) {
+    const int pace = pacing_for(out, rc_pacing(FFT_size / 2).ordinary, rc_pacing(FFT_size / 2).mixed);
     switch (FFT_size) {
-        case 512:  return launch_rc<256>(in, out, count, inverse, path, g_grid_cap, g_nreuses, st);
-        case 1024: return launch_rc<512>(in, out, count, inverse, path, g_grid_cap, g_nreuses, st);
-        case 2048: return launch_rc<1024>(in, out, count, inverse, path, g_grid_cap, g_nreuses, st);
-        case 4096: return launch_rc<2048>(in, out, count, inverse, path, g_grid_cap, g_nreuses, st);
+        case 512:  return launch_rc<256>(in, out, count, inverse, path, g_grid_cap, g_nreuses, pace, st);
+        case 1024: return launch_rc<512>(in, out, count, inverse, path, g_grid_cap, g_nreuses, pace, st);
+        case 2048: return launch_rc<1024>(in, out, count, inverse, path, g_grid_cap, g_nreuses, pace, st);
+        case 4096: return launch_rc<2048>(in, out, count, inverse, path, g_grid_cap, g_nreuses, pace, st);
         default:   return -1;
     }
 }
@@ -143,18 +150,19 @@ PairRec g_pair_cache;                  // SMFFT_PAIR_CACHE=1 only: the last sear
 std::mutex g_pairs_mutex;              // shared by the per-GPU host threads of a multi-GPU driver
 SmfftPairInfo g_last_pair_info = {};
 
-// Pacing per launch (smfft_kernels.hpp, vmem_throttle): on when the kernel writes into ordinary memory, off when the
-// output is one of the mixed buffers smfft_malloc_pair built (the paced kernels are 1-2.5 % faster into the former and
-// 1-3.5 % slower into the latter, profiles/r02_ab_pacing_*.txt).  SMFFT_PACING=0 / 1 forces it.
-int pacing_for(const void* d_output) {
-    static const int forced = [] { const char* e = getenv("SMFFT_PACING"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
-    if (forced >= 0) return forced;
+// Pacing per launch (smfft_kernels.hpp, vmem_throttle): K serialised loads between a wave's loads and its stores.  Into
+// ordinary memory the paced kernels are 2-8 % faster, most when input and output lie in different memory classes (K = 12 for N <= 1024, 8 above; R2C / C2R of real N = 1024 / 2048:
+// 6 / 8), into the mixed outputs smfft_malloc_pair builds a light K = 4 is worth 0.3-1.6 % and more costs
+// (profiles/r02_pacing_sweep_*.txt).  SMFFT_PACING=K forces K loads for every length (0: off); the variable is read at
+// every launch so that one process can sweep it.
+int pacing_for(const void* d_output, int k_ordinary, int k_mixed) {
+    if (const char* e = getenv("SMFFT_PACING")) return atoi(e) > 0 ? atoi(e) : 0;
     std::lock_guard<std::mutex> lock(g_pairs_mutex);
     for (auto& kv : g_pairs) {
         const PairRec& r = kv.second;
-        if (r.va_bytes && (const char*)d_output >= (const char*)r.b && (const char*)d_output < (const char*)r.b + r.va_bytes) return r.mixed ? 0 : 1;
+        if (r.va_bytes && (const char*)d_output >= (const char*)r.b && (const char*)d_output < (const char*)r.b + r.va_bytes) return r.mixed ? k_mixed : k_ordinary;
     }
-    return 1;
+    return k_ordinary;
 }
 
 constexpr double kGoodRatio = 2.30;    // candidates policy: mixed targets copy in 2.2-2.3 x the pure read time; other class 2.5; same class 2.6
@@ -572,7 +580,7 @@ int smfft_launch(int family, int path, const void* d_input, void* d_output, int 
 
 int smfft_copy_launch(const void* d_input, void* d_output, long long n_float2, void* hip_stream) {
     read_env();
-    return smfft::launch_stream_copy((const float2*)d_input, (float2*)d_output, (long)n_float2, g_grid_cap, pacing_for(d_output), (hipStream_t)hip_stream);
+    return smfft::launch_stream_copy((const float2*)d_input, (float2*)d_output, (long)n_float2, g_grid_cap, pacing_for(d_output, 16, 0), (hipStream_t)hip_stream);
 }
 
 // ---- L3 wrappers ---------------------------------------------------------------------------------

@@ -81,12 +81,12 @@ int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int p
 
 #if SMFFT_N >= 256 && SMFFT_N <= 2048
 template <>
-int launch_rc<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int path, int grid_cap, int nreuses, hipStream_t stream) {
+int launch_rc<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int path, int grid_cap, int nreuses, int pace, hipStream_t stream) {
     if (count <= 0) return 0;
     dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
     if (path == 0) {
-        if (!inverse) FFT_GPU_R2C_C2R_external<ST_CLASS, FFT_forward><<<grid, block, 0, stream>>>(d_input, d_output, count);
-        else          FFT_GPU_R2C_C2R_external<ST_CLASS, FFT_inverse><<<grid, block, 0, stream>>>(d_input, d_output, count);
+        if (!inverse) FFT_GPU_R2C_C2R_external<ST_CLASS, FFT_forward><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
+        else          FFT_GPU_R2C_C2R_external<ST_CLASS, FFT_inverse><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
     } else {
         grid = dim3(grid_for(count, Geometry<SMFFT_N>::kCompactFfts, grid_cap));
         block = dim3(Geometry<SMFFT_N>::kCompactThreads);

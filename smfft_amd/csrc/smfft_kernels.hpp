@@ -97,25 +97,20 @@ __device__ __forceinline__ void lds_to_wave_chunk(float2* __restrict__ gwave, co
 // for N = 1024 / 4096 (every K measured equal or worse there).
 // (Round 1 had two more forms that did the same thing through `volatile` generic-pointer reads of LDS -- i.e. through
 //  how hipcc happens to lower them; they measured equal to this explicit one, profiles/r02_ab_pacing_plain.txt, and are gone.)
-template <int K>
-__device__ __forceinline__ void vmem_throttle(const float2* rows, float2 (&r)[16]) {
+__device__ __forceinline__ void vmem_throttle(const float2* rows, float2 (&r)[16], int k) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) asm volatile("" : "+v"(r[c].x), "+v"(r[c].y));   // all global loads have arrived
-#pragma unroll
-    for (int c = 0; c < K; ++c) {
+    for (int c = 0; c < k; ++c) {                                                  // k is a kernel argument: a scalar loop
         const float2* q = rows + (threadIdx.x & 63) + 64 * (c & 15);
         v2f d;
         asm volatile("flat_load_dwordx2 %0, %1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" : "=v"(d) : "v"(q) : "memory");
     }
 }
-template <int N>
-constexpr int throttle_loads() { return N <= SMFFT_STAGED_MAX_N ? 16 : (N == 256 || N == 512) ? 8 : N == 2048 ? 6 : 0; }
 
 template <int N, int DIR, int REORDER>
 __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nFFTs, int pace, float2* s) {
     using G = Geometry<N>;
     constexpr bool kStaged = (N <= SMFFT_STAGED_MAX_N);
-    constexpr int kThrottle = throttle_loads<N>();
     constexpr int kFftsPerWave = (N <= 1024) ? 1024 / N : 1;
     Engine<N, DIR, REORDER> eng;
     eng.init(threadIdx.x);
@@ -133,7 +128,7 @@ __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_i
             fft_sync<false>();
             eng.load_lds(r, sf);
             fft_sync<false>();
-            if constexpr (kThrottle > 0) { if (pace) vmem_throttle<kThrottle>(swave, r); }   // kernel argument: wave-uniform branch
+            if (pace) vmem_throttle(swave, r, pace);   // kernel argument: wave-uniform branch
             eng.transform(r, sf);
             fft_sync<false>();
             eng.store_lds(r, sf);
@@ -143,7 +138,7 @@ __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_i
         } else {
             eng.load_global(r, d_input + (active ? f : 0) * N);
             if (G::kMultiWave) __syncthreads();   // the previous tile's exchange reads are complete
-            if constexpr (kThrottle > 0) { if (pace) vmem_throttle<kThrottle>(s + (threadIdx.x >> 6) * 1088, r); }
+            if (pace) vmem_throttle(s + (threadIdx.x >> 6) * 1088, r, pace);
             eng.transform(r, sf);
             eng.store_global(r, d_output + f * N, active);
         }
@@ -408,7 +403,7 @@ struct HermitianRegisters {
 #define SMFFT_RC_PREFETCH 0
 #endif
 template <int L, int DIR>
-__device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nFFTs, float2* s) {
+__device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nFFTs, int pace, float2* s) {
     using G = Geometry<L>;
     Engine<L, DIR, 1> eng;
     eng.init(threadIdx.x);
@@ -437,6 +432,7 @@ __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__
             for (int c = 0; c < 16; ++c) r[c] = nx[c];
 #else
             eng.load_global(r, d_input + (active ? f : 0) * L);
+            if (pace) vmem_throttle(s + (threadIdx.x >> 6) * 1088, r, pace);
             if (DIR == 1) herm.apply(r);
             eng.transform(r, sf);
             if (DIR == 0) herm.apply(r);
@@ -445,6 +441,7 @@ __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__
         } else if (DIR == 0) {
             eng.load_global(r, d_input + (active ? f : 0) * L);
             if (G::kMultiWave) __syncthreads();
+            if (pace) vmem_throttle(s + (threadIdx.x >> 6) * 1088, r, pace);
             eng.transform(r, sf);
             fft_sync<G::kMultiWave>();
             eng.store_lds(r, sf);
@@ -456,6 +453,7 @@ __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__
         } else {
             eng.load_global(r, d_input + (active ? f : 0) * L);
             if (G::kMultiWave) __syncthreads();
+            if (pace) vmem_throttle(s + (threadIdx.x >> 6) * 1088, r, pace);
             eng.store_lds(r, sf);
             fft_sync<G::kMultiWave>();
             hermitian_pass<L, 1>(sf, eng.u);
@@ -506,7 +504,7 @@ __global__ void __launch_bounds__(256) SMFFT_stream_copy(const float2* __restric
         float2 r[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) r[c] = smfft::gload(g + 64 * c);
-        if (pace) smfft::vmem_throttle<16>(s_rows + wave * 1088, r);   // the same rate limiter as the FFT kernels (16 for a bare copy)
+        if (pace) smfft::vmem_throttle(s_rows + wave * 1088, r, pace);   // the same rate limiter as the FFT kernels
 #pragma unroll
         for (int c = 0; c < 16; ++c) smfft::gstore(o + 64 * c, r[c]);
     }
@@ -598,9 +596,9 @@ __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_length) FFT_GPU_multiple(
 #define SMFFT_RC_BOUNDS(L) __launch_bounds__(256)
 #endif
 template <class const_params, class const_direction>
-__global__ void SMFFT_RC_BOUNDS(const_params::fft_length) FFT_GPU_R2C_C2R_external(const float2* d_input, float2* d_output, int nFFTs) {
+__global__ void SMFFT_RC_BOUNDS(const_params::fft_length) FFT_GPU_R2C_C2R_external(const float2* d_input, float2* d_output, int nFFTs, int pace) {
     __shared__ float2 s_input[4352];
-    smfft::r2c_c2r_external_body<const_params::fft_length, const_direction::fft_direction>(d_input, d_output, nFFTs, s_input);
+    smfft::r2c_c2r_external_body<const_params::fft_length, const_direction::fft_direction>(d_input, d_output, nFFTs, pace, s_input);
 }
 template <class const_params, class const_direction>
 __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_length) FFT_GPU_R2C_C2R_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {

@@ -8,7 +8,7 @@ namespace smfft {
 
 // path: 0 = external (count = number of FFTs), 1 = multiple (count = number of FFT slots, each
 // transformed nreuses times in LDS; the benchmark entry points pass NREUSES = 100).  grid_cap <= 0: one workgroup per 4096-element tile.
-// pace != 0: the external kernels run their rate limiter (smfft_kernels.hpp, vmem_throttle); the host API decides it per launch.
+// pace = K > 0: the external kernels run their rate limiter with K serialised loads (smfft_kernels.hpp, vmem_throttle); the host API decides it per launch.
 // Returns hipSuccess (0) or the launch error.
 template <int N>
 int launch_ct(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, int grid_cap, int nreuses, int pace, hipStream_t stream);
@@ -17,7 +17,7 @@ template <int N>
 int launch_st(const float2* d_input, float2* d_output, int count, int path, int grid_cap, int nreuses, int pace, hipStream_t stream);
 // R2C (inverse = 0) / C2R (inverse = 1) of real length 2L, L = 256..2048.
 template <int L>
-int launch_rc(const float2* d_input, float2* d_output, int count, int inverse, int path, int grid_cap, int nreuses, hipStream_t stream);
+int launch_rc(const float2* d_input, float2* d_output, int count, int inverse, int path, int grid_cap, int nreuses, int pace, hipStream_t stream);
 
 // calibration copy of n_float2 elements (multiple of 4096) with the external kernels' access shape
 int launch_stream_copy(const float2* d_input, float2* d_output, long n_float2, int grid_cap, int pace, hipStream_t stream);

@@ -46,6 +46,34 @@ __global__ void __launch_bounds__(256) copy_static(const v2f* __restrict__ in, v
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) tile_work(in, out, tile, s, k);
 }
 
+// single-wave workgroups: every wave is its own workgroup and strides over 8 KiB rows
+__global__ void __launch_bounds__(64) copy_static_wave(const v2f* __restrict__ in, v2f* __restrict__ out, long nrows, float k) {
+    __shared__ v2f s[1088];
+    const int lane = threadIdx.x;
+    for (long row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const v2f* g = in + row * 1024 + lane;
+        v2f* o = out + row * 1024 + lane;
+        v2f r[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) r[c] = __builtin_nontemporal_load(g + 64 * c);
+#pragma unroll
+        for (int f = 0; f < 16; ++f)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                r[c].x = __builtin_fmaf(r[c].x, k, r[(c + 1) & 15].y);
+                r[c].y = __builtin_fmaf(r[c].y, k, r[(c + 5) & 15].x);
+            }
+        v2f* q = s + lane;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) q[64 * c] = r[c];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) r[c] = q[64 * (15 - c) + ((63 - lane) - lane)];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) __builtin_nontemporal_store(r[c], o + 64 * c);
+    }
+}
+
 // counters[0] = next tile, counters[1] = workgroups done
 __global__ void __launch_bounds__(256) copy_dynamic(const v2f* __restrict__ in, v2f* __restrict__ out, long ntiles, float k, unsigned* counters) {
     __shared__ v2f s[4352];
@@ -136,7 +164,7 @@ int main() {
     v2f* out = (v2f*)pb;
     struct Cfg { const char* name; int kind; int grid; };
     const Cfg cfgs[] = {{"static 12288", 0, 12288}, {"static 4096", 0, 4096}, {"static 1024", 0, 1024}, {"static 24576", 0, 24576},
-                        {"dynamic 1024", 1, 1024}, {"dynamic 768", 1, 768}, {"dynamic 2048", 1, 2048}, {"dynamic-wave 1024", 2, 1024}, {"dynamic-wave 768", 2, 768}};
+                        {"dynamic 1024", 1, 1024}, {"static-wave 24576", 3, 24576}, {"static-wave 49152", 3, 49152}, {"static-wave 98304", 3, 98304}, {"static-wave 196608", 3, 196608}};
     for (int round = 0; round < 2; ++round)
         for (const Cfg& c : cfgs) {
             float t[3];
@@ -145,12 +173,13 @@ int main() {
                 t[s] = median_ms([&] {
                     if (c.kind == 0) copy_static<<<c.grid, 256>>>(in, out, ntiles, 0.999f);
                     else if (c.kind == 1) copy_dynamic<<<c.grid, 256>>>(in, out, ntiles, 0.999f, counters);
-                    else copy_dynamic_wave<<<c.grid, 256>>>(in, out, ntiles * 4, 0.999f, counters);
+                    else if (c.kind == 2) copy_dynamic_wave<<<c.grid, 256>>>(in, out, ntiles * 4, 0.999f, counters);
+                    else copy_static_wave<<<c.grid, 64>>>(in, out, ntiles * 4, 0.999f);
                 });
             }
             const float k = (t[2] - t[1]) / 2.f, fixed = t[1] - 2.f * k;
             printf("%-18s 1 GiB %.4f  2 GiB %.4f  4 GiB %.4f ms | per GiB %.4f ms (%.3f of peak)  fixed %.1f us | 4 GiB frac %.3f  2 GiB frac %.3f\n", c.name, t[0], t[1], t[2], k,
-                   2.147483648 / k / 8000.0, fixed * 1e3, 8.589934592 / t[2] / 8000.0, 4.294967296 / t[1] / 8000.0);
+                   2.147483648 / k / 8.0, fixed * 1e3, 8.589934592 / t[2] / 8.0, 4.294967296 / t[1] / 8.0);
         }
     unsigned h[2];
     CK(hipMemcpy(h, counters, 8, hipMemcpyDeviceToHost));
