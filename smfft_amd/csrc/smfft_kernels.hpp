@@ -87,14 +87,11 @@ __device__ __forceinline__ void lds_to_wave_chunk(float2* __restrict__ gwave, co
 // (profiles/r02_placement_pmc.json, study_copy vs study_copy_paced, same buffers): L2 -> DRAM credit stalls fall 8-10 x
 // (TCC_EA0_WRREQ_DRAM_CREDIT_STALL 1.8e7 -> 1.7e6, RDREQ 6.1e6 -> 0.8e6 per launch), TCC_TAG_STALL 6 x, the write queue
 // depth (TCC_EA0_WRREQ_LEVEL) 25 %, the L1 -> L2 read / write latencies 15 % / 27 %: the bursts each wave sends are
-// spread out, the queues in front of the DRAM stop overflowing.  Whether that PAYS depends on the write target
-// (profiles/r02_ab_pacing_*.txt): into ordinary memory (a caller's plain hipMalloc buffer: writes 5.6 TB/s at best)
-// the paced kernels are 1-2.5 % faster; into the mixed memory smfft_malloc_pair builds its outputs from (6.9 TB/s)
-// they are 1-3.5 % slower.  So the launcher decides per launch: paced unless the output buffer is one of the library's
-// mixed outputs (SMFFT_PACING=0 / 1 forces it).  K per length as measured in round 1 on ordinary placements (tools/
-// microbench/pacing.hip, profiles/r01_pacing.txt: 16 for a bare copy; the FFT kernels, which already spend time between
-// their loads and stores, want fewer): 16 for the LDS-staged lengths N <= 128, 8 for N = 256 / 512, 6 for N = 2048, none
-// for N = 1024 / 4096 (every K measured equal or worse there).
+// spread out, the queues in front of the DRAM stop overflowing.  How much of it PAYS depends on the write target, so K
+// is a kernel argument the host API decides per launch from the output pointer (smfft_api.hip, pacing_for; sweeps on
+// the same buffers: tools/pacing_sweep.py, profiles/r02_pacing_sweep_*.txt): into ordinary memory (a caller's plain
+// hipMalloc buffer: writes 5.6 TB/s at best) K = 12 for N <= 1024 and 8 above is worth 2-8 %; into the mixed memory
+// smfft_malloc_pair builds its outputs from (6.9 TB/s) K = 4 is worth 0.3-1.6 % and more costs.  SMFFT_PACING=K forces it.
 // (Round 1 had two more forms that did the same thing through `volatile` generic-pointer reads of LDS -- i.e. through
 //  how hipcc happens to lower them; they measured equal to this explicit one, profiles/r02_ab_pacing_plain.txt, and are gone.)
 __device__ __forceinline__ void vmem_throttle(const float2* rows, float2 (&r)[16], int k) {
@@ -277,7 +274,12 @@ struct HermitianRegisters {
     static constexpr int T = L / 16;
     // used by the external kernels of real N = 1024 and 2048 (measured: 2048 R2C +2.6 %, C2R +3.0 %; 1024 0 / +1.8 %;
     // 512 -1.8 / -0.7 %: LDS form there; in-LDS path 1-5 % slower with it: LDS form there too)
-    static constexpr bool kEnabled = SMFFT_RC_REGISTERS && (L == 512 || L == 1024);
+    // kFromLds: the partner values come out of the FFT's LDS region (the registers are written there in natural order
+    // first) instead of from ds_bpermute -- for the C2R of L = 2048, where the partner thread sits in another wave: one
+    // LDS write + read of the data instead of the LDS-resident merge's two (C2R +3 %; the R2C of that length measured
+    // 1.3 % SLOWER this way and L = 256 unchanged, so both keep the LDS form)
+    static constexpr bool kFromLds = (L == 2048 && DIR == 1);
+    static constexpr bool kEnabled = SMFFT_RC_REGISTERS && (L == 512 || L == 1024 || kFromLds);
     float2 wu;          // (-+i / 2) * W_{2L}^u (W conjugated, +i, for DIR = 1): see combine
     int partner_addr;   // byte address of the partner lane for ds_bpermute
     bool first;         // u == 0
@@ -353,7 +355,7 @@ struct HermitianRegisters {
         }
     }
 #if SMFFT_RC_INPLACE
-    __device__ __forceinline__ void apply(float2 (&r)[16]) const {
+    __device__ __forceinline__ void apply(float2 (&r)[16], float2* = nullptr) const {
         float2 carried = make_float2(0.f, 0.f);   // step 0 of thread 0 does not use it (packed DC / Nyquist)
         apply_pair<0>(r, carried, fetch<0>(r));
     }
@@ -363,7 +365,8 @@ struct HermitianRegisters {
     // (SMFFT_RC_INPLACE=1: 93-113 VGPRs, 4 waves per SIMD) on the same buffers, profiles/r02_ab_rc.txt / r02_ab_ext_pair.txt:
     // this form is 0.6-2 % FASTER (config 4: R2C 0.692 vs 0.697 ms, C2R 0.679 vs 0.693 ms) -- these kernels are bound by
     // what one wave keeps in flight, not by how many waves there are.
-    __device__ __forceinline__ void apply(float2 (&r)[16]) const {
+    // sf: the FFT's LDS region (kFromLds only; free on entry, the caller orders its later re-use)
+    __device__ __forceinline__ void apply(float2 (&r)[16], float2* sf = nullptr) const {
         constexpr float c32[16] = {1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f, 0.55557023301960229f,
                                    0.38268343236508984f, 0.19509032201612833f, 0.f, -0.19509032201612819f, -0.38268343236508973f, -0.55557023301960196f,
                                    -0.70710678118654746f, -0.83146961230254535f, -0.92387953251128674f, -0.98078528040323043f};
@@ -371,13 +374,27 @@ struct HermitianRegisters {
                                    0.92387953251128674f, 0.98078528040323043f, 1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254546f,
                                    0.70710678118654757f, 0.55557023301960218f, 0.38268343236508989f, 0.19509032201612861f};
         float2 B[16];
+        if constexpr (kFromLds) {
+            const int u = threadIdx.x % T;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float2 src = r[15 - q];
-            const float bx = __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(src.x)));
-            const float by = __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(src.y)));
-            const float2 own = r[(16 - q) & 15];
-            B[q] = first ? own : make_float2(bx, by);
+            for (int q = 0; q < 16; ++q) sf[u + T * q] = r[q];
+            fft_sync<(T > 64)>();
+            const float2* partner = sf + ((T - u) % T);     // x[L - (u + T*q)] = x[(T - u) + T*(15 - q)], u > 0
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float2 own = r[(16 - q) & 15];
+                const float2 got = partner[T * (15 - q)];
+                B[q] = first ? own : got;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float2 src = r[15 - q];
+                const float bx = __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(src.x)));
+                const float by = __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(src.y)));
+                const float2 own = r[(16 - q) & 15];
+                B[q] = first ? own : make_float2(bx, by);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -432,16 +449,22 @@ __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__
             for (int c = 0; c < 16; ++c) r[c] = nx[c];
 #else
             eng.load_global(r, d_input + (active ? f : 0) * L);
+            if (G::kMultiWave) __syncthreads();   // the previous tile's LDS reads are complete
             if (pace) vmem_throttle(s + (threadIdx.x >> 6) * 1088, r, pace);
-            if (DIR == 1) herm.apply(r);
+            if (DIR == 1) {
+                herm.apply(r, sf);
+                if (HermitianRegisters<L, DIR>::kFromLds) fft_sync<G::kMultiWave>();   // partner reads done before the exchanges write
+            }
             eng.transform(r, sf);
-            if (DIR == 0) herm.apply(r);
+            if (DIR == 0) {
+                if (HermitianRegisters<L, DIR>::kFromLds) fft_sync<G::kMultiWave>();   // last-pass reads done before the registers are written over them
+                herm.apply(r, sf);
+            }
             eng.store_global(r, d_output + f * L, active);
 #endif
         } else if (DIR == 0) {
             eng.load_global(r, d_input + (active ? f : 0) * L);
             if (G::kMultiWave) __syncthreads();
-            if (pace) vmem_throttle(s + (threadIdx.x >> 6) * 1088, r, pace);
             eng.transform(r, sf);
             fft_sync<G::kMultiWave>();
             eng.store_lds(r, sf);
@@ -453,7 +476,6 @@ __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__
         } else {
             eng.load_global(r, d_input + (active ? f : 0) * L);
             if (G::kMultiWave) __syncthreads();
-            if (pace) vmem_throttle(s + (threadIdx.x >> 6) * 1088, r, pace);
             eng.store_lds(r, sf);
             fft_sync<G::kMultiWave>();
             hermitian_pass<L, 1>(sf, eng.u);
