@@ -438,6 +438,39 @@ def test_in_place_and_grid_cap_invariance(sm, oracle_lib):
         assert rc == 0 and np.array_equal(buf.to_host(np.complex64, x.shape).view(np.uint32), want.view(np.uint32))
 
 
+def test_pacing_count_does_not_change_results(sm, monkeypatch):
+    """The external kernels' rate limiter (K discarded LDS loads per tile, a kernel argument chosen per launch) is
+    invisible in the results: SMFFT_PACING = 0, 5, 12, 33 give bit-identical outputs for C2C, Stockham, R2C and C2R."""
+    rng = np.random.default_rng(11)
+    outs = {}
+    for k in ("0", "5", "12", "33"):
+        monkeypatch.setenv("SMFFT_PACING", k)
+        got = []
+        for n in (32, 256, 1024, 2048, 4096):
+            x = (rng.random((37, n), dtype=np.float32) - 0.5 + 1j * rng.random((37, n), dtype=np.float32)).astype(np.complex64) if k == "0" else outs["x", n]
+            outs["x", n] = x
+            got.append(sm.c2c(x, False, True))
+            got.append(sm.c2c(x, True, False))
+        for n in R2C_SIZES:
+            xr = rng.random((21, n), dtype=np.float32) if k == "0" else outs["xr", n]
+            outs["xr", n] = xr
+            spec = sm.r2c(xr)
+            got.append(spec)
+            got.append(sm.c2r(spec))
+        outs[k] = got
+    for k in ("5", "12", "33"):
+        for a, b in zip(outs["0"], outs[k]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), k
+
+
+def test_mem_info(sm):
+    import ctypes
+    free, total = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+    assert sm.lib.smfft_mem_info(ctypes.byref(free), ctypes.byref(total)) == 0
+    assert 0 < free.value <= total.value and total.value > (100 << 30)
+    assert sm.lib.smfft_mem_info(None, None) == 0
+
+
 @pytest.mark.parametrize("n", R2C_SIZES)
 def test_c2r_multiple_extension(sm, oracle_lib, n):
     """Upstream has no C2R `multiple` kernel (RC:435-467 is forward only); here the launch-only
