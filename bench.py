@@ -443,8 +443,20 @@ def main():
             ms = median_ms(lambda t, inv=inv, src=src, dst=dst: sm.lib.smfft_rc_external_benchmark(src, dst, rn, rnffts, inv, t))
             gbps = 2 * rbytes / (ms * 1e-3) / 1e9
             c4[name] = {"ms": ms, "TB/s": gbps / 1e3, "frac": gbps / HBM_PEAK_GBPS}
+        # config 2's other half (inverse, reorder) and the external path at every length (forward, reorder), whole 4 GiB batch
+        c2 = {}
+        for fn_n in (32, 64, 128, 256, 512, 1024, 2048, 4096):
+            bn = nffts * n // fn_n
+            row = {"nFFTs": bn}
+            for name, inv in (("forward", 0), ("inverse", 1)):
+                if inv and fn_n != n:
+                    continue
+                ms = median_ms(lambda t, inv=inv: sm.lib.smfft_ct_external_benchmark(pa.value, pb.value, fn_n, bn, inv, 1, t))
+                gbps = 2 * fn_n * bn * 8 / (ms * 1e-3) / 1e9
+                row[name] = {"ms": ms, "TB/s": gbps / 1e3, "frac": gbps / HBM_PEAK_GBPS}
+            c2[str(fn_n)] = row
         configs = {"timing": "median of 11 event-timed launches after 3 warm-ups, buffers of `roofline`",
-                   "config3_multiple": c3, "config4_r2c_c2r_external": c4}
+                   "config2_external_by_length": c2, "config3_multiple": c3, "config4_r2c_c2r_external": c4}
 
     # release everything, then look at the driver's accounting once more: freed VRAM is returned asynchronously
     sm.lib.smfft_free_pair(pa.value)

@@ -212,26 +212,45 @@ __device__ __forceinline__ float2 mul_w16(float2 a) {
     }
 }
 
-template <int R, int STRIDE, int DIR>
+template <int R, int STRIDE, int DIR, bool TAN = true>
 struct SmallDft {
     __device__ static __forceinline__ void run(const float2* in, float2* out) {
         float2 e[R / 2], o[R / 2];
-        SmallDft<R / 2, 2 * STRIDE, DIR>::run(in, e);
-        SmallDft<R / 2, 2 * STRIDE, DIR>::run(in + STRIDE, o);
+        SmallDft<R / 2, 2 * STRIDE, DIR, TAN>::run(in, e);
+        SmallDft<R / 2, 2 * STRIDE, DIR, TAN>::run(in + STRIDE, o);
         combine<0>(e, o, out);
     }
+#ifndef SMFFT_TAN_BUTTERFLY
+#define SMFFT_TAN_BUTTERFLY 1
+#endif
     template <int K>
     __device__ static __forceinline__ void combine(const float2* e, const float2* o, float2* out) {
         if constexpr (K < R / 2) {
-            float2 t = mul_w16<K*(16 / R), DIR>(o[K]);
-            out[K] = cadd(e[K], t);
-            out[K + R / 2] = csub(e[K], t);
+            constexpr int IDX = K * (16 / R);
+            if constexpr (SMFFT_TAN_BUTTERFLY && TAN && (IDX & 1)) {
+                // e +- W*o with W = wr * (1 + i*tn): two multiply-adds for u = o * (1 + i*tn), four for e +- wr*u -- six
+                // instructions where product, sum and difference take eight (the odd powers of W_16 only: the others are
+                // cheaper still as they are).  16 instructions fewer per N = 1024 FFT; in-LDS path N >= 256 +0.5-2.5 %,
+                // N = 32 / 64 1-7 % SLOWER (their register-transposed kernels schedule worse with it): TAN = false there
+                // (profiles/r02_ab_tan.txt)
+                constexpr float c1 = 0.92387953251128673848f, s1 = 0.38268343236508978178f;
+                constexpr float wr = (IDX == 1) ? c1 : (IDX == 3) ? s1 : (IDX == 5) ? -s1 : -c1;
+                constexpr float wi_f = (IDX == 1) ? -s1 : (IDX == 3) ? -c1 : (IDX == 5) ? -c1 : -s1;
+                constexpr float tn = (DIR ? -wi_f : wi_f) / wr;
+                const float ux = fmaf(-tn, o[K].y, o[K].x), uy = fmaf(tn, o[K].x, o[K].y);
+                out[K] = make_float2(fmaf(wr, ux, e[K].x), fmaf(wr, uy, e[K].y));
+                out[K + R / 2] = make_float2(fmaf(-wr, ux, e[K].x), fmaf(-wr, uy, e[K].y));
+            } else {
+                float2 t = mul_w16<IDX, DIR>(o[K]);
+                out[K] = cadd(e[K], t);
+                out[K + R / 2] = csub(e[K], t);
+            }
             combine<K + 1>(e, o, out);
         }
     }
 };
-template <int STRIDE, int DIR>
-struct SmallDft<1, STRIDE, DIR> {
+template <int STRIDE, int DIR, bool TAN>
+struct SmallDft<1, STRIDE, DIR, TAN> {
     __device__ static __forceinline__ void run(const float2* in, float2* out) { out[0] = in[0]; }
 };
 
@@ -648,7 +667,7 @@ struct Engine {
         if constexpr (G::kRegTwoPass) {
             float2 x[16];
             exchange_last_registers(r, x);
-            SmallDft<16, 1, DIR>::run(x, r);
+            SmallDft<16, 1, DIR, false>::run(x, r);
             return;
         }
         if constexpr (G::kRegExchange1) {
