@@ -266,9 +266,6 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_i
 #ifndef SMFFT_RC_REGISTERS
 #define SMFFT_RC_REGISTERS 1
 #endif
-#ifndef SMFFT_RC_INPLACE
-#define SMFFT_RC_INPLACE 0
-#endif
 template <int L, int DIR>
 struct HermitianRegisters {
     static constexpr int T = L / 16;
@@ -293,78 +290,11 @@ struct HermitianRegisters {
     // out[i] = H1 + W^i * H2 with A = x[i], B = x[L - i]  (i = u + T*q) and, as upstream (RC:289-328),
     //   H1 = ((A.x + B.x)/2, (A.y - B.y)/2),  H2 = (ohx * (A.y + B.y), ohy * (A.x - B.x)),  (ohx, ohy) = (1/2, -1/2) forward, (-1/2, 1/2) inverse.
     // With S = A + conj(B) and D = A - conj(B): H1 = S/2 and H2 = (-+i/2) * D, so out = S/2 + V * D, V = (-+i/2) * W^u * W_32^q:
-    // 4 additions + 6 multiply-adds per element once V is there (`wu` holds (-+i/2) * W^u).
-    template <int Q>
-    __device__ __forceinline__ float2 combine(float2 A, float2 B, float2 vu) const {
-        constexpr float c32[16] = {1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f, 0.55557023301960229f,
-                                   0.38268343236508984f, 0.19509032201612833f, 0.f, -0.19509032201612819f, -0.38268343236508973f, -0.55557023301960196f,
-                                   -0.70710678118654746f, -0.83146961230254535f, -0.92387953251128674f, -0.98078528040323043f};
-        constexpr float s32[16] = {0.f, 0.19509032201612825f, 0.38268343236508978f, 0.55557023301960218f, 0.70710678118654746f, 0.83146961230254524f,
-                                   0.92387953251128674f, 0.98078528040323043f, 1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254546f,
-                                   0.70710678118654757f, 0.55557023301960218f, 0.38268343236508989f, 0.19509032201612861f};
-        const float2 S = make_float2(A.x + B.x, A.y - B.y);
-        const float2 D = make_float2(A.x - B.x, A.y + B.y);
-        const float2 V = (Q == 0) ? vu : cmul(vu, make_float2(c32[Q], DIR ? s32[Q] : -s32[Q]));
-        return make_float2(fmaf(V.x, D.x, fmaf(-V.y, D.y, 0.5f * S.x)), fmaf(V.x, D.y, fmaf(V.y, D.x, 0.5f * S.y)));
-    }
-    __device__ __forceinline__ float2 from_partner(float2 v) const {
-        return make_float2(__int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(v.x))),
-                           __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(v.y))));
-    }
-    // In place, two registers (q, 15 - q) at a time, so that only a few fetched partner values are alive at once (the
-    // all-at-once form kept thirty-two: 139-146 VGPRs, 3 waves per SIMD).  Thread u > 0 pairs register q with register
-    // 15 - q of thread T - u: both fetches of a step are made before either register is overwritten, and all lanes of a
-    // wave make them together.  Thread 0 pairs register q with its OWN register 16 - q: for q that is the register
-    // 15 - (q - 1) the previous step overwrote (its original is carried over in `carried`), for 15 - q it is register
-    // q + 1, still untouched.  The steps are software-pipelined: the fetches of step q + 1 are issued before the
-    // arithmetic of step q, so their latency overlaps it, and an empty asm keeps step q + 2 from starting earlier.
-    struct Fetched { float2 lo, hi; };
-    template <int Q>
-    __device__ __forceinline__ Fetched fetch(const float2 (&r)[16]) const {
-        return {from_partner(r[15 - Q]), from_partner(r[Q])};   // partner's register 15 - Q -> B of register Q; its register Q -> B of 15 - Q
-    }
-    template <int Q>
-    __device__ __forceinline__ void apply_pair(float2 (&r)[16], float2& carried, Fetched cur) const {
-        if constexpr (Q < 8) {
-            Fetched next = cur;
-            if constexpr (Q < 7) next = fetch<Q + 1>(r);
-            const float2 a_lo = r[Q], a_hi = r[15 - Q];
-            const float2 b_lo = first ? carried : cur.lo;        // thread 0: original register 16 - Q
-            const float2 b_hi = first ? r[(Q + 1) & 15] : cur.hi;   // thread 0: register 16 - (15 - Q) = Q + 1 (Q = 7: register 8 itself)
-            carried = a_hi;
-            // W^i = W^u * W_32^q is the same for every tile, so the compiler would hoist all fifteen products out of the
-            // grid-stride loop and keep them in 30 registers (140 VGPRs, 3 waves per SIMD): the copy below is opaque to it
-            float2 w = wu;
-            asm volatile("" : "+v"(w.x), "+v"(w.y));
-            float2 o_lo = combine<Q>(a_lo, b_lo, w);
-            if constexpr (Q == 0) {   // element 0 of thread 0 packs DC and Nyquist (RC:280-286, 332-339)
-                const float2 packed = DIR ? make_float2(0.5f * (a_lo.x + a_lo.y), 0.5f * (a_lo.x - a_lo.y)) : make_float2(a_lo.x + a_lo.y, a_lo.x - a_lo.y);
-                o_lo = first ? packed : o_lo;
-            }
-            const float2 o_hi = combine<15 - Q>(a_hi, b_hi, w);
-            r[Q] = o_lo;
-            r[15 - Q] = o_hi;
-            // this step's results and the inputs of the step after next are outputs of the empty asm: the fetches of
-            // step Q + 2 cannot be issued before this step's arithmetic is done (left alone, the compiler hoists all
-            // thirty-two fetches to the top and keeps their results in thirty-two registers)
-            if constexpr (Q < 6) {
-                asm volatile("" : "+v"(r[Q].x), "+v"(r[Q].y), "+v"(r[15 - Q].x), "+v"(r[15 - Q].y),
-                                  "+v"(r[Q + 2].x), "+v"(r[Q + 2].y), "+v"(r[13 - Q].x), "+v"(r[13 - Q].y));
-            }
-            apply_pair<Q + 1>(r, carried, next);
-        }
-    }
-#if SMFFT_RC_INPLACE
-    __device__ __forceinline__ void apply(float2 (&r)[16], float2* = nullptr) const {
-        float2 carried = make_float2(0.f, 0.f);   // step 0 of thread 0 does not use it (packed DC / Nyquist)
-        apply_pair<0>(r, carried, fetch<0>(r));
-    }
-#else
+    // 4 additions + 6 multiply-adds per element once V is there (`wu` holds (-+i/2) * W^u; the fifteen products V are the
+    // same for every tile and stay in registers across the grid-stride loop).
     // All sixteen partner values fetched at once: thirty-two ds_bpermute back to back, their latencies overlapped, at the
-    // price of 139-146 VGPRs (3 waves per SIMD).  Measured against the in-place, software-pipelined form above
-    // (SMFFT_RC_INPLACE=1: 93-113 VGPRs, 4 waves per SIMD) on the same buffers, profiles/r02_ab_rc.txt / r02_ab_ext_pair.txt:
-    // this form is 0.6-2 % FASTER (config 4: R2C 0.692 vs 0.697 ms, C2R 0.679 vs 0.693 ms) -- these kernels are bound by
-    // what one wave keeps in flight, not by how many waves there are.
+    // price of 135-146 VGPRs (3 waves per SIMD).  An in-place form that fetched two partners at a time, software-pipelined,
+    // at 93-113 VGPRs = 4 waves per SIMD measured 0.6-2 % SLOWER on the same buffers (profiles/r02_ab_rc.txt) and is gone.
     // sf: the FFT's LDS region (kFromLds only; free on entry, the caller orders its later re-use)
     __device__ __forceinline__ void apply(float2 (&r)[16], float2* sf = nullptr) const {
         constexpr float c32[16] = {1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f, 0.55557023301960229f,
@@ -401,7 +331,7 @@ struct HermitianRegisters {
             const float2 A = r[q];
             const float2 S = make_float2(A.x + B[q].x, A.y - B[q].y);       // A + conj(B)
             const float2 D = make_float2(A.x - B[q].x, A.y + B[q].y);       // A - conj(B)
-            const float2 V = (q == 0) ? wu : cmul(wu, make_float2(c32[q], DIR ? s32[q] : -s32[q]));   // (-+i/2) * W^i, see combine
+            const float2 V = (q == 0) ? wu : cmul(wu, make_float2(c32[q], DIR ? s32[q] : -s32[q]));   // (-+i/2) * W^i
             float2 out = make_float2(fmaf(V.x, D.x, fmaf(-V.y, D.y, 0.5f * S.x)), fmaf(V.x, D.y, fmaf(V.y, D.x, 0.5f * S.y)));
             if (q == 0) {   // element 0 of thread 0 packs DC and Nyquist (RC:280-286, 332-339)
                 const float2 packed = DIR ? make_float2(0.5f * (A.x + A.y), 0.5f * (A.x - A.y)) : make_float2(A.x + A.y, A.x - A.y);
@@ -410,15 +340,8 @@ struct HermitianRegisters {
             r[q] = out;
         }
     }
-#endif
 };
 
-
-
-
-#ifndef SMFFT_RC_PREFETCH
-#define SMFFT_RC_PREFETCH 0
-#endif
 template <int L, int DIR>
 __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nFFTs, int pace, float2* s) {
     using G = Geometry<L>;
@@ -433,21 +356,6 @@ __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__
         const long f = (long)tile * G::kFftsPerBlock + eng.fft;
         const bool active = f < nFFTs;
         if constexpr (HermitianRegisters<L, DIR>::kEnabled) {
-#if SMFFT_RC_PREFETCH
-            // the next tile's loads are issued before this tile is transformed (they return in order, so waiting for this
-            // tile's data does not wait for them): two tiles per wave in flight
-            float2 nx[16];
-            if (tile == (int)blockIdx.x) eng.load_global(r, d_input + (active ? f : 0) * L);
-            const int nt = tile + gridDim.x;
-            const long fn = (long)nt * G::kFftsPerBlock + eng.fft;
-            if (nt < ntiles) eng.load_global(nx, d_input + (fn < nFFTs ? fn : 0) * L);
-            if (DIR == 1) herm.apply(r);
-            eng.transform(r, sf);
-            if (DIR == 0) herm.apply(r);
-            eng.store_global(r, d_output + f * L, active);
-#pragma unroll
-            for (int c = 0; c < 16; ++c) r[c] = nx[c];
-#else
             eng.load_global(r, d_input + (active ? f : 0) * L);
             if (G::kMultiWave) __syncthreads();   // the previous tile's LDS reads are complete
             if (pace) vmem_throttle(s + (threadIdx.x >> 6) * 1088, r, pace);
@@ -461,7 +369,6 @@ __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__
                 herm.apply(r, sf);
             }
             eng.store_global(r, d_output + f * L, active);
-#endif
         } else if (DIR == 0) {
             eng.load_global(r, d_input + (active ? f : 0) * L);
             if (G::kMultiWave) __syncthreads();
@@ -608,17 +515,8 @@ __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_length) FFT_GPU_multiple(
 }
 
 // R2C/C2R program.
-// SMFFT_RC_INPLACE=1 (A/B switch): the in-place Hermitian step, compiled for 4 waves per SIMD (<= 128 VGPRs)
-#ifndef SMFFT_RC_INPLACE
-#define SMFFT_RC_INPLACE 0
-#endif
-#if SMFFT_RC_INPLACE
-#define SMFFT_RC_BOUNDS(L) __launch_bounds__(256, ((L) <= 1024 ? 4 : 3))
-#else
-#define SMFFT_RC_BOUNDS(L) __launch_bounds__(256)
-#endif
 template <class const_params, class const_direction>
-__global__ void SMFFT_RC_BOUNDS(const_params::fft_length) FFT_GPU_R2C_C2R_external(const float2* d_input, float2* d_output, int nFFTs, int pace) {
+__global__ void __launch_bounds__(256) FFT_GPU_R2C_C2R_external(const float2* d_input, float2* d_output, int nFFTs, int pace) {
     __shared__ float2 s_input[4352];
     smfft::r2c_c2r_external_body<const_params::fft_length, const_direction::fft_direction>(d_input, d_output, nFFTs, pace, s_input);
 }
