@@ -150,9 +150,11 @@ typedef struct SmfftPairInfo {
     unsigned long long candidate_bytes;  /* physical memory the scan held at its end (<= max(byte budget + 1 GiB, bytes)) */
     int candidates;                      /* mixed policy: GiB chunks scanned; candidates policy: blocks probed; 0: plain */
     int chosen;                          /* mixed policy: GiB of mixed memory in the output; candidates policy: index of the block kept */
-    int good_enough;                     /* 1: the output is all mixed memory (mixed) / met the 2.3 x read-time criterion (candidates) */
+    int good_enough;                     /* 1: the output is all mixed or interleaved memory (mixed) / met the 2.3 x read-time criterion (candidates) */
     float read_ms, copy_ms, first_copy_ms;   /* over min(bytes, 1 GiB): pure read of the input; copy into the output; copy into the first chunk / block seen */
     double search_ms;
+    unsigned long long mixed_bytes;        /* mixed policy: bytes of the output that are mixed memory ... */
+    unsigned long long interleaved_bytes;  /* ... and bytes that are ordinary memory of two classes interleaved in 8 MiB handles */
 } SmfftPairInfo;
 int smfft_last_pair_info(SmfftPairInfo* out);
 int smfft_free(void* d_ptr);

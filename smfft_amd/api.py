@@ -96,7 +96,7 @@ class SmfftPairInfo(ctypes.Structure):
     """mirror of include/smfft.h SmfftPairInfo"""
     _fields_ = [("bytes", ctypes.c_ulonglong), ("candidate_bytes", ctypes.c_ulonglong), ("candidates", ctypes.c_int), ("chosen", ctypes.c_int),
                 ("good_enough", ctypes.c_int), ("read_ms", ctypes.c_float), ("copy_ms", ctypes.c_float), ("first_copy_ms", ctypes.c_float),
-                ("search_ms", ctypes.c_double)]
+                ("search_ms", ctypes.c_double), ("mixed_bytes", ctypes.c_ulonglong), ("interleaved_bytes", ctypes.c_ulonglong)]
 
 
 def last_pair_info():

@@ -112,28 +112,32 @@ int timed(F&& launch, double* FFT_time) {
 
 // ---- paired allocation ----------------------------------------------------------------------------
 // What round 2 measured on MI355X (tools/microbench/placement_study.hip; profiles/r02_placement_map.txt,
-// profiles/r02_placement_pmc.json, profiles/r02_vmm_mixed_assembly.txt):
-//  * The 288 GB of HBM fall into THREE classes of ~89 GiB (the three ranks of the 12-high stacks is the reading that
-//    fits).  An ordinary allocation lies inside one class; pure reads from it run at 7.2 TB/s, pure writes at 5.6 TB/s.
+// profiles/r02_placement_pmc.json, profiles/r02_vmm_mixed_assembly.txt, profiles/r02_vmm_interleave.txt):
+//  * Physical memory comes in CLASSES (three were told apart).  A plain allocation of a few GiB lies inside one class;
+//    pure reads from it run at 7.2 TB/s, pure writes at 5.6 TB/s.
 //  * About one physical GiB in seven is MIXED: pure writes 20 % FASTER (6.9 TB/s), pure reads 7 % slower.
 //  * A kernel that reads buffer A and writes buffer B moves the 4 GiB + 4 GiB batch in 1.55-1.60 ms when A and B are
 //    ordinary and in the same class -- what two hipMalloc calls in a row give -- in 1.48-1.53 ms in different classes, and
 //    in 1.30-1.31 ms (0.82 of the HBM peak) when B consists of mixed memory; reading FROM mixed memory is the slowest case.
 //    Same request counts in every case (TCC_EA0_RDREQ / WRREQ = the algorithmic bytes): what differs is DRAM service time.
-//  * None of it shows in virtual addresses, but the pure write rate of a physical GiB tells mixed from ordinary at once.
+//  * Mixed memory can be MADE: a range whose 8 MiB handles alternate between ordinary memory of two different classes
+//    takes writes like mixed memory (copy into it 1.32 ms); alternating within one class, or in 128 MiB stripes, does not.
+//  * None of it shows in virtual addresses, but write passes tell: a physical GiB is mixed if its own pass is fast, and two
+//    ordinary GiB are of different classes if the pass over their interleaved halves is.
 // smfft_malloc_pair ("mixed" policy, the default) therefore takes the input from hipMalloc and BUILDS the output with
-// the virtual-memory API: physical memory is created in 8 MiB handles, 1 GiB at a time; each GiB is mapped at a slot
-// of its own, timed with one write-only pass (0.2 ms), and kept for the output if it is mixed; the scan ends when
-// the output is complete, or at the byte budget (default: a quarter of the free memory) or the time budget (default
-// 2 s), whatever is missing then coming from the last ordinary chunks scanned (the farthest from the input).  The
-// chosen handles are mapped back to back into one virtual range -- the caller sees an ordinary device pointer -- and
-// everything else is released.  Cost measured on six boxes: 4-40 ms per scanned GiB (hipMemCreate); 8-14 GiB scanned in
-// 40-230 ms for a 4 GiB output on five of them, the byte budget (69 GiB) in 1.6 s on the sixth; output all mixed every time.
+// the virtual-memory API: physical memory is created in 8 MiB handles, 1 GiB at a time; each GiB is mapped at a slot of its
+// own and classified by those two passes (0.2 ms each); the scan ends as soon as mixed memory plus equal amounts of two
+// classes cover the output -- typically after 4-17 GiB and 30-250 ms for a 4 GiB output, where hunting for mixed memory
+// alone needed up to the whole byte budget and found none on some boxes -- or at the byte budget (default: a quarter of
+// the free memory) or the time budget (default 2 s), whatever is missing then coming from the last ordinary chunks
+// scanned.  The chosen handles are blended evenly into one virtual range -- the caller sees an ordinary device pointer --
+// a final write pass over it checks the result, and everything else is released.
 //   SMFFT_PAIR_POLICY=mixed|candidates|plain   candidates: round-1 style, whole hipMalloc / hipMallocAsync blocks timed as
 //                                              copy targets inside the same budgets; plain: two plain allocations
 //   SMFFT_PAIR_BUDGET_FRAC=0.25                byte budget of the scan as a fraction of the free memory
 //   SMFFT_PAIR_BUDGET_MS=2000                  time budget
 //   SMFFT_PAIR_CACHE=1                         keep the last released pair for the next request of the same size
+//   SMFFT_PAIR_NO_MIXED=1 / SMFFT_PAIR_NO_INTERLEAVE=1   A/B and test switches: only interleaving / only mixed chunks count
 struct PairRec {
     void* a = nullptr;
     void* b = nullptr;
@@ -167,7 +171,10 @@ int pacing_for(const void* d_output, int k_ordinary, int k_mixed) {
 
 constexpr double kGoodRatio = 2.30;    // candidates policy: mixed targets copy in 2.2-2.3 x the pure read time; other class 2.5; same class 2.6
 constexpr float kMixedWriteRatio = 0.91f;   // mixed policy: a chunk is mixed if its write pass takes < 0.91 x the typical one (mixed: 0.79-0.88)
-constexpr size_t kHandleBytes = 8ull << 20, kChunkBytes = 1ull << 30;
+#ifndef SMFFT_PAIR_HANDLE_MIB
+#define SMFFT_PAIR_HANDLE_MIB 8
+#endif
+constexpr size_t kHandleBytes = (size_t)SMFFT_PAIR_HANDLE_MIB << 20, kChunkBytes = 1ull << 30;
 
 // mean ms of `launches` passes in the external kernels' access shape over the first `bytes`: copy (in, out), pure read
 // (in, nullptr) or pure write (nullptr, out)
@@ -251,6 +258,14 @@ struct Budget {
 
 // "mixed" policy: the output as a virtual range over scanned physical chunks (see the comment above).  false: the VMM
 // API is not usable here (nothing is left allocated), the caller falls back to the candidates policy.
+//
+// Two kinds of memory make a fast write target (tools/microbench/placement_study.hip vmm / vmm_il,
+// profiles/r02_vmm_mixed_assembly.txt, r02_vmm_interleave.txt): MIXED chunks (pure writes 20 % faster; copy into them 1.30 ms
+// per 4 GiB + 4 GiB), and ORDINARY chunks of two different memory classes INTERLEAVED handle by handle (8 MiB): 1.32 ms,
+// against 1.55 ms into ordinary memory of one class -- what mixed memory is, made by hand.  Interleaving chunks of the SAME
+// class gains nothing, nor does interleaving in stripes of 128 MiB.  So every scanned chunk is classified twice: mixed or not
+// by its own write pass, and -- if not -- same or other class than the first ordinary chunk by the write pass over a test
+// range in which their handles alternate.  The scan ends as soon as mixed + 2 * min(same, other) covers the output.
 bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& budget, PairRec& rec, SmfftPairInfo& info) {
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
@@ -264,10 +279,14 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
     const size_t need = (bytes + kHandleBytes - 1) / kHandleBytes, per_chunk = kChunkBytes / kHandleBytes;
     char* out = arena_take(need * kHandleBytes);
     if (!out) return false;
-    struct Chunk { std::vector<hipMemGenericAllocationHandle_t> hs; float write_ms; };
+    enum Kind { kUnknown, kSameClass, kOtherClass };
+    struct Chunk { std::vector<hipMemGenericAllocationHandle_t> hs; float write_ms; Kind kind; };
     std::vector<Chunk> chunks;
     size_t created = 0, extra_after_enough = 0;
+    int reference = -1;            // the first ordinary chunk: the class the others are compared with
     bool api_ok = true;
+    const bool interleave = getenv("SMFFT_PAIR_NO_INTERLEAVE") == nullptr;   // A/B and test switches: only mixed chunks count /
+    const bool use_mixed = getenv("SMFFT_PAIR_NO_MIXED") == nullptr;         // only interleaving counts
     // the reference a chunk's write pass is judged against: the median chunk (six chunks in seven are ordinary), but not
     // less than the write pass over the input buffer itself (an ordinary hipMalloc block), so that a run of mixed chunks
     // at the start of the scan is recognised as such
@@ -279,20 +298,45 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
         const float med = t.empty() ? 0.f : (t.size() < 3 ? t.back() : t[t.size() / 2]);
         return med > in_write_ms ? med : in_write_ms;
     };
-    auto mixed_handles = [&] {
+    auto is_mixed = [&](const Chunk& c, float typ) { return use_mixed && c.write_ms < kMixedWriteRatio * typ; };
+    struct Tally { size_t mixed, same, other; };
+    auto tally = [&] {
         const float typ = typical();
-        size_t n = 0;
-        for (auto& c : chunks) if (c.write_ms < kMixedWriteRatio * typ) n += c.hs.size();
-        return n;
+        Tally t = {0, 0, 0};
+        for (auto& c : chunks) {
+            if (is_mixed(c, typ)) t.mixed += c.hs.size();
+            else if (c.kind == kSameClass) t.same += c.hs.size();
+            else if (c.kind == kOtherClass) t.other += c.hs.size();
+        }
+        return t;
+    };
+    // write pass over a test range in which the first halves of two chunks alternate handle by handle: clearly faster than
+    // the chunks' own passes if they belong to different classes
+    auto other_class = [&](const Chunk& x, const Chunk& y) {
+        char* slot = arena_take(kChunkBytes);
+        if (!slot) return false;
+        bool ok = true;
+        for (size_t k = 0; k < per_chunk / 2 && ok; ++k)
+            ok = hipMemMap(slot + (2 * k) * kHandleBytes, kHandleBytes, 0, x.hs[k], 0) == hipSuccess &&
+                 hipMemMap(slot + (2 * k + 1) * kHandleBytes, kHandleBytes, 0, y.hs[k], 0) == hipSuccess;
+        ok = ok && hipMemSetAccess(slot, kChunkBytes, &acc, 1) == hipSuccess;
+        const float ms = ok ? probe_ms(nullptr, slot, kChunkBytes, 3) : 1e30f;
+        (void)hipMemUnmap(slot, kChunkBytes);
+        if (!ok) (void)hipGetLastError();
+        if (getenv("SMFFT_PAIR_DEBUG")) printf("smfft_malloc_pair: interleave probe %.3f ms (own passes %.3f, %.3f)\n", ms, x.write_ms, y.write_ms);
+        return ms < kMixedWriteRatio * 0.5f * (x.write_ms + y.write_ms);
     };
     while (true) {
-        // once the output is covered, at most four more chunks are scanned for up to two spare mixed GiB (the output
-        // then takes the fastest ones); otherwise the scan runs to its budgets
-        const size_t have = chunks.empty() ? 0 : mixed_handles();
-        if (have >= need && extra_after_enough == 0) extra_after_enough = chunks.size() + 4;
-        if (!chunks.empty() && (have >= need + 2 * per_chunk || (extra_after_enough && chunks.size() >= extra_after_enough)
+        // covered by mixed memory alone: at most four more chunks are scanned for up to two spare mixed GiB (the output
+        // then takes the fastest ones); covered with the help of interleaved ordinary chunks: done; else to the budgets
+        const Tally have = chunks.empty() ? Tally{0, 0, 0} : tally();
+        if (have.mixed >= need && extra_after_enough == 0) extra_after_enough = chunks.size() + 4;
+        const bool covered = have.mixed + 2 * std::min(have.same, have.other) >= need;
+        if (!chunks.empty() && (have.mixed >= need + 2 * per_chunk || (extra_after_enough && chunks.size() >= extra_after_enough)
+                                || (covered && have.mixed < need)
                                 || created + kChunkBytes > budget.bytes || budget.elapsed_ms() > budget.ms)) break;
         Chunk c;
+        c.kind = kUnknown;
         for (size_t h = 0; h < per_chunk; ++h) {
             hipMemGenericAllocationHandle_t handle;
             if (hipMemCreate(&handle, kHandleBytes, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
@@ -313,10 +357,15 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
         if (chunks.empty()) info.first_copy_ms = probe_ms(in, scratch, bytes < kChunkBytes ? bytes : kChunkBytes, 3);   // copy into the first (almost surely ordinary) chunk
         (void)hipMemUnmap(scratch, kChunkBytes);
         chunks.push_back(std::move(c));
+        Chunk& last = chunks.back();
+        if (interleave && !is_mixed(last, typical())) {
+            if (reference < 0) { reference = (int)chunks.size() - 1; last.kind = kSameClass; }
+            else last.kind = other_class(chunks[reference], last) ? kOtherClass : kSameClass;
+        }
     }
     if (getenv("SMFFT_PAIR_DEBUG")) {
-        printf("smfft_malloc_pair scan: %zu chunks, write ms per GiB:", chunks.size());
-        for (auto& c : chunks) printf(" %.3f", c.write_ms);
+        printf("smfft_malloc_pair scan: %zu chunks, write ms per GiB (class):", chunks.size());
+        for (auto& c : chunks) printf(" %.3f(%c)", c.write_ms, c.kind == kOtherClass ? 'o' : c.kind == kSameClass ? 's' : '-');
         printf("\n");
     }
     if (!api_ok || chunks.empty()) {
@@ -329,7 +378,8 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
         for (auto& c : chunks) total += c.hs.size();
         if (total < need) {
             Chunk c;
-            c.write_ms = 1e30f;                                    // counts as ordinary, used last
+            c.write_ms = 1e30f;
+            c.kind = kUnknown;
             for (size_t h = total; h < need; ++h) {
                 hipMemGenericAllocationHandle_t handle;
                 if (hipMemCreate(&handle, kHandleBytes, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
@@ -339,39 +389,88 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
             chunks.push_back(std::move(c));
         }
     }
-    // mixed chunks first (fastest writes first), then the last ordinary chunks scanned
+    // The output's handles.  Three pools: mixed memory (fastest chunks first, their handles taken round-robin across the
+    // chunks), ordinary memory of the reference's class, ordinary memory of another class; the last two contribute equal
+    // numbers.  The pools are spread EVENLY over the range (largest-remainder round-robin), so that every part of the buffer
+    // is the same blend -- a caller that uses half of it gets the same rate as one that uses all of it -- and neighbouring
+    // handles alternate between the classes.  What the pools cannot cover comes from the remaining ordinary memory, at the end.
     const float typ = typical();
-    std::vector<size_t> order;
-    for (size_t i = 0; i < chunks.size(); ++i) if (chunks[i].write_ms < kMixedWriteRatio * typ) order.push_back(i);
-    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return chunks[x].write_ms < chunks[y].write_ms; });
-    const size_t n_mixed = order.size();
-    for (size_t i = chunks.size(); i-- > 0;) if (!(chunks[i].write_ms < kMixedWriteRatio * typ)) order.push_back(i);
-    size_t mapped = 0, mixed_used = 0;
-    bool ok = true;
-    for (size_t k = 0; k < order.size() && ok; ++k) {
-        auto& hs = chunks[order[k]].hs;
-        while (!hs.empty() && mapped < need && ok) {
-            ok = hipMemMap(out + mapped * kHandleBytes, kHandleBytes, 0, hs.back(), 0) == hipSuccess;
-            if (ok) { rec.handles.push_back(hs.back()); hs.pop_back(); ++mapped; if (k < n_mixed) ++mixed_used; }
+    std::vector<hipMemGenericAllocationHandle_t> chosen;
+    size_t mixed_used = 0, interleaved_used = 0;
+    {
+        auto drain = [&](std::vector<size_t> order, size_t limit) {       // handles of these chunks, round-robin across them
+            std::vector<hipMemGenericAllocationHandle_t> pool;
+            for (bool any = true; any && pool.size() < limit;) {
+                any = false;
+                for (size_t i : order)
+                    if (!chunks[i].hs.empty() && pool.size() < limit) { pool.push_back(chunks[i].hs.back()); chunks[i].hs.pop_back(); any = true; }
+            }
+            return pool;
+        };
+        std::vector<size_t> m_chunks, s_chunks, o_chunks;
+        for (size_t i = 0; i < chunks.size(); ++i) {
+            if (is_mixed(chunks[i], typ)) m_chunks.push_back(i);
+            else if (chunks[i].kind == kSameClass) s_chunks.push_back(i);
+            else if (chunks[i].kind == kOtherClass) o_chunks.push_back(i);
         }
+        std::sort(m_chunks.begin(), m_chunks.end(), [&](size_t x, size_t y) { return chunks[x].write_ms < chunks[y].write_ms; });
+        size_t m_total = 0, s_total = 0, o_total = 0;
+        for (size_t i : m_chunks) m_total += chunks[i].hs.size();
+        for (size_t i : s_chunks) s_total += chunks[i].hs.size();
+        for (size_t i : o_chunks) o_total += chunks[i].hs.size();
+        // as many whole mixed chunks as fit (the fastest), the rest in equal parts from the two classes
+        const size_t m_take = std::min(m_total, need);
+        const size_t each = std::min((need - m_take + 1) / 2, std::min(s_total, o_total));
+        if (m_take < m_total) m_chunks.resize((m_take + per_chunk - 1) / per_chunk);
+        std::vector<hipMemGenericAllocationHandle_t> pool[3];
+        pool[0] = drain(m_chunks, m_take);
+        pool[1] = drain(s_chunks, each);
+        pool[2] = drain(o_chunks, std::min(each, need - m_take - pool[1].size()));
+        const size_t count[3] = {pool[0].size(), pool[1].size(), pool[2].size()};
+        const size_t blended = count[0] + count[1] + count[2];
+        size_t next[3] = {0, 0, 0};
+        double acc[3] = {0.0, 0.0, 0.0};
+        for (size_t k = 0; k < blended; ++k) {
+            int best = -1;
+            for (int q = 0; q < 3; ++q) {
+                if (next[q] == count[q]) continue;
+                acc[q] += (double)count[q];
+                if (best < 0 || acc[q] > acc[best]) best = q;
+            }
+            acc[best] -= (double)blended;
+            chosen.push_back(pool[best][next[best]++]);
+        }
+        mixed_used = count[0];
+        interleaved_used = count[1] + count[2];
+        for (size_t i = chunks.size(); i-- > 0 && chosen.size() < need;)
+            while (!chunks[i].hs.empty() && chosen.size() < need) { chosen.push_back(chunks[i].hs.back()); chunks[i].hs.pop_back(); }
     }
     for (auto& c : chunks) for (auto h : c.hs) (void)hipMemRelease(h);      // everything that was not used
-    ok = ok && mapped == need && hipMemSetAccess(out, need * kHandleBytes, &acc, 1) == hipSuccess;
+    bool ok = chosen.size() == need;
+    size_t mapped = 0;
+    for (; mapped < chosen.size() && ok; ++mapped) ok = hipMemMap(out + mapped * kHandleBytes, kHandleBytes, 0, chosen[mapped], 0) == hipSuccess;
+    ok = ok && hipMemSetAccess(out, need * kHandleBytes, &acc, 1) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
         if (mapped) (void)hipMemUnmap(out, mapped * kHandleBytes);
-        for (auto h : rec.handles) (void)hipMemRelease(h);
-        rec.handles.clear();
+        for (auto h : chosen) (void)hipMemRelease(h);
         return false;
     }
+    // the claim is checked on the result: one write pass over the whole output must be as fast as mixed memory's
+    const float verify_ms = probe_ms(nullptr, out, need * kHandleBytes, 2);
+    const bool fast = verify_ms < kMixedWriteRatio * typ * (float)((double)(need * kHandleBytes) / (double)kChunkBytes);
+    if (getenv("SMFFT_PAIR_DEBUG")) printf("smfft_malloc_pair: output write pass %.3f ms (typical %.3f ms per GiB): %s\n", verify_ms, typ, fast ? "fast" : "NOT fast");
+    rec.handles = chosen;
     rec.b = out;
     rec.va_bytes = need * kHandleBytes;
     rec.searched = true;
-    rec.mixed = 2 * mixed_used >= need;
+    rec.mixed = fast;
     info.candidates = (int)chunks.size();
     info.candidate_bytes = created;
     info.chosen = (int)((mixed_used * kHandleBytes + kChunkBytes - 1) / kChunkBytes);
-    info.good_enough = mixed_used == need ? 1 : 0;
+    info.good_enough = (fast && mixed_used + interleaved_used == need) ? 1 : 0;
+    info.mixed_bytes = mixed_used * kHandleBytes;
+    info.interleaved_bytes = interleaved_used * kHandleBytes;
     return true;
 }
 

@@ -577,6 +577,25 @@ def test_malloc_pair_bounded_search(sm, monkeypatch):
     assert _settled_usage(sm, free0, 256 << 20) <= (256 << 20)
     monkeypatch.delenv("SMFFT_PAIR_BUDGET_FRAC")
     monkeypatch.delenv("SMFFT_PAIR_POLICY")
+    # the output as ordinary memory of two classes interleaved handle by handle (mixed chunks not allowed to count): every
+    # 8 MiB handle of the range is distinct memory (a pattern per handle survives all the other writes) and the pair works
+    monkeypatch.setenv("SMFFT_PAIR_NO_MIXED", "1")
+    assert sm.lib.smfft_malloc_pair(2 * nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
+    info = sm.last_pair_info()
+    print("interleave only:", info)
+    assert info["mixed_bytes"] == 0 and info["interleaved_bytes"] <= 2 * nbytes and (not info["good_enough"] or info["interleaved_bytes"] == 2 * nbytes)
+    handle = 8 << 20
+    pats = [np.full(1024, k + 1, dtype=np.uint32) for k in range(2 * nbytes // handle)]
+    for k, pat in enumerate(pats):
+        sm.lib.smfft_memcpy_h2d(b.value + k * handle + 4096 * (k % 7), pat.ctypes.data, pat.nbytes)
+    back = np.empty(1024, dtype=np.uint32)
+    for k, pat in enumerate(pats):
+        sm.lib.smfft_memcpy_d2h(back.ctypes.data, b.value + k * handle + 4096 * (k % 7), back.nbytes)
+        assert np.array_equal(back, pat), k
+    use(a, b)
+    assert sm.lib.smfft_free_pair(a.value) == 0
+    assert _settled_usage(sm, free0, 256 << 20) <= (256 << 20)
+    monkeypatch.delenv("SMFFT_PAIR_NO_MIXED")
     # an odd size (not a multiple of the 8 MiB handles): the whole range is usable up to the last byte
     odd = nbytes + 12345 * 8
     assert sm.lib.smfft_malloc_pair(odd, ctypes.byref(a), ctypes.byref(b)) == 0

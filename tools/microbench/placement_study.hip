@@ -254,6 +254,178 @@ static int vmm_mode(size_t handle_mib, size_t max_gib) {
     return 0;
 }
 
+// vmm_il: can ORDINARY memory be made to behave like mixed memory by interleaving it by hand?  120 GiB of physical memory in
+// creation order, 1 GiB chunks classified (mixed / ordinary) by a write pass; 4 GiB buffers assembled (each in a fresh virtual
+// range) from ordinary chunks taken near the start, the middle and the end of the range -- consecutive ("seq": one region) or
+// handle by handle round-robin over the three regions ("il") -- and the copy matrix between them, with mixed targets as reference.
+static int vmm_il_mode(size_t handle_mib, size_t max_gib) {
+    const size_t G = 1ull << 30, H = handle_mib << 20, per_chunk = G / H;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    size_t free_b = 0, total_b = 0;
+    CK(hipMemGetInfo(&free_b, &total_b));
+    size_t nchunks = std::min<size_t>(max_gib, (free_b - (24ull << 30)) / G);
+    char* va = nullptr;
+    CK(hipMemAddressReserve((void**)&va, nchunks * G, 0, nullptr, 0));
+    std::vector<hipMemGenericAllocationHandle_t> handle(nchunks * per_chunk);
+    size_t made = 0;
+    for (; made < handle.size(); ++made)
+        if (hipMemCreate(&handle[made], H, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+    nchunks = made / per_chunk;
+    for (size_t h = 0; h < nchunks * per_chunk; ++h) CK(hipMemMap(va + h * H, H, 0, handle[h], 0));
+    CK(hipMemSetAccess(va, nchunks * G, &acc, 1));
+    printf("vmm_il: %zu chunks of 1 GiB in handles of %zu MiB\n", nchunks, handle_mib);
+    g_ntiles = (long)(G / 8 / 4096);
+    for (size_t j = 0; j < nchunks; ++j) study_write<0><<<g_grid, 256>>>((v2f*)(va + j * G), g_ntiles);
+    CK(hipDeviceSynchronize());
+    for (int k = 0; k < 300; ++k) study_copy<0><<<g_grid, 256>>>((const v2f*)va, (v2f*)(va + G), g_ntiles);
+    CK(hipDeviceSynchronize());
+    std::vector<float> wr(nchunks);
+    for (size_t j = 0; j < nchunks; ++j) wr[j] = t_write<0>(va + j * G, 4);
+    std::vector<float> sorted_wr(wr);
+    std::sort(sorted_wr.begin(), sorted_wr.end());
+    const float wr_typ = sorted_wr[nchunks / 2];
+    std::vector<size_t> mixed, ordinary;
+    for (size_t j = 0; j < nchunks; ++j) {
+        if (wr[j] < 0.90f * wr_typ) mixed.push_back(j);
+        else if (wr[j] > 0.97f * wr_typ) ordinary.push_back(j);      // chunks in between are left out of the experiment
+    }
+    std::sort(mixed.begin(), mixed.end(), [&](size_t x, size_t y) { return wr[x] < wr[y]; });
+    printf("write ms per GiB by chunk:");
+    for (size_t j = 0; j < nchunks; ++j) printf(" %.3f", wr[j]);
+    printf("\ntypical write %.3f ms per GiB; %zu mixed, %zu strictly ordinary chunks\n", wr_typ, mixed.size(), ordinary.size());
+    if (mixed.size() < 4 || ordinary.size() < 75) { printf("not enough chunks\n"); return 0; }
+    CK(hipMemUnmap(va, nchunks * G));
+    // three regions of ordinary chunks: start, middle, end of the creation order; each gives its chunks away one after the other
+    const size_t third = ordinary.size() / 3;
+    size_t next_chunk[3] = {0, third, 2 * third};
+    auto take_chunk = [&](int region) { return ordinary[next_chunk[region]++]; };
+    g_ntiles = (long)(4 * G / 8 / 4096);
+    auto map_handles = [&](const std::vector<hipMemGenericAllocationHandle_t>& hs, const char* what) -> char* {
+        char* t = nullptr;
+        CK(hipMemAddressReserve((void**)&t, 4 * G, 0, nullptr, 0));
+        for (size_t k = 0; k < hs.size(); ++k) CK(hipMemMap(t + k * H, H, 0, hs[k], 0));
+        CK(hipMemSetAccess(t, 4 * G, &acc, 1));
+        study_write<0><<<g_grid, 256>>>((v2f*)t, g_ntiles);
+        CK(hipDeviceSynchronize());
+        printf("assembled %s\n", what);
+        return t;
+    };
+    auto seq = [&](int region, const char* what) {
+        std::vector<hipMemGenericAllocationHandle_t> hs;
+        for (int c = 0; c < 4; ++c) { const size_t ch = take_chunk(region); for (size_t h = 0; h < per_chunk; ++h) hs.push_back(handle[ch * per_chunk + h]); }
+        return map_handles(hs, what);
+    };
+    // `stripe` consecutive handles from one region, then from the next, ...: 4 chunks of every region make three buffers' worth;
+    // one buffer takes 4/3 chunks of each (the spare handles stay unused)
+    // regs: the regions the `ways` interleaved streams come from (a region may appear more than once: separate chunks of it)
+    auto il_regions = [&](std::vector<int> regs, size_t stripe, const char* what) {
+        const size_t ways = regs.size();
+        std::vector<size_t> ch(ways), used(ways, 0);
+        for (size_t w = 0; w < ways; ++w) ch[w] = take_chunk(regs[w]);
+        std::vector<hipMemGenericAllocationHandle_t> hs;
+        const size_t need = 4 * per_chunk;
+        for (size_t k = 0; hs.size() < need; ++k) {
+            const size_t w = k % ways;
+            for (size_t i = 0; i < stripe && hs.size() < need; ++i) {
+                if (used[w] == per_chunk) { ch[w] = take_chunk(regs[w]); used[w] = 0; }
+                hs.push_back(handle[ch[w] * per_chunk + used[w]++]);
+            }
+        }
+        return map_handles(hs, what);
+    };
+    auto il = [&](size_t stripe, const char* what) { return il_regions({0, 1, 2}, stripe, what); };
+    auto from_mixed = [&](size_t first, const char* what) {
+        std::vector<hipMemGenericAllocationHandle_t> hs;
+        for (size_t c = 0; c < 4; ++c) for (size_t h = 0; h < per_chunk; ++h) hs.push_back(handle[mixed[(first + c) % mixed.size()] * per_chunk + h]);
+        return map_handles(hs, what);
+    };
+    char* inSeq = seq(0, "inSeq   (4 ordinary chunks, start of the range)");
+    char* outSeq0 = seq(0, "outSeq0 (4 ordinary chunks, start of the range)");
+    char* outSeq1 = seq(1, "outSeq1 (4 ordinary chunks, middle)");
+    char* outSeq2 = seq(2, "outSeq2 (4 ordinary chunks, end)");
+    char* inIl1 = il(1, "inIl1   (one handle from each region in turn)");
+    char* outIl1 = il(1, "outIl1  (one handle from each region in turn)");
+    char* inIl16 = il(16, "inIl16  (16 handles from each region in turn)");
+    char* outIl16 = il(16, "outIl16 (16 handles from each region in turn)");
+    char* outM = from_mixed(0, "outM    (the four most mixed chunks)");
+    char* out000 = il_regions({0, 0, 0}, 1, "out000  (three chunks of the first region, handle by handle)");
+    char* out01 = il_regions({0, 1}, 1, "out01   (first and middle region, handle by handle)");
+    char* out12 = il_regions({1, 2}, 1, "out12   (middle and last region, handle by handle)");
+    char* out02 = il_regions({0, 2}, 1, "out02   (first and last region, handle by handle)");
+    char* out0122 = il_regions({0, 1, 2, 2, 1, 0}, 1, "out012210 (six streams over the three regions)");
+    struct Case { const char* name; char* in; char* out; };
+    std::vector<Case> cases = {{"seq -> seq (same region)", inSeq, outSeq0}, {"seq -> seq (middle)", inSeq, outSeq1}, {"seq -> seq (end)", inSeq, outSeq2},
+                               {"seq -> il1", inSeq, outIl1}, {"il1 -> seq (same region)", inIl1, outSeq0}, {"il1 -> il1", inIl1, outIl1},
+                               {"seq -> il16", inSeq, outIl16}, {"il16 -> il16", inIl16, outIl16}, {"il1 -> il16", inIl1, outIl16},
+                               {"seq -> mixed", inSeq, outM}, {"il1 -> mixed", inIl1, outM}, {"il16 -> mixed", inIl16, outM},
+                               {"seq -> il(0,0,0)", inSeq, out000}, {"seq -> il(0,1)", inSeq, out01}, {"seq -> il(1,2)", inSeq, out12}, {"seq -> il(0,2)", inSeq, out02},
+                               {"seq -> il(0,1,2,2,1,0)", inSeq, out0122}};
+    for (int rep = 0; rep < 2; ++rep)
+        for (auto& c : cases)
+            printf("%-28s copy %.3f ms | paced copy %.3f ms | write-only %.3f ms | read-only %.3f ms\n", c.name, t_copy<0>(c.in, c.out, 6), t_paced<0>(c.in, c.out, 6),
+                   t_write<0>(c.out, 6), t_read<0>(c.in, c.out, 6));
+    return 0;
+}
+
+// vmm_spacer: the cheap way to physical memory of ANOTHER class: 2 GiB of handles (A), one plain hipMalloc of X GiB as a
+// spacer, 2 GiB of handles (B), spacer freed; output = A and B interleaved handle by handle.  For X = 0, 8, ... GiB: how long the
+// steps take, the write-only time of the output and the copy time from a hipMalloc input.
+static int vmm_spacer_mode(size_t handle_mib) {
+    const size_t G = 1ull << 30, H = handle_mib << 20, half = 2 * G / H;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    void* in = nullptr;
+    CK(hipMalloc(&in, 4 * G));
+    g_ntiles = (long)(4 * G / 8 / 4096);
+    study_write<0><<<g_grid, 256>>>((v2f*)in, g_ntiles);
+    for (int k = 0; k < 200; ++k) study_read<0><<<g_grid, 256>>>((const v2f*)in, (v2f*)in, g_ntiles);
+    CK(hipDeviceSynchronize());
+    for (int rep = 0; rep < 2; ++rep)
+        for (size_t spacer_gib : {0, 8, 16, 24, 32, 48, 64, 96}) {
+            std::vector<hipMemGenericAllocationHandle_t> a(half), b(half);
+            double t0 = now_s();
+            for (auto& h : a) CK(hipMemCreate(&h, H, &prop, 0));
+            const double t_a = now_s() - t0;
+            t0 = now_s();
+            void* spacer = nullptr;
+            if (spacer_gib && hipMalloc(&spacer, spacer_gib * G) != hipSuccess) { (void)hipGetLastError(); printf("spacer %zu GiB: no memory\n", spacer_gib); for (auto h : a) CK(hipMemRelease(h)); continue; }
+            const double t_s = now_s() - t0;
+            for (auto& h : b) CK(hipMemCreate(&h, H, &prop, 0));
+            t0 = now_s();
+            if (spacer) CK(hipFree(spacer));
+            const double t_f = now_s() - t0;
+            char* out = nullptr;
+            CK(hipMemAddressReserve((void**)&out, 4 * G, 0, nullptr, 0));
+            t0 = now_s();
+            for (size_t k = 0; k < half; ++k) {
+                CK(hipMemMap(out + (2 * k) * H, H, 0, a[k], 0));
+                CK(hipMemMap(out + (2 * k + 1) * H, H, 0, b[k], 0));
+            }
+            CK(hipMemSetAccess(out, 4 * G, &acc, 1));
+            const double t_m = now_s() - t0;
+            study_write<0><<<g_grid, 256>>>((v2f*)out, g_ntiles);
+            CK(hipDeviceSynchronize());
+            printf("spacer %2zu GiB: create 2 GiB %.0f ms, hipMalloc spacer %.1f ms, hipFree %.1f ms, map 4 GiB %.0f ms | write-only %.3f ms | copy from hipMalloc input %.3f ms\n",
+                   spacer_gib, t_a * 1e3, t_s * 1e3, t_f * 1e3, t_m * 1e3, t_write<0>(out, 6), t_copy<0>(in, out, 6));
+            CK(hipMemUnmap(out, 4 * G));
+            for (auto h : a) CK(hipMemRelease(h));
+            for (auto h : b) CK(hipMemRelease(h));
+            // the virtual range is deliberately not re-used (stale translations, see vmm7)
+        }
+    return 0;
+}
+
 // vmm7: does re-using a virtual range for ANOTHER handle (hipMemUnmap, then hipMemMap) really redirect the accesses?
 // X and Y are two physical 8 MiB handles.  X mapped at S, filled with 1.0; unmapped; Y mapped at S, filled with 2.0;
 // then X and Y are mapped at two FRESH ranges and read back.  Correct: X holds 1.0, Y holds 2.0.
@@ -318,6 +490,8 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&g_e0));
     CK(hipEventCreate(&g_e1));
     if (mode == "vmm7") return vmm7_mode();
+    if (mode == "vmm_spacer") return vmm_spacer_mode(argc > 2 ? atol(argv[2]) : 8);
+    if (mode == "vmm_il") return vmm_il_mode(argc > 2 ? atol(argv[2]) : 8, argc > 3 ? atol(argv[3]) : 120);
     if (mode == "vmm") return vmm_mode(argc > 2 ? atol(argv[2]) : 8, argc > 3 ? atol(argv[3]) : 140);
     size_t free_b = 0, total_b = 0;
     CK(hipMemGetInfo(&free_b, &total_b));
