@@ -122,16 +122,19 @@ const char* smfft_version(void);
 void* smfft_malloc(unsigned long long bytes);
 /* Two buffers of `bytes` each for a kernel that READS the first and WRITES the second.  On MI355X the rate of such a
  * kernel depends on which physical memory the two buffers are (profiles/r02_placement_*,
- * profiles/r02_vmm_mixed_assembly.txt): the HBM falls into three classes of ~89 GiB, and about one physical GiB in seven
- * is MIXED (pure writes 20 % faster, pure reads 7 % slower than ordinary memory).  Input and output ordinary and in the
- * same class -- what two hipMalloc calls in a row give -- move the 4 GiB + 4 GiB N=1024 batch in 1.55-1.60 ms (0.69 of the
- * HBM peak), in different classes in 1.48-1.53 ms, and with the output in mixed memory in 1.30-1.31 ms (0.82).
- * This call takes the input from hipMalloc and BUILDS the output out of mixed memory with the virtual-memory API:
- * physical memory is created in 8 MiB handles, 1 GiB at a time, each GiB is timed with one write-only pass and kept if it
- * is mixed; the scan ends when the output is complete or at its budgets -- a quarter of the free memory
- * (SMFFT_PAIR_BUDGET_FRAC), 2 s (SMFFT_PAIR_BUDGET_MS) -- and whatever is missing then comes from ordinary chunks.  The
- * chosen handles are mapped back to back into one virtual range (an ordinary device pointer for the caller), the rest
- * is released at once.  Buffers are exactly `bytes` long (the output's range is rounded up to 8 MiB).
+ * profiles/r02_vmm_mixed_assembly.txt, profiles/r02_vmm_interleave.txt): physical memory comes in classes, and about one
+ * physical GiB in seven is MIXED (pure writes 20 % faster, pure reads 7 % slower than ordinary memory).  Input and output
+ * ordinary and in the same class -- what two hipMalloc calls in a row give -- move the 4 GiB + 4 GiB N=1024 batch in
+ * 1.55-1.60 ms (0.69 of the HBM peak), in different classes in 1.48-1.53 ms, with the output in mixed memory in
+ * 1.30-1.31 ms (0.82) -- and in 1.32 ms with an output whose 8 MiB pieces alternate between ordinary memory of two classes.
+ * This call takes the input from hipMalloc and BUILDS the output with the virtual-memory API: physical memory is created
+ * in 8 MiB handles, 1 GiB at a time, and each GiB is classified by two write-only passes (mixed or not; same or other
+ * class than the first ordinary GiB); the scan ends as soon as mixed memory plus equal parts of two classes cover the
+ * output (typically 4-17 GiB, 30-250 ms for a 4 GiB output -- what two plain hipMalloc calls of that size cost) or at its
+ * budgets -- a quarter of the free memory (SMFFT_PAIR_BUDGET_FRAC), 2 s (SMFFT_PAIR_BUDGET_MS) -- and whatever is missing
+ * then comes from ordinary chunks.  The chosen handles are blended evenly into one virtual range (an ordinary device
+ * pointer for the caller), the rest is released at once.  Buffers are exactly `bytes` long (the output's range is
+ * rounded up to 8 MiB).
  * SMFFT_PAIR_POLICY=candidates: whole hipMallocAsync / hipMalloc blocks timed as copy targets inside the same budgets
  * (also the fallback where the virtual-memory API is unavailable); =plain: two plain allocations.  Nothing is kept after
  * smfft_free_pair unless SMFFT_PAIR_CACHE=1.  Requests below 256 MiB are served plainly.
@@ -139,7 +142,7 @@ void* smfft_malloc(unsigned long long bytes);
  * Release with smfft_free_pair(d_read) (an error for a pointer this call did not return). */
 int smfft_malloc_pair(unsigned long long bytes, void** d_read, void** d_written);
 /* the same with explicit budgets for this call (a negative value = the default / the environment's): for a process that owns
- * the device and prefers a longer scan to an output that is only partly mixed (bench.py's second attempt) */
+ * the device and prefers a longer scan to an output that is only partly fast (bench.py's second attempt) */
 int smfft_malloc_pair_budget(unsigned long long bytes, void** d_read, void** d_written, double budget_frac, double budget_ms);
 int smfft_free_pair(void* d_read);
 /* gives back the pair SMFFT_PAIR_CACHE=1 keeps */
@@ -148,7 +151,7 @@ int smfft_pair_cache_release(void);
 typedef struct SmfftPairInfo {
     unsigned long long bytes;            /* size of each buffer */
     unsigned long long candidate_bytes;  /* physical memory the scan held at its end (<= max(byte budget + 1 GiB, bytes)) */
-    int candidates;                      /* mixed policy: GiB chunks scanned; candidates policy: blocks probed; 0: plain */
+    int candidates;                      /* mixed policy: GiB chunks scanned (+1 if a remainder was created unprobed); candidates policy: blocks probed; 0: plain */
     int chosen;                          /* mixed policy: GiB of mixed memory in the output; candidates policy: index of the block kept */
     int good_enough;                     /* 1: the output is all mixed or interleaved memory (mixed) / met the 2.3 x read-time criterion (candidates) */
     float read_ms, copy_ms, first_copy_ms;   /* over min(bytes, 1 GiB): pure read of the input; copy into the output; copy into the first chunk / block seen */
