@@ -145,6 +145,11 @@ int smfft_malloc_pair(unsigned long long bytes, void** d_read, void** d_written)
  * the device and prefers a longer scan to an output that is only partly fast (bench.py's second attempt) */
 int smfft_malloc_pair_budget(unsigned long long bytes, void** d_read, void** d_written, double budget_frac, double budget_ms);
 int smfft_free_pair(void* d_read);
+/* Only the WRITTEN buffer, built the same way, for a caller whose input exists already (allocated elsewhere, produced by
+ * another library): changing the allocation of the output is then the one-line way to the rates above.  Release with
+ * smfft_free_written. */
+int smfft_malloc_written(unsigned long long bytes, void** d_written);
+int smfft_free_written(void* d_written);
 /* gives back the pair SMFFT_PAIR_CACHE=1 keeps */
 int smfft_pair_cache_release(void);
 /* what the last smfft_malloc_pair of this process did (telemetry for bench.py and the tests) */

@@ -290,7 +290,8 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
     // the reference a chunk's write pass is judged against: the median chunk (six chunks in seven are ordinary), but not
     // less than the write pass over the input buffer itself (an ordinary hipMalloc block), so that a run of mixed chunks
     // at the start of the scan is recognised as such
-    const float in_write_ms = probe_ms(nullptr, const_cast<void*>(in), bytes < kChunkBytes ? bytes : kChunkBytes, 3) * (float)((double)kChunkBytes / (double)(bytes < kChunkBytes ? bytes : kChunkBytes));
+    // (no input buffer -- smfft_malloc_written: the median alone)
+    const float in_write_ms = !in ? 0.f : probe_ms(nullptr, const_cast<void*>(in), bytes < kChunkBytes ? bytes : kChunkBytes, 3) * (float)((double)kChunkBytes / (double)(bytes < kChunkBytes ? bytes : kChunkBytes));
     auto typical = [&] {
         std::vector<float> t;
         for (auto& c : chunks) if (c.write_ms < 1e29f) t.push_back(c.write_ms);
@@ -354,7 +355,7 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
         ok = ok && hipMemSetAccess(scratch, kChunkBytes, &acc, 1) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); if (scratch) (void)hipMemUnmap(scratch, kChunkBytes); for (auto h : c.hs) (void)hipMemRelease(h); api_ok = !chunks.empty(); break; }
         c.write_ms = probe_ms(nullptr, scratch, kChunkBytes, 3);
-        if (chunks.empty()) info.first_copy_ms = probe_ms(in, scratch, bytes < kChunkBytes ? bytes : kChunkBytes, 3);   // copy into the first (almost surely ordinary) chunk
+        if (chunks.empty() && in) info.first_copy_ms = probe_ms(in, scratch, bytes < kChunkBytes ? bytes : kChunkBytes, 3);   // copy into the first (almost surely ordinary) chunk
         (void)hipMemUnmap(scratch, kChunkBytes);
         chunks.push_back(std::move(c));
         Chunk& last = chunks.back();
@@ -514,8 +515,11 @@ bool pick_candidate_output(size_t bytes, const void* in, const Budget& budget, f
     return true;
 }
 
-int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search, double budget_frac = -1.0, double budget_ms = -1.0) {
-    *d_a = *d_b = nullptr;
+// with_input = false (smfft_malloc_written): only the written buffer, for a caller whose input exists already; the record is
+// kept under the written buffer's address
+int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search, double budget_frac = -1.0, double budget_ms = -1.0, bool with_input = true) {
+    if (d_a) *d_a = nullptr;
+    *d_b = nullptr;
     int device = -1;
     (void)hipGetDevice(&device);
     const char* pol = getenv("SMFFT_PAIR_POLICY");
@@ -523,7 +527,7 @@ int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search, double b
     const bool candidates_only = pol && strcmp(pol, "candidates") == 0;
     SmfftPairInfo info = {};
     info.bytes = bytes;
-    if (!plain && getenv("SMFFT_PAIR_CACHE")) {
+    if (!plain && with_input && getenv("SMFFT_PAIR_CACHE")) {
         std::lock_guard<std::mutex> lock(g_pairs_mutex);
         if (g_pair_cache.a && g_pair_cache.device == device && g_pair_cache.bytes == bytes) {
             PairRec rec = g_pair_cache;
@@ -535,7 +539,7 @@ int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search, double b
         }
     }
     void* in = nullptr;
-    if (hipMalloc(&in, bytes) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    if (with_input && hipMalloc(&in, bytes) != hipSuccess) { (void)hipGetLastError(); return 1; }
     PairRec rec;
     rec.a = in; rec.device = device; rec.bytes = bytes;
     if (!plain) {
@@ -545,21 +549,21 @@ int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search, double b
         budget.bytes = (size_t)((budget_frac >= 0.0 ? budget_frac : env_double("SMFFT_PAIR_BUDGET_FRAC", 0.25)) * (double)free_mem);
         budget.ms = budget_ms >= 0.0 ? budget_ms : env_double("SMFFT_PAIR_BUDGET_MS", 2000.0);
         const size_t window = bytes < kChunkBytes ? bytes : kChunkBytes;
-        info.read_ms = probe_ms(in, nullptr, window, 3);
+        if (in) info.read_ms = probe_ms(in, nullptr, window, 3);
         bool done = !candidates_only && build_mixed_output(bytes, in, device, budget, rec, info);
-        if (!done) done = pick_candidate_output(bytes, in, budget, info.read_ms, rec, info);
-        if (done) info.copy_ms = probe_ms(in, rec.b, window, 3);
+        if (!done && in) done = pick_candidate_output(bytes, in, budget, info.read_ms, rec, info);
+        if (done && in) info.copy_ms = probe_ms(in, rec.b, window, 3);
         info.search_ms = budget.elapsed_ms();
     }
     if (!rec.b) {
-        if (hipMalloc(&rec.b, bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(in); return 1; }
+        if (hipMalloc(&rec.b, bytes) != hipSuccess) { (void)hipGetLastError(); if (in) (void)hipFree(in); return 1; }
     }
     {
         std::lock_guard<std::mutex> lock(g_pairs_mutex);
-        g_pairs[rec.a] = rec;
+        g_pairs[with_input ? rec.a : rec.b] = rec;
         g_last_pair_info = info;
     }
-    *d_a = rec.a;
+    if (d_a) *d_a = rec.a;
     *d_b = rec.b;
     return 0;
 }
@@ -573,14 +577,14 @@ int free_pair(void* d_a) {
         if (it == g_pairs.end()) return (int)hipErrorInvalidValue;   // not a pair of this allocator: nothing is freed
         rec = it->second;
         g_pairs.erase(it);
-        if (rec.searched && getenv("SMFFT_PAIR_CACHE")) {
+        if (rec.searched && rec.a && getenv("SMFFT_PAIR_CACHE")) {
             evicted = g_pair_cache;
             g_pair_cache = rec;
             rec = evicted;
             if (!rec.a) return 0;
         }
     }
-    int rc = (int)hipFree(rec.a);
+    int rc = rec.a ? (int)hipFree(rec.a) : 0;
     release_output(rec);
     return rc;
 }
@@ -846,6 +850,8 @@ int smfft_set_device(int device) { read_env(); g_device = device; return (int)hi
 const char* smfft_version(void) { return "smfft_amd 0.1 (gfx950)"; }
 
 int smfft_malloc_pair(unsigned long long bytes, void** d_read, void** d_written) { read_env(); return alloc_pair((size_t)bytes, d_read, d_written, true); }
+int smfft_malloc_written(unsigned long long bytes, void** d_written) { read_env(); return alloc_pair((size_t)bytes, nullptr, d_written, true, -1.0, -1.0, false); }
+int smfft_free_written(void* d_written) { return free_pair(d_written); }
 int smfft_malloc_pair_budget(unsigned long long bytes, void** d_read, void** d_written, double budget_frac, double budget_ms) {
     read_env();
     return alloc_pair((size_t)bytes, d_read, d_written, true, budget_frac, budget_ms);

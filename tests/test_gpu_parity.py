@@ -635,6 +635,30 @@ def _settled_usage(sm, free0, limit):
     return used
 
 
+def test_malloc_written_with_a_callers_own_input(sm):
+    """smfft_malloc_written: only the output is built (mixed / interleaved memory); the input is the caller's plain buffer."""
+    import ctypes
+    nbytes = 1 << 30
+    free0 = _free_bytes(sm)
+    x = (np.random.default_rng(2).random((64, 1024, 2), dtype=np.float32)).view(np.complex64).reshape(64, 1024)
+    src = sm.DeviceBuffer.from_host(x)
+    out = ctypes.c_void_p()
+    assert sm.lib.smfft_malloc_written(nbytes, ctypes.byref(out)) == 0 and out.value
+    info = sm.last_pair_info()
+    print("smfft_malloc_written:", info)
+    assert info["bytes"] == nbytes and info["mixed_bytes"] + info["interleaved_bytes"] <= nbytes and info["read_ms"] == 0.0
+    assert sm.lib.smfft_memset(out.value, 0, nbytes) == 0                       # the whole range is mapped
+    rc, _ = sm.FFT_external_benchmark(src.ptr, out.value, 1024, 64)
+    got = np.empty_like(x)
+    sm.lib.smfft_memcpy_d2h(got.ctypes.data, out.value, x.nbytes)
+    ref.assert_close_fp32(got, ref.ct_c2c(x, False, True), "written buffer")
+    assert sm.lib.smfft_free_pair(src.ptr) != 0                                 # not a pair
+    assert sm.lib.smfft_free_written(out.value) == 0
+    assert sm.lib.smfft_free_written(out.value) != 0
+    src.free()
+    assert _settled_usage(sm, free0, 256 << 20) <= (256 << 20)
+
+
 def test_malloc_pair_plain_policy_and_many_pairs(sm, monkeypatch):
     """SMFFT_PAIR_POLICY=plain: two plain allocations, no probing; the pair table grows as needed (more than the 64
     slots round 1 had) and every pair is released by its read pointer."""
