@@ -138,7 +138,7 @@ void* smfft_malloc(unsigned long long bytes);
  * SMFFT_PAIR_POLICY=candidates: whole hipMallocAsync / hipMalloc blocks timed as copy targets inside the same budgets
  * (also the fallback where the virtual-memory API is unavailable); =plain: two plain allocations.  Nothing is kept after
  * smfft_free_pair unless SMFFT_PAIR_CACHE=1.  Requests below 256 MiB are served plainly.
- * The L3 wrappers allocate plainly, like the reference (CT:850-853), unless SMFFT_WRAPPER_PLACEMENT=1.
+ * The L3 wrappers take their two buffers from this call; SMFFT_WRAPPER_PLACEMENT=0: two plain allocations as upstream (CT:850-853).
  * Release with smfft_free_pair(d_read) (an error for a pointer this call did not return). */
 int smfft_malloc_pair(unsigned long long bytes, void** d_read, void** d_written);
 /* the same with explicit budgets for this call (a negative value = the default / the environment's): for a process that owns

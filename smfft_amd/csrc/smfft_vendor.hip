@@ -15,9 +15,9 @@
 #include "../../include/smfft_reference_api.h"
 #include "smfft_host_util.hpp"
 
-// Both libraries of a harness run are timed on the same KIND of buffers: two plain allocations by default (what the
-// reference's wrappers do), the placement search of smfft_malloc_pair for both when SMFFT_WRAPPER_PLACEMENT=1 (the
-// switch the smFFT wrappers follow).  libsmfft_amd.so is looked up at run time so this library keeps no link dependency.
+// Both libraries of a harness run are timed on the same KIND of buffers: a smfft_malloc_pair pair by default, two plain
+// allocations (what the reference's wrappers do) for both with SMFFT_WRAPPER_PLACEMENT=0 -- the switch the smFFT wrappers
+// follow.  libsmfft_amd.so is looked up at run time so this library keeps no link dependency.
 struct VendorPair {
     void *in = nullptr, *out = nullptr;
     bool placed = false;
@@ -25,7 +25,7 @@ struct VendorPair {
 static VendorPair vendor_alloc(size_t in_bytes, size_t out_bytes) {
     VendorPair p;
     const char* e = getenv("SMFFT_WRAPPER_PLACEMENT");
-    if (e && atoi(e) != 0 && in_bytes == out_bytes) {
+    if (!(e && atoi(e) == 0) && in_bytes == out_bytes) {
         typedef int (*pair_fn)(unsigned long long, void**, void**);
         pair_fn f = (pair_fn)dlsym(RTLD_DEFAULT, "smfft_malloc_pair");
         if (f && f(in_bytes, &p.in, &p.out) == 0) { p.placed = true; return p; }

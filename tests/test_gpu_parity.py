@@ -376,16 +376,17 @@ def test_reference_shaped_multiple_kernels_launch(sm):
     assert sm.lib.smfft_synchronize() == 0
 
 
-def test_harness_with_wrapper_placement(sm):
-    """SMFFT_WRAPPER_PLACEMENT=1: the L3 wrapper and the hipFFT comparator both take their buffers from smfft_malloc_pair
-    (the output a VMM-backed range): the harness still passes."""
+@pytest.mark.parametrize("placement", ["1", "0"])
+def test_harness_with_wrapper_placement(sm, placement):
+    """The L3 wrapper and the hipFFT comparator both take their buffers from smfft_malloc_pair (the output a VMM-backed
+    range; default) or both allocate plainly like upstream (SMFFT_WRAPPER_PLACEMENT=0): the harness passes either way."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "harness", "FFT_CooleyTukey_C2C.exe")
     if not os.path.exists(exe):
         pytest.skip("harness not built")
-    env = dict(os.environ, SMFFT_WRAPPER_PLACEMENT="1", SMFFT_PAIR_BUDGET_FRAC="0.05")
+    env = dict(os.environ, SMFFT_WRAPPER_PLACEMENT=placement, SMFFT_PAIR_BUDGET_FRAC="0.05")
     p = subprocess.run([exe, "1024", "262144", "3", "0", "1"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "PASSED" in p.stdout and "FAILED" not in p.stdout, p.stdout + p.stderr
 
