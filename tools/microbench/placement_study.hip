@@ -373,6 +373,102 @@ static int vmm_il_mode(size_t handle_mib, size_t max_gib) {
     return 0;
 }
 
+// vmm_cls: the three classes told apart with the interleave probe (write pass over a 1 GiB range in which the handles of two
+// chunks alternate: fast = different classes): A = the class of the first ordinary chunk, B = the class of the first chunk that
+// differs from it, C = what differs from both.  Then: input from A; outputs from one class, and interleaved from two -- is an
+// output that shares NO class with the input better still?
+static int vmm_cls_mode(size_t handle_mib, size_t max_gib) {
+    const size_t G = 1ull << 30, H = handle_mib << 20, per_chunk = G / H;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    size_t free_b = 0, total_b = 0;
+    CK(hipMemGetInfo(&free_b, &total_b));
+    size_t nchunks = std::min<size_t>(max_gib, (free_b - (24ull << 30)) / G);
+    char* va = nullptr;
+    CK(hipMemAddressReserve((void**)&va, nchunks * G, 0, nullptr, 0));
+    std::vector<hipMemGenericAllocationHandle_t> handle(nchunks * per_chunk);
+    for (size_t h = 0; h < handle.size(); ++h) CK(hipMemCreate(&handle[h], H, &prop, 0));
+    for (size_t h = 0; h < nchunks * per_chunk; ++h) CK(hipMemMap(va + h * H, H, 0, handle[h], 0));
+    CK(hipMemSetAccess(va, nchunks * G, &acc, 1));
+    g_ntiles = (long)(G / 8 / 4096);
+    for (size_t j = 0; j < nchunks; ++j) study_write<0><<<g_grid, 256>>>((v2f*)(va + j * G), g_ntiles);
+    CK(hipDeviceSynchronize());
+    for (int k = 0; k < 300; ++k) study_copy<0><<<g_grid, 256>>>((const v2f*)va, (v2f*)(va + G), g_ntiles);
+    CK(hipDeviceSynchronize());
+    std::vector<float> wr(nchunks);
+    for (size_t j = 0; j < nchunks; ++j) wr[j] = t_write<0>(va + j * G, 4);
+    std::vector<float> sorted_wr(wr);
+    std::sort(sorted_wr.begin(), sorted_wr.end());
+    const float wr_typ = sorted_wr[nchunks / 2];
+    CK(hipMemUnmap(va, nchunks * G));
+    std::vector<size_t> ordinary;
+    for (size_t j = 0; j < nchunks; ++j) if (wr[j] > 0.97f * wr_typ) ordinary.push_back(j);
+    auto differs = [&](size_t x, size_t y) {
+        char* t = nullptr;
+        CK(hipMemAddressReserve((void**)&t, G, 0, nullptr, 0));
+        for (size_t k = 0; k < per_chunk / 2; ++k) {
+            CK(hipMemMap(t + (2 * k) * H, H, 0, handle[x * per_chunk + k], 0));
+            CK(hipMemMap(t + (2 * k + 1) * H, H, 0, handle[y * per_chunk + k], 0));
+        }
+        CK(hipMemSetAccess(t, G, &acc, 1));
+        g_ntiles = (long)(G / 8 / 4096);
+        const float ms = t_write<0>(t, 4);
+        CK(hipMemUnmap(t, G));
+        return ms < 0.91f * wr_typ;
+    };
+    std::vector<size_t> cls[3];
+    cls[0].push_back(ordinary[0]);
+    for (size_t i = 1; i < ordinary.size(); ++i) {
+        const size_t j = ordinary[i];
+        if (!differs(cls[0][0], j)) cls[0].push_back(j);
+        else if (cls[1].empty() || !differs(cls[1][0], j)) cls[1].push_back(j);
+        else cls[2].push_back(j);
+    }
+    printf("vmm_cls: %zu chunks, %zu strictly ordinary: class A %zu, B %zu, C %zu chunks\nclass by chunk:", nchunks, ordinary.size(), cls[0].size(), cls[1].size(), cls[2].size());
+    {
+        std::vector<char> tag(nchunks, '.');
+        for (int c = 0; c < 3; ++c) for (size_t j : cls[c]) tag[j] = (char)('A' + c);
+        for (size_t j = 0; j < nchunks; ++j) printf("%c", tag[j]);
+        printf("\n");
+    }
+    if (cls[0].size() < 12 || cls[1].size() < 8 || cls[2].size() < 8) { printf("not enough chunks of every class\n"); return 0; }
+    size_t next[3] = {0, 0, 0};
+    g_ntiles = (long)(4 * G / 8 / 4096);
+    auto build = [&](std::vector<int> ways, const char* what) -> char* {     // 4 GiB, handles round-robin over the listed classes
+        std::vector<size_t> ch(ways.size()), used(ways.size(), 0);
+        for (size_t w = 0; w < ways.size(); ++w) ch[w] = cls[ways[w]][next[ways[w]]++];
+        char* t = nullptr;
+        CK(hipMemAddressReserve((void**)&t, 4 * G, 0, nullptr, 0));
+        for (size_t k = 0; k < 4 * per_chunk; ++k) {
+            const size_t w = k % ways.size();
+            if (used[w] == per_chunk) { ch[w] = cls[ways[w]][next[ways[w]]++]; used[w] = 0; }
+            CK(hipMemMap(t + k * H, H, 0, handle[ch[w] * per_chunk + used[w]++], 0));
+        }
+        CK(hipMemSetAccess(t, 4 * G, &acc, 1));
+        study_write<0><<<g_grid, 256>>>((v2f*)t, g_ntiles);
+        CK(hipDeviceSynchronize());
+        printf("assembled %s\n", what);
+        return t;
+    };
+    char* inA = build({0}, "inA");
+    struct Case { const char* name; char* in; char* out; };
+    std::vector<Case> cases = {{"A -> A", inA, build({0}, "outA")}, {"A -> B", inA, build({1}, "outB")}, {"A -> C", inA, build({2}, "outC")},
+                               {"A -> il(A,B)", inA, build({0, 1}, "outAB")}, {"A -> il(A,C)", inA, build({0, 2}, "outAC")}, {"A -> il(B,C)", inA, build({1, 2}, "outBC")},
+                               {"A -> il(A,B,C)", inA, build({0, 1, 2}, "outABC")}};
+    char* inBC = build({1, 2}, "inBC (interleaved input)");
+    cases.push_back({"il(B,C) -> A", inBC, cases[0].out});
+    for (int rep = 0; rep < 2; ++rep)
+        for (auto& c : cases)
+            printf("%-16s copy %.3f ms | paced copy %.3f ms | write-only %.3f ms | read-only %.3f ms\n", c.name, t_copy<0>(c.in, c.out, 6), t_paced<0>(c.in, c.out, 6),
+                   t_write<0>(c.out, 6), t_read<0>(c.in, c.out, 6));
+    return 0;
+}
+
 // vmm_spacer: the cheap way to physical memory of ANOTHER class: 2 GiB of handles (A), one plain hipMalloc of X GiB as a
 // spacer, 2 GiB of handles (B), spacer freed; output = A and B interleaved handle by handle.  For X = 0, 8, ... GiB: how long the
 // steps take, the write-only time of the output and the copy time from a hipMalloc input.
@@ -490,6 +586,7 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&g_e0));
     CK(hipEventCreate(&g_e1));
     if (mode == "vmm7") return vmm7_mode();
+    if (mode == "vmm_cls") return vmm_cls_mode(argc > 2 ? atol(argv[2]) : 8, argc > 3 ? atol(argv[3]) : 140);
     if (mode == "vmm_spacer") return vmm_spacer_mode(argc > 2 ? atol(argv[2]) : 8);
     if (mode == "vmm_il") return vmm_il_mode(argc > 2 ? atol(argv[2]) : 8, argc > 3 ? atol(argv[3]) : 120);
     if (mode == "vmm") return vmm_mode(argc > 2 ? atol(argv[2]) : 8, argc > 3 ? atol(argv[3]) : 140);
