@@ -485,7 +485,7 @@ bool pick_candidate_output(size_t bytes, const void* in, const Budget& budget, f
     int best = -1;
     bool good = false;
     while (!good) {
-        const bool pool = cands.empty() && getenv("SMFFT_NO_POOL_SHORTCUT") == nullptr;
+        const bool pool = cands.empty();
         if (!cands.empty() && (used + bytes > budget.bytes || budget.elapsed_ms() > budget.ms)) break;
         void* p = nullptr;
         hipError_t rc = pool ? hipMallocAsync(&p, bytes, 0) : hipMalloc(&p, bytes);
@@ -523,7 +523,7 @@ int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search, double b
     int device = -1;
     (void)hipGetDevice(&device);
     const char* pol = getenv("SMFFT_PAIR_POLICY");
-    const bool plain = !allow_search || getenv("SMFFT_NO_PAIR_PLACEMENT") != nullptr || (pol && strcmp(pol, "plain") == 0) || bytes < (256ull << 20);
+    const bool plain = !allow_search || (pol && strcmp(pol, "plain") == 0) || bytes < (256ull << 20);
     const bool candidates_only = pol && strcmp(pol, "candidates") == 0;
     SmfftPairInfo info = {};
     info.bytes = bytes;
