@@ -45,23 +45,27 @@ namespace smfft {
 template <int L, int DIR>
 __device__ __forceinline__ void hermitian_pass(float2* sf, int u) {
     constexpr int T = L / 16;
-    constexpr float ohx = DIR ? -0.5f : 0.5f, ohy = DIR ? 0.5f : -0.5f;
+    constexpr float ohx = DIR ? -0.5f : 0.5f;   // upstream's (ohx, ohy) = (1/2, -1/2) forward, (-1/2, 1/2) inverse (RC:289-328)
     if (DIR) {
         if (u == 0) {
             float2 z = sf[0];
             sf[0] = make_float2(0.5f * (z.x + z.y), 0.5f * (z.x - z.y));
         }
     }
+    // H1 = S/2 with S = (A.x + B.x, A.y - B.y); H2 = (ohx * D.x, ohy * D.y) with D = (A.y + B.y, A.x - B.x) and ohy = -ohx,
+    // so W * H2 = ((ohx W).x D.x + (ohx W).y D.y, (ohx W).y D.x - (ohx W).x D.y): with ohx folded into the twiddle (loop
+    // invariant across the applications of the in-LDS kernels) a pair costs 12 instructions instead of 16
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int i = 1 + u + T * j;
-        float2 A = sf[i], B = sf[L - i];
-        float2 H1 = make_float2(0.5f * (A.x + B.x), 0.5f * (A.y - B.y));
-        float2 H2 = make_float2(ohx * (A.y + B.y), ohy * (A.x - B.x));
-        float2 W = twiddle<DIR>(i * (4096 / (2 * L)));
-        float2 WH = cmul(H2, W);
-        sf[i] = make_float2(H1.x + WH.x, H1.y + WH.y);
-        sf[L - i] = make_float2(H1.x - WH.x, -H1.y + WH.y);   // for i == L/2 this value stays (RC:308)
+        const float2 A = sf[i], B = sf[L - i];
+        const float2 W = twiddle<DIR>(i * (4096 / (2 * L)));
+        const float2 Wh = make_float2(ohx * W.x, ohx * W.y);
+        const float2 S = make_float2(A.x + B.x, A.y - B.y);
+        const float2 D = make_float2(A.y + B.y, A.x - B.x);
+        const float2 WH = make_float2(fmaf(Wh.x, D.x, Wh.y * D.y), fmaf(Wh.y, D.x, -Wh.x * D.y));
+        sf[i] = make_float2(fmaf(0.5f, S.x, WH.x), fmaf(0.5f, S.y, WH.y));
+        sf[L - i] = make_float2(fmaf(0.5f, S.x, -WH.x), fmaf(-0.5f, S.y, WH.y));   // for i == L/2 this value stays (RC:308)
     }
     if (!DIR) {
         if (u == 0) {   // sf[0] is not touched by the pair loop (i >= 1, L - i >= L/2)
