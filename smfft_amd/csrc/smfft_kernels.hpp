@@ -295,7 +295,10 @@ struct HermitianRegisters {
     // All sixteen partner values fetched at once: thirty-two ds_bpermute back to back, their latencies overlapped, at the
     // price of 135-146 VGPRs (3 waves per SIMD).  An in-place form that fetched two partners at a time, software-pipelined,
     // at 93-113 VGPRs = 4 waves per SIMD measured 0.6-2 % SLOWER on the same buffers (profiles/r02_ab_rc.txt) and is gone.
-    // sf: the FFT's LDS region (kFromLds only; free on entry, the caller orders its later re-use)
+    // sf: the FFT's LDS region (kFromLds only; free on entry, the caller orders its later re-use).
+    // RESIDENT = true (the in-LDS kernels): the data the registers were loaded from still lies in sf in natural order, so
+    // the partners are read from there without the store -- the split / merge fused into a load.
+    template <bool RESIDENT = false>
     __device__ __forceinline__ void apply(float2 (&r)[16], float2* sf = nullptr) const {
         constexpr float c32[16] = {1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f, 0.55557023301960229f,
                                    0.38268343236508984f, 0.19509032201612833f, 0.f, -0.19509032201612819f, -0.38268343236508973f, -0.55557023301960196f,
@@ -304,18 +307,18 @@ struct HermitianRegisters {
                                    0.92387953251128674f, 0.98078528040323043f, 1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254546f,
                                    0.70710678118654757f, 0.55557023301960218f, 0.38268343236508989f, 0.19509032201612861f};
         float2 B[16];
-        if constexpr (kFromLds) {
+        if constexpr (kFromLds || RESIDENT) {
             const int u = threadIdx.x % T;
+            if constexpr (!RESIDENT) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) sf[u + T * q] = r[q];
-            fft_sync<(T > 64)>();
-            const float2* partner = sf + ((T - u) % T);     // x[L - (u + T*q)] = x[(T - u) + T*(15 - q)], u > 0
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float2 own = r[(16 - q) & 15];
-                const float2 got = partner[T * (15 - q)];
-                B[q] = first ? own : got;
+                for (int q = 0; q < 16; ++q) sf[u + T * q] = r[q];
+                fft_sync<(T > 64)>();
             }
+            // x[L - (u + T*q)] = x[(T - u) + T*(15 - q)] -- for thread 0, too (x[T*(16 - q)], q >= 1); its q = 0 reads one
+            // element past the data (inside the region's padding) and is replaced by the packed DC / Nyquist value below
+            const float2* partner = sf + (T - u);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) B[q] = partner[T * (15 - q)];
         } else {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -326,12 +329,17 @@ struct HermitianRegisters {
                 B[q] = first ? own : make_float2(bx, by);
             }
         }
+        // the fifteen products V are the same for every tile and application: the external kernels let the compiler keep
+        // them in 30 registers across the grid-stride loop; the in-LDS kernels (RESIDENT), which live on their occupancy,
+        // recompute them -- the copy below is opaque to the compiler
+        float2 w = wu;
+        if constexpr (RESIDENT) asm volatile("" : "+v"(w.x), "+v"(w.y));
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const float2 A = r[q];
             const float2 S = make_float2(A.x + B[q].x, A.y - B[q].y);       // A + conj(B)
             const float2 D = make_float2(A.x - B[q].x, A.y + B[q].y);       // A - conj(B)
-            const float2 V = (q == 0) ? wu : cmul(wu, make_float2(c32[q], DIR ? s32[q] : -s32[q]));   // (-+i/2) * W^i
+            const float2 V = (q == 0) ? w : cmul(w, make_float2(c32[q], DIR ? s32[q] : -s32[q]));   // (-+i/2) * W^i
             float2 out = make_float2(fmaf(V.x, D.x, fmaf(-V.y, D.y, 0.5f * S.x)), fmaf(V.x, D.y, fmaf(V.y, D.x, 0.5f * S.y)));
             if (q == 0) {   // element 0 of thread 0 packs DC and Nyquist (RC:280-286, 332-339)
                 const float2 packed = DIR ? make_float2(0.5f * (A.x + A.y), 0.5f * (A.x - A.y)) : make_float2(A.x + A.y, A.x - A.y);
@@ -395,21 +403,52 @@ __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__
     }
 }
 
+#ifndef SMFFT_RC_MULTIPLE_FUSED
+#define SMFFT_RC_MULTIPLE_FUSED 1
+#endif
 template <int L, int DIR>
 __device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, float2* s) {
     using G = Geometry<L>;
     Engine<L, DIR, 1> eng;
     eng.init(threadIdx.x);
+#if SMFFT_RC_MULTIPLE_FUSED
+    HermitianRegisters<L, DIR> herm;
+    herm.init(threadIdx.x);
+#endif
     const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long first = (long)tile * G::kCompactFfts;
         fft_sync<G::kMultiWave>();
         tile_to_lds<L, false>(d_input + first * L, s, first, nSlots);
         fft_sync<G::kMultiWave>();
+#if SMFFT_RC_MULTIPLE_FUSED
+        // The split (R2C, after the FFT) / merge (C2R, before it) of an application is fused into the LOAD of the transform
+        // that follows it: the partner x[L - i] is read from the resident data next to x[i] and the pair is combined in
+        // registers -- two LDS round trips per application instead of three (the LDS-resident pass reads and re-writes the
+        // data once more).  R2C: the first load is plain and the last split is the LDS pass.
+        float2* sf = s + eng.fft * G::SF;
+        for (int f = 0; f < nreuses; ++f) {
+            float2 r[16];
+            eng.load_lds(r, sf);
+            if (DIR == 1 || f > 0) herm.template apply<true>(r, sf);
+            fft_sync<G::kMultiWave>();          // every read of the region is done before the exchanges write into it
+            eng.transform(r, sf);
+            fft_sync<G::kMultiWave>();
+            eng.store_lds(r, sf);
+            fft_sync<G::kMultiWave>();
+        }
+        if (DIR == 0) {
+            int u = eng.u;
+            asm volatile("" : "+v"(u));         // keeps the pass's eight twiddle loads after the loop (16 registers less in it)
+            hermitian_pass<L, 0>(sf, u);
+            fft_sync<G::kMultiWave>();
+        }
+#else
         for (int f = 0; f < nreuses; ++f) {
             r2c_c2r_lds_inplace<L, DIR, true>(s, eng);
             fft_sync<G::kMultiWave>();
         }
+#endif
         lds_to_tile<L, false>(d_output + first * L, s, first, nSlots);
     }
 }
