@@ -11,6 +11,7 @@
 #include <chrono>
 #include <map>
 #include <mutex>
+#include <set>
 #include <vector>
 
 #include "../../include/smfft.h"
@@ -171,6 +172,7 @@ int pacing_for(const void* d_output, int k_ordinary, int k_mixed) {
 
 constexpr double kGoodRatio = 2.30;    // candidates policy: mixed targets copy in 2.2-2.3 x the pure read time; other class 2.5; same class 2.6
 constexpr float kMixedWriteRatio = 0.91f;   // mixed policy: a chunk is mixed if its write pass takes < 0.91 x the typical one (mixed: 0.79-0.88)
+constexpr float kOrdinaryWriteRatio = 0.96f;   // ... and clearly ordinary above 0.96 x (ordinary chunks scatter by +-3 %)
 #ifndef SMFFT_PAIR_HANDLE_MIB
 #define SMFFT_PAIR_HANDLE_MIB 8
 #endif
@@ -282,7 +284,7 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
     enum Kind { kUnknown, kSameClass, kOtherClass };
     struct Chunk { std::vector<hipMemGenericAllocationHandle_t> hs; float write_ms; Kind kind; };
     std::vector<Chunk> chunks;
-    size_t created = 0, extra_after_enough = 0;
+    size_t created = 0, first_covered = 0;
     int reference = -1;            // the first ordinary chunk: the class the others are compared with
     bool api_ok = true;
     const bool interleave = getenv("SMFFT_PAIR_NO_INTERLEAVE") == nullptr;   // A/B and test switches: only mixed chunks count /
@@ -328,13 +330,14 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
         return ms < kMixedWriteRatio * 0.5f * (x.write_ms + y.write_ms);
     };
     while (true) {
-        // covered by mixed memory alone: at most four more chunks are scanned for up to two spare mixed GiB (the output
-        // then takes the fastest ones); covered with the help of interleaved ordinary chunks: done; else to the budgets
+        // covered (mixed memory plus equal parts of two classes make an output): up to six more chunks are scanned so that
+        // either recipe alone -- all mixed, all interleaved -- is complete (the choice between them is measured, see below,
+        // and spare mixed chunks let the output take the fastest ones); else to the budgets
         const Tally have = chunks.empty() ? Tally{0, 0, 0} : tally();
-        if (have.mixed >= need && extra_after_enough == 0) extra_after_enough = chunks.size() + 4;
         const bool covered = have.mixed + 2 * std::min(have.same, have.other) >= need;
-        if (!chunks.empty() && (have.mixed >= need + 2 * per_chunk || (extra_after_enough && chunks.size() >= extra_after_enough)
-                                || (covered && have.mixed < need)
+        const bool both = have.mixed >= need && 2 * std::min(have.same, have.other) >= need;
+        if (covered && first_covered == 0) first_covered = chunks.size();
+        if (!chunks.empty() && (both || (covered && chunks.size() >= first_covered + 6)
                                 || created + kChunkBytes > budget.bytes || budget.elapsed_ms() > budget.ms)) break;
         Chunk c;
         c.kind = kUnknown;
@@ -359,7 +362,9 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
         (void)hipMemUnmap(scratch, kChunkBytes);
         chunks.push_back(std::move(c));
         Chunk& last = chunks.back();
-        if (interleave && !is_mixed(last, typical())) {
+        // only CLEARLY ordinary chunks are classified (and only such a chunk is the reference): one whose own pass lies
+        // between the two kinds is partly mixed, its probes against other chunks come out between the two answers
+        if (interleave && last.write_ms > kOrdinaryWriteRatio * typical()) {
             if (reference < 0) { reference = (int)chunks.size() - 1; last.kind = kSameClass; }
             else last.kind = other_class(chunks[reference], last) ? kOtherClass : kSameClass;
         }
@@ -395,38 +400,47 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
     // numbers.  The pools are spread EVENLY over the range (largest-remainder round-robin), so that every part of the buffer
     // is the same blend -- a caller that uses half of it gets the same rate as one that uses all of it -- and neighbouring
     // handles alternate between the classes.  What the pools cannot cover comes from the remaining ordinary memory, at the end.
+    // Which blend is best depends on the class of the INPUT, which cannot be probed (a hipMalloc block has no handles): an
+    // output that shares no class with it is 1.4 % better than one that does, and what a mixed chunk consists of is not known
+    // either (profiles/r02_vmm_classes.txt).  So when the scan holds enough for both, the two recipes -- mixed memory first,
+    // interleaved classes only -- are each mapped at a range of their own and TIMED as the target of a copy from the real
+    // input; the faster one is kept.
     const float typ = typical();
-    std::vector<hipMemGenericAllocationHandle_t> chosen;
-    size_t mixed_used = 0, interleaved_used = 0;
-    {
-        auto drain = [&](std::vector<size_t> order, size_t limit) {       // handles of these chunks, round-robin across them
+    std::vector<size_t> m_chunks, s_chunks, o_chunks;
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        if (is_mixed(chunks[i], typ)) m_chunks.push_back(i);
+        else if (chunks[i].kind == kSameClass) s_chunks.push_back(i);
+        else if (chunks[i].kind == kOtherClass) o_chunks.push_back(i);
+    }
+    std::sort(m_chunks.begin(), m_chunks.end(), [&](size_t x, size_t y) { return chunks[x].write_ms < chunks[y].write_ms; });
+    size_t m_total = 0, s_total = 0, o_total = 0;
+    for (size_t i : m_chunks) m_total += chunks[i].hs.size();
+    for (size_t i : s_chunks) s_total += chunks[i].hs.size();
+    for (size_t i : o_chunks) o_total += chunks[i].hs.size();
+    struct Recipe { size_t m_take; const char* name; };
+    struct Built { std::vector<hipMemGenericAllocationHandle_t> hs; size_t mixed_used = 0, interleaved_used = 0; };
+    auto build = [&](const Recipe& rc) {
+        Built out_b;
+        auto take = [&](std::vector<size_t> order, size_t limit) {       // handles of these chunks, round-robin across them
             std::vector<hipMemGenericAllocationHandle_t> pool;
+            std::vector<size_t> pos(order.size(), 0);
             for (bool any = true; any && pool.size() < limit;) {
                 any = false;
-                for (size_t i : order)
-                    if (!chunks[i].hs.empty() && pool.size() < limit) { pool.push_back(chunks[i].hs.back()); chunks[i].hs.pop_back(); any = true; }
+                for (size_t k = 0; k < order.size(); ++k) {
+                    const auto& hs = chunks[order[k]].hs;
+                    if (pos[k] < hs.size() && pool.size() < limit) { pool.push_back(hs[pos[k]++]); any = true; }
+                }
             }
             return pool;
         };
-        std::vector<size_t> m_chunks, s_chunks, o_chunks;
-        for (size_t i = 0; i < chunks.size(); ++i) {
-            if (is_mixed(chunks[i], typ)) m_chunks.push_back(i);
-            else if (chunks[i].kind == kSameClass) s_chunks.push_back(i);
-            else if (chunks[i].kind == kOtherClass) o_chunks.push_back(i);
-        }
-        std::sort(m_chunks.begin(), m_chunks.end(), [&](size_t x, size_t y) { return chunks[x].write_ms < chunks[y].write_ms; });
-        size_t m_total = 0, s_total = 0, o_total = 0;
-        for (size_t i : m_chunks) m_total += chunks[i].hs.size();
-        for (size_t i : s_chunks) s_total += chunks[i].hs.size();
-        for (size_t i : o_chunks) o_total += chunks[i].hs.size();
-        // as many whole mixed chunks as fit (the fastest), the rest in equal parts from the two classes
-        const size_t m_take = std::min(m_total, need);
-        const size_t each = std::min((need - m_take + 1) / 2, std::min(s_total, o_total));
-        if (m_take < m_total) m_chunks.resize((m_take + per_chunk - 1) / per_chunk);
+        // as many whole mixed chunks as the recipe takes (the fastest), the rest in equal parts from the two classes
+        const size_t each = std::min((need - rc.m_take + 1) / 2, std::min(s_total, o_total));
+        std::vector<size_t> mc = m_chunks;
+        if (rc.m_take < m_total) mc.resize((rc.m_take + per_chunk - 1) / per_chunk);
         std::vector<hipMemGenericAllocationHandle_t> pool[3];
-        pool[0] = drain(m_chunks, m_take);
-        pool[1] = drain(s_chunks, each);
-        pool[2] = drain(o_chunks, std::min(each, need - m_take - pool[1].size()));
+        pool[0] = take(mc, rc.m_take);
+        pool[1] = take(s_chunks, each);
+        pool[2] = take(o_chunks, std::min(each, need - rc.m_take - pool[1].size()));
         const size_t count[3] = {pool[0].size(), pool[1].size(), pool[2].size()};
         const size_t blended = count[0] + count[1] + count[2];
         size_t next[3] = {0, 0, 0};
@@ -439,21 +453,50 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
                 if (best < 0 || acc[q] > acc[best]) best = q;
             }
             acc[best] -= (double)blended;
-            chosen.push_back(pool[best][next[best]++]);
+            out_b.hs.push_back(pool[best][next[best]++]);
         }
-        mixed_used = count[0];
-        interleaved_used = count[1] + count[2];
-        for (size_t i = chunks.size(); i-- > 0 && chosen.size() < need;)
-            while (!chunks[i].hs.empty() && chosen.size() < need) { chosen.push_back(chunks[i].hs.back()); chunks[i].hs.pop_back(); }
+        out_b.mixed_used = count[0];
+        out_b.interleaved_used = count[1] + count[2];
+        if (out_b.hs.size() < need) {                                    // the rest: ordinary memory, last scanned first
+            std::set<hipMemGenericAllocationHandle_t> used(out_b.hs.begin(), out_b.hs.end());
+            for (size_t i = chunks.size(); i-- > 0 && out_b.hs.size() < need;)
+                for (size_t k = chunks[i].hs.size(); k-- > 0 && out_b.hs.size() < need;)
+                    if (!used.count(chunks[i].hs[k])) out_b.hs.push_back(chunks[i].hs[k]);
+        }
+        return out_b;
+    };
+    auto map_at = [&](char* va, const std::vector<hipMemGenericAllocationHandle_t>& hs) {
+        size_t mapped = 0;
+        bool ok = true;
+        for (; mapped < hs.size() && ok; ++mapped) ok = hipMemMap(va + mapped * kHandleBytes, kHandleBytes, 0, hs[mapped], 0) == hipSuccess;
+        ok = ok && hipMemSetAccess(va, hs.size() * kHandleBytes, &acc, 1) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); if (mapped) (void)hipMemUnmap(va, mapped * kHandleBytes); }
+        return ok;
+    };
+    std::vector<Recipe> recipes = {{std::min(m_total, need), "mixed first"}};
+    if (m_total > 0 && 2 * std::min(s_total, o_total) >= need && getenv("SMFFT_PAIR_NO_COMPARE") == nullptr) recipes.push_back({0, "interleaved only"});
+    Built winner = build(recipes[0]);
+    if (recipes.size() > 1 && winner.hs.size() == need) {
+        Built other = build(recipes[1]);
+        float ms[2] = {1e30f, 1e30f};
+        const Built* cand[2] = {&winner, &other};
+        for (int k = 0; k < 2; ++k) {
+            char* va = arena_take(need * kHandleBytes);
+            if (!va || cand[k]->hs.size() != need || !map_at(va, cand[k]->hs)) continue;
+            ms[k] = in ? probe_ms(in, va, bytes, 3) : probe_ms(nullptr, va, bytes, 3);
+            (void)hipMemUnmap(va, need * kHandleBytes);
+        }
+        if (getenv("SMFFT_PAIR_DEBUG")) printf("smfft_malloc_pair: %s %.4f ms, %s %.4f ms as the target of a %s pass over the whole buffer\n", recipes[0].name, ms[0], recipes[1].name, ms[1], in ? "copy" : "write");
+        if (ms[1] < ms[0]) winner = other;
     }
-    for (auto& c : chunks) for (auto h : c.hs) (void)hipMemRelease(h);      // everything that was not used
-    bool ok = chosen.size() == need;
-    size_t mapped = 0;
-    for (; mapped < chosen.size() && ok; ++mapped) ok = hipMemMap(out + mapped * kHandleBytes, kHandleBytes, 0, chosen[mapped], 0) == hipSuccess;
-    ok = ok && hipMemSetAccess(out, need * kHandleBytes, &acc, 1) == hipSuccess;
+    std::vector<hipMemGenericAllocationHandle_t>& chosen = winner.hs;
+    const size_t mixed_used = winner.mixed_used, interleaved_used = winner.interleaved_used;
+    {
+        std::set<hipMemGenericAllocationHandle_t> used(chosen.begin(), chosen.end());
+        for (auto& c : chunks) for (auto h : c.hs) if (!used.count(h)) (void)hipMemRelease(h);      // everything that was not used
+    }
+    bool ok = chosen.size() == need && map_at(out, chosen);
     if (!ok) {
-        (void)hipGetLastError();
-        if (mapped) (void)hipMemUnmap(out, mapped * kHandleBytes);
         for (auto h : chosen) (void)hipMemRelease(h);
         return false;
     }
