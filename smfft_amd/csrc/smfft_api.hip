@@ -12,6 +12,7 @@
 #include <map>
 #include <mutex>
 #include <set>
+#include <string>
 #include <vector>
 
 #include "../../include/smfft.h"
@@ -170,7 +171,7 @@ int pacing_for(const void* d_output, int k_ordinary, int k_mixed) {
     return k_ordinary;
 }
 
-constexpr double kGoodRatio = 2.30;    // candidates policy: mixed targets copy in 2.2-2.3 x the pure read time; other class 2.5; same class 2.6
+constexpr double kGoodRatio = 2.22;    // a good write target: copy of the whole pair within 2.22 x the input's own read time (mixed / interleaved 2.18-2.24; other class 2.5; same class 2.6)
 constexpr float kMixedWriteRatio = 0.91f;   // mixed policy: a chunk is mixed if its write pass takes < 0.91 x the typical one (mixed: 0.79-0.88)
 constexpr float kOrdinaryWriteRatio = 0.96f;   // ... and clearly ordinary above 0.96 x (ordinary chunks scatter by +-3 %)
 #ifndef SMFFT_PAIR_HANDLE_MIB
@@ -329,45 +330,167 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
         if (getenv("SMFFT_PAIR_DEBUG")) printf("smfft_malloc_pair: interleave probe %.3f ms (own passes %.3f, %.3f)\n", ms, x.write_ms, y.write_ms);
         return ms < kMixedWriteRatio * 0.5f * (x.write_ms + y.write_ms);
     };
-    while (true) {
-        // covered (mixed memory plus equal parts of two classes make an output): up to six more chunks are scanned so that
-        // either recipe alone -- all mixed, all interleaved -- is complete (the choice between them is measured, see below,
-        // and spare mixed chunks let the output take the fastest ones); else to the budgets
-        const Tally have = chunks.empty() ? Tally{0, 0, 0} : tally();
-        const bool covered = have.mixed + 2 * std::min(have.same, have.other) >= need;
-        const bool both = have.mixed >= need && 2 * std::min(have.same, have.other) >= need;
-        if (covered && first_covered == 0) first_covered = chunks.size();
-        if (!chunks.empty() && (both || (covered && chunks.size() >= first_covered + 6)
-                                || created + kChunkBytes > budget.bytes || budget.elapsed_ms() > budget.ms)) break;
-        Chunk c;
-        c.kind = kUnknown;
-        for (size_t h = 0; h < per_chunk; ++h) {
-            hipMemGenericAllocationHandle_t handle;
-            if (hipMemCreate(&handle, kHandleBytes, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
-            c.hs.push_back(handle);
+    // Scans until the output is covered (mixed memory plus equal parts of two classes) and `lookahead` chunks further -- so
+    // that either recipe alone, all mixed or all interleaved, may become complete and spare mixed chunks let the output take
+    // the fastest ones -- or to the budgets.  false: nothing more can be scanned.
+    bool budget_hit = false;
+    auto scan = [&](size_t lookahead) {
+        while (true) {
+            const Tally have = chunks.empty() ? Tally{0, 0, 0} : tally();
+            const bool covered = have.mixed + 2 * std::min(have.same, have.other) >= need;
+            if (covered && first_covered == 0) first_covered = chunks.size();
+            if (covered && chunks.size() >= first_covered + lookahead) return true;
+            if (!chunks.empty() && (created + kChunkBytes > budget.bytes || budget.elapsed_ms() > budget.ms)) { budget_hit = true; return false; }
+            Chunk c;
+            c.kind = kUnknown;
+            for (size_t h = 0; h < per_chunk; ++h) {
+                hipMemGenericAllocationHandle_t handle;
+                if (hipMemCreate(&handle, kHandleBytes, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+                c.hs.push_back(handle);
+            }
+            if (c.hs.size() < per_chunk) {      // out of memory (or no VMM): give the partial chunk back and stop scanning
+                for (auto h : c.hs) (void)hipMemRelease(h);
+                api_ok = !chunks.empty();
+                budget_hit = true;
+                return false;
+            }
+            created += kChunkBytes;
+            char* scratch = arena_take(kChunkBytes);      // a slot of its own: virtual addresses are never re-used (see arena_take)
+            bool ok = scratch != nullptr;
+            for (size_t h = 0; h < per_chunk && ok; ++h) ok = hipMemMap(scratch + h * kHandleBytes, kHandleBytes, 0, c.hs[h], 0) == hipSuccess;
+            ok = ok && hipMemSetAccess(scratch, kChunkBytes, &acc, 1) == hipSuccess;
+            if (!ok) {
+                (void)hipGetLastError();
+                if (scratch) (void)hipMemUnmap(scratch, kChunkBytes);
+                for (auto h : c.hs) (void)hipMemRelease(h);
+                api_ok = !chunks.empty();
+                budget_hit = true;
+                return false;
+            }
+            c.write_ms = probe_ms(nullptr, scratch, kChunkBytes, 3);
+            if (chunks.empty() && in) info.first_copy_ms = probe_ms(in, scratch, bytes < kChunkBytes ? bytes : kChunkBytes, 3);   // copy into the first (almost surely ordinary) chunk
+            (void)hipMemUnmap(scratch, kChunkBytes);
+            chunks.push_back(std::move(c));
+            Chunk& last = chunks.back();
+            // only CLEARLY ordinary chunks are classified (and only such a chunk is the reference): one whose own pass lies
+            // between the two kinds is partly mixed, its probes against other chunks come out between the two answers
+            if (interleave && last.write_ms > kOrdinaryWriteRatio * typical()) {
+                if (reference < 0) { reference = (int)chunks.size() - 1; last.kind = kSameClass; }
+                else last.kind = other_class(chunks[reference], last) ? kOtherClass : kSameClass;
+            }
         }
-        if (c.hs.size() < per_chunk) {      // out of memory (or no VMM): give the partial chunk back and stop scanning
-            for (auto h : c.hs) (void)hipMemRelease(h);
-            api_ok = !chunks.empty();
-            break;
+    };
+
+    // One candidate output = a list of handles.  Three pools: mixed memory (fastest chunks first, their handles taken
+    // round-robin across the chunks), ordinary memory of the reference's class, ordinary memory of another class; the last two
+    // contribute equal numbers.  The pools are spread EVENLY over the range (largest-remainder round-robin), so that every part
+    // of the buffer is the same blend -- a caller that uses half of it gets the same rate as one that uses all of it -- and
+    // neighbouring handles alternate between the classes.  What the pools cannot cover comes from the remaining memory, at the end.
+    struct Built { std::vector<hipMemGenericAllocationHandle_t> hs; size_t mixed_used = 0, interleaved_used = 0; };
+    auto build = [&](size_t m_limit) {                        // m_limit: how much of the output mixed memory may provide
+        const float typ = typical();
+        std::vector<size_t> m_chunks, s_chunks, o_chunks;
+        for (size_t i = 0; i < chunks.size(); ++i) {
+            if (is_mixed(chunks[i], typ)) m_chunks.push_back(i);
+            else if (chunks[i].kind == kSameClass) s_chunks.push_back(i);
+            else if (chunks[i].kind == kOtherClass) o_chunks.push_back(i);
         }
-        created += kChunkBytes;
-        char* scratch = arena_take(kChunkBytes);      // a slot of its own: virtual addresses are never re-used (see arena_take)
-        bool ok = scratch != nullptr;
-        for (size_t h = 0; h < per_chunk && ok; ++h) ok = hipMemMap(scratch + h * kHandleBytes, kHandleBytes, 0, c.hs[h], 0) == hipSuccess;
-        ok = ok && hipMemSetAccess(scratch, kChunkBytes, &acc, 1) == hipSuccess;
-        if (!ok) { (void)hipGetLastError(); if (scratch) (void)hipMemUnmap(scratch, kChunkBytes); for (auto h : c.hs) (void)hipMemRelease(h); api_ok = !chunks.empty(); break; }
-        c.write_ms = probe_ms(nullptr, scratch, kChunkBytes, 3);
-        if (chunks.empty() && in) info.first_copy_ms = probe_ms(in, scratch, bytes < kChunkBytes ? bytes : kChunkBytes, 3);   // copy into the first (almost surely ordinary) chunk
-        (void)hipMemUnmap(scratch, kChunkBytes);
-        chunks.push_back(std::move(c));
-        Chunk& last = chunks.back();
-        // only CLEARLY ordinary chunks are classified (and only such a chunk is the reference): one whose own pass lies
-        // between the two kinds is partly mixed, its probes against other chunks come out between the two answers
-        if (interleave && last.write_ms > kOrdinaryWriteRatio * typical()) {
-            if (reference < 0) { reference = (int)chunks.size() - 1; last.kind = kSameClass; }
-            else last.kind = other_class(chunks[reference], last) ? kOtherClass : kSameClass;
+        std::sort(m_chunks.begin(), m_chunks.end(), [&](size_t x, size_t y) { return chunks[x].write_ms < chunks[y].write_ms; });
+        size_t m_total = 0, s_total = 0, o_total = 0;
+        for (size_t i : m_chunks) m_total += chunks[i].hs.size();
+        for (size_t i : s_chunks) s_total += chunks[i].hs.size();
+        for (size_t i : o_chunks) o_total += chunks[i].hs.size();
+        auto take = [&](std::vector<size_t> order, size_t limit) {       // handles of these chunks, round-robin across them
+            std::vector<hipMemGenericAllocationHandle_t> pool;
+            std::vector<size_t> pos(order.size(), 0);
+            for (bool any = true; any && pool.size() < limit;) {
+                any = false;
+                for (size_t k = 0; k < order.size(); ++k) {
+                    const auto& hs = chunks[order[k]].hs;
+                    if (pos[k] < hs.size() && pool.size() < limit) { pool.push_back(hs[pos[k]++]); any = true; }
+                }
+            }
+            return pool;
+        };
+        // as many whole mixed chunks as allowed (the fastest), the rest in equal parts from the two classes
+        const size_t m_take = std::min(std::min(m_total, m_limit), need);
+        const size_t each = std::min((need - m_take + 1) / 2, std::min(s_total, o_total));
+        if (m_take < m_total) m_chunks.resize((m_take + per_chunk - 1) / per_chunk);
+        std::vector<hipMemGenericAllocationHandle_t> pool[3];
+        pool[0] = take(m_chunks, m_take);
+        pool[1] = take(s_chunks, each);
+        pool[2] = take(o_chunks, std::min(each, need - m_take - pool[1].size()));
+        const size_t count[3] = {pool[0].size(), pool[1].size(), pool[2].size()};
+        const size_t blended = count[0] + count[1] + count[2];
+        size_t next[3] = {0, 0, 0};
+        double acc_rr[3] = {0.0, 0.0, 0.0};
+        Built b;
+        for (size_t k = 0; k < blended; ++k) {
+            int best = -1;
+            for (int q = 0; q < 3; ++q) {
+                if (next[q] == count[q]) continue;
+                acc_rr[q] += (double)count[q];
+                if (best < 0 || acc_rr[q] > acc_rr[best]) best = q;
+            }
+            acc_rr[best] -= (double)blended;
+            b.hs.push_back(pool[best][next[best]++]);
         }
+        b.mixed_used = count[0];
+        b.interleaved_used = count[1] + count[2];
+        if (b.hs.size() < need) {                                        // the rest: whatever memory is left, last scanned first
+            std::set<hipMemGenericAllocationHandle_t> used(b.hs.begin(), b.hs.end());
+            for (size_t i = chunks.size(); i-- > 0 && b.hs.size() < need;)
+                for (size_t k = chunks[i].hs.size(); k-- > 0 && b.hs.size() < need;)
+                    if (!used.count(chunks[i].hs[k])) b.hs.push_back(chunks[i].hs[k]);
+        }
+        return b;
+    };
+    auto map_at = [&](char* va, const std::vector<hipMemGenericAllocationHandle_t>& hs) {
+        size_t mapped = 0;
+        bool ok = true;
+        for (; mapped < hs.size() && ok; ++mapped) ok = hipMemMap(va + mapped * kHandleBytes, kHandleBytes, 0, hs[mapped], 0) == hipSuccess;
+        ok = ok && hipMemSetAccess(va, hs.size() * kHandleBytes, &acc, 1) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); if (mapped) (void)hipMemUnmap(va, mapped * kHandleBytes); }
+        return ok;
+    };
+    // The measure of a candidate: the time of a pass over the WHOLE pair in the kernels' access shape -- a copy from the real
+    // input (no input: a write pass) -- with the candidate mapped at a range of its own.  Which blend is best depends on the
+    // class of the input, which cannot be probed (a hipMalloc block has no handles): an output that shares no class with it is
+    // 1.4 % better than one that does, and what a mixed chunk consists of is not known either (profiles/r02_vmm_classes.txt).
+    // So the recipes -- mixed memory first, interleaved classes only -- are TIMED and the best candidate seen is kept; while
+    // it is not good (a copy within kGoodRatio x the input's own read time) and the budgets allow, eight more chunks are
+    // scanned and the recipes tried again with what they add.
+    auto measure = [&](const Built& b) {
+        char* va = arena_take(need * kHandleBytes);
+        if (!va || b.hs.size() != need || !map_at(va, b.hs)) return 1e30f;
+        const float ms = in ? probe_ms(in, va, bytes, 3) : probe_ms(nullptr, va, bytes, 3);
+        (void)hipMemUnmap(va, need * kHandleBytes);
+        return ms;
+    };
+    const float read_whole_ms = in ? probe_ms(in, nullptr, bytes, 3) : 0.f;
+    Built best;
+    float best_ms = 1e30f;
+    bool good = false;
+    const bool compare = getenv("SMFFT_PAIR_NO_COMPARE") == nullptr;
+    const size_t max_rounds = budget.ms > 5000.0 ? 16 : 4;      // a caller that grants a long scan (smfft_malloc_pair_budget) gets more tries
+    for (size_t lookahead = 6, round = 0; round < max_rounds && api_ok; lookahead += 8, ++round) {
+        const bool more = scan(lookahead);
+        size_t total = 0;
+        for (auto& c : chunks) total += c.hs.size();
+        if (!api_ok || total < need) break;
+        const Built cand[2] = {build(need), build(0)};
+        const int ncand = (compare && cand[0].mixed_used > 0 && cand[1].mixed_used + cand[1].interleaved_used == need) ? 2 : 1;
+        float ms[2] = {1e30f, 1e30f};
+        for (int k = 0; k < ncand; ++k) {
+            ms[k] = measure(cand[k]);
+            if (ms[k] < best_ms) { best_ms = ms[k]; best = cand[k]; }
+        }
+        const float typ_total = typical() * (float)((double)(need * kHandleBytes) / (double)kChunkBytes);
+        good = in ? best_ms <= (float)kGoodRatio * read_whole_ms : best_ms < kMixedWriteRatio * typ_total;
+        if (getenv("SMFFT_PAIR_DEBUG"))
+            printf("smfft_malloc_pair: after %zu chunks: mixed first %.4f ms%s as the target of a %s pass over the whole buffer (input read %.4f ms): %s\n", chunks.size(), ms[0],
+                   ncand > 1 ? (std::string(", interleaved only ") + std::to_string(ms[1]) + " ms").c_str() : "", in ? "copy" : "write", read_whole_ms, good ? "good" : "not good");
+        if (good || !more) break;
     }
     if (getenv("SMFFT_PAIR_DEBUG")) {
         printf("smfft_malloc_pair scan: %zu chunks, write ms per GiB (class):", chunks.size());
@@ -378,8 +501,8 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
         for (auto& c : chunks) for (auto h : c.hs) (void)hipMemRelease(h);
         return false;
     }
-    // a scan that ended on its budget may hold less memory than the output needs: the rest is created unprobed
-    {
+    if (best.hs.size() != need) {
+        // a scan that ended on its budget before it held the output's size: the rest is created unprobed
         size_t total = 0;
         for (auto& c : chunks) total += c.hs.size();
         if (total < need) {
@@ -394,127 +517,28 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
             created += c.hs.size() * kHandleBytes;
             chunks.push_back(std::move(c));
         }
+        best = build(need);
+        good = false;
     }
-    // The output's handles.  Three pools: mixed memory (fastest chunks first, their handles taken round-robin across the
-    // chunks), ordinary memory of the reference's class, ordinary memory of another class; the last two contribute equal
-    // numbers.  The pools are spread EVENLY over the range (largest-remainder round-robin), so that every part of the buffer
-    // is the same blend -- a caller that uses half of it gets the same rate as one that uses all of it -- and neighbouring
-    // handles alternate between the classes.  What the pools cannot cover comes from the remaining ordinary memory, at the end.
-    // Which blend is best depends on the class of the INPUT, which cannot be probed (a hipMalloc block has no handles): an
-    // output that shares no class with it is 1.4 % better than one that does, and what a mixed chunk consists of is not known
-    // either (profiles/r02_vmm_classes.txt).  So when the scan holds enough for both, the two recipes -- mixed memory first,
-    // interleaved classes only -- are each mapped at a range of their own and TIMED as the target of a copy from the real
-    // input; the faster one is kept.
-    const float typ = typical();
-    std::vector<size_t> m_chunks, s_chunks, o_chunks;
-    for (size_t i = 0; i < chunks.size(); ++i) {
-        if (is_mixed(chunks[i], typ)) m_chunks.push_back(i);
-        else if (chunks[i].kind == kSameClass) s_chunks.push_back(i);
-        else if (chunks[i].kind == kOtherClass) o_chunks.push_back(i);
-    }
-    std::sort(m_chunks.begin(), m_chunks.end(), [&](size_t x, size_t y) { return chunks[x].write_ms < chunks[y].write_ms; });
-    size_t m_total = 0, s_total = 0, o_total = 0;
-    for (size_t i : m_chunks) m_total += chunks[i].hs.size();
-    for (size_t i : s_chunks) s_total += chunks[i].hs.size();
-    for (size_t i : o_chunks) o_total += chunks[i].hs.size();
-    struct Recipe { size_t m_take; const char* name; };
-    struct Built { std::vector<hipMemGenericAllocationHandle_t> hs; size_t mixed_used = 0, interleaved_used = 0; };
-    auto build = [&](const Recipe& rc) {
-        Built out_b;
-        auto take = [&](std::vector<size_t> order, size_t limit) {       // handles of these chunks, round-robin across them
-            std::vector<hipMemGenericAllocationHandle_t> pool;
-            std::vector<size_t> pos(order.size(), 0);
-            for (bool any = true; any && pool.size() < limit;) {
-                any = false;
-                for (size_t k = 0; k < order.size(); ++k) {
-                    const auto& hs = chunks[order[k]].hs;
-                    if (pos[k] < hs.size() && pool.size() < limit) { pool.push_back(hs[pos[k]++]); any = true; }
-                }
-            }
-            return pool;
-        };
-        // as many whole mixed chunks as the recipe takes (the fastest), the rest in equal parts from the two classes
-        const size_t each = std::min((need - rc.m_take + 1) / 2, std::min(s_total, o_total));
-        std::vector<size_t> mc = m_chunks;
-        if (rc.m_take < m_total) mc.resize((rc.m_take + per_chunk - 1) / per_chunk);
-        std::vector<hipMemGenericAllocationHandle_t> pool[3];
-        pool[0] = take(mc, rc.m_take);
-        pool[1] = take(s_chunks, each);
-        pool[2] = take(o_chunks, std::min(each, need - rc.m_take - pool[1].size()));
-        const size_t count[3] = {pool[0].size(), pool[1].size(), pool[2].size()};
-        const size_t blended = count[0] + count[1] + count[2];
-        size_t next[3] = {0, 0, 0};
-        double acc[3] = {0.0, 0.0, 0.0};
-        for (size_t k = 0; k < blended; ++k) {
-            int best = -1;
-            for (int q = 0; q < 3; ++q) {
-                if (next[q] == count[q]) continue;
-                acc[q] += (double)count[q];
-                if (best < 0 || acc[q] > acc[best]) best = q;
-            }
-            acc[best] -= (double)blended;
-            out_b.hs.push_back(pool[best][next[best]++]);
-        }
-        out_b.mixed_used = count[0];
-        out_b.interleaved_used = count[1] + count[2];
-        if (out_b.hs.size() < need) {                                    // the rest: ordinary memory, last scanned first
-            std::set<hipMemGenericAllocationHandle_t> used(out_b.hs.begin(), out_b.hs.end());
-            for (size_t i = chunks.size(); i-- > 0 && out_b.hs.size() < need;)
-                for (size_t k = chunks[i].hs.size(); k-- > 0 && out_b.hs.size() < need;)
-                    if (!used.count(chunks[i].hs[k])) out_b.hs.push_back(chunks[i].hs[k]);
-        }
-        return out_b;
-    };
-    auto map_at = [&](char* va, const std::vector<hipMemGenericAllocationHandle_t>& hs) {
-        size_t mapped = 0;
-        bool ok = true;
-        for (; mapped < hs.size() && ok; ++mapped) ok = hipMemMap(va + mapped * kHandleBytes, kHandleBytes, 0, hs[mapped], 0) == hipSuccess;
-        ok = ok && hipMemSetAccess(va, hs.size() * kHandleBytes, &acc, 1) == hipSuccess;
-        if (!ok) { (void)hipGetLastError(); if (mapped) (void)hipMemUnmap(va, mapped * kHandleBytes); }
-        return ok;
-    };
-    std::vector<Recipe> recipes = {{std::min(m_total, need), "mixed first"}};
-    if (m_total > 0 && 2 * std::min(s_total, o_total) >= need && getenv("SMFFT_PAIR_NO_COMPARE") == nullptr) recipes.push_back({0, "interleaved only"});
-    Built winner = build(recipes[0]);
-    if (recipes.size() > 1 && winner.hs.size() == need) {
-        Built other = build(recipes[1]);
-        float ms[2] = {1e30f, 1e30f};
-        const Built* cand[2] = {&winner, &other};
-        for (int k = 0; k < 2; ++k) {
-            char* va = arena_take(need * kHandleBytes);
-            if (!va || cand[k]->hs.size() != need || !map_at(va, cand[k]->hs)) continue;
-            ms[k] = in ? probe_ms(in, va, bytes, 3) : probe_ms(nullptr, va, bytes, 3);
-            (void)hipMemUnmap(va, need * kHandleBytes);
-        }
-        if (getenv("SMFFT_PAIR_DEBUG")) printf("smfft_malloc_pair: %s %.4f ms, %s %.4f ms as the target of a %s pass over the whole buffer\n", recipes[0].name, ms[0], recipes[1].name, ms[1], in ? "copy" : "write");
-        if (ms[1] < ms[0]) winner = other;
-    }
-    std::vector<hipMemGenericAllocationHandle_t>& chosen = winner.hs;
-    const size_t mixed_used = winner.mixed_used, interleaved_used = winner.interleaved_used;
     {
-        std::set<hipMemGenericAllocationHandle_t> used(chosen.begin(), chosen.end());
+        std::set<hipMemGenericAllocationHandle_t> used(best.hs.begin(), best.hs.end());
         for (auto& c : chunks) for (auto h : c.hs) if (!used.count(h)) (void)hipMemRelease(h);      // everything that was not used
     }
-    bool ok = chosen.size() == need && map_at(out, chosen);
-    if (!ok) {
-        for (auto h : chosen) (void)hipMemRelease(h);
+    if (best.hs.size() != need || !map_at(out, best.hs)) {
+        for (auto h : best.hs) (void)hipMemRelease(h);
         return false;
     }
-    // the claim is checked on the result: one write pass over the whole output must be as fast as mixed memory's
-    const float verify_ms = probe_ms(nullptr, out, need * kHandleBytes, 2);
-    const bool fast = verify_ms < kMixedWriteRatio * typ * (float)((double)(need * kHandleBytes) / (double)kChunkBytes);
-    if (getenv("SMFFT_PAIR_DEBUG")) printf("smfft_malloc_pair: output write pass %.3f ms (typical %.3f ms per GiB): %s\n", verify_ms, typ, fast ? "fast" : "NOT fast");
-    rec.handles = chosen;
+    rec.handles = best.hs;
     rec.b = out;
     rec.va_bytes = need * kHandleBytes;
     rec.searched = true;
-    rec.mixed = fast;
+    rec.mixed = good;
     info.candidates = (int)chunks.size();
     info.candidate_bytes = created;
-    info.chosen = (int)((mixed_used * kHandleBytes + kChunkBytes - 1) / kChunkBytes);
-    info.good_enough = (fast && mixed_used + interleaved_used == need) ? 1 : 0;
-    info.mixed_bytes = mixed_used * kHandleBytes;
-    info.interleaved_bytes = interleaved_used * kHandleBytes;
+    info.chosen = (int)((best.mixed_used * kHandleBytes + kChunkBytes - 1) / kChunkBytes);
+    info.good_enough = good ? 1 : 0;
+    info.mixed_bytes = best.mixed_used * kHandleBytes;
+    info.interleaved_bytes = best.interleaved_used * kHandleBytes;
     return true;
 }
 
