@@ -129,12 +129,14 @@ void* smfft_malloc(unsigned long long bytes);
  * 1.30-1.31 ms (0.82) -- and in 1.32 ms with an output whose 8 MiB pieces alternate between ordinary memory of two classes.
  * This call takes the input from hipMalloc and BUILDS the output with the virtual-memory API: physical memory is created
  * in 8 MiB handles, 1 GiB at a time, and each GiB is classified by two write-only passes (mixed or not; same or other
- * class than the first ordinary GiB); the scan ends as soon as mixed memory plus equal parts of two classes cover the
- * output (typically 4-17 GiB, 30-250 ms for a 4 GiB output -- what two plain hipMalloc calls of that size cost) or at its
- * budgets -- a quarter of the free memory (SMFFT_PAIR_BUDGET_FRAC), 2 s (SMFFT_PAIR_BUDGET_MS) -- and whatever is missing
- * then comes from ordinary chunks.  The chosen handles are blended evenly into one virtual range (an ordinary device
- * pointer for the caller), the rest is released at once.  Buffers are exactly `bytes` long (the output's range is
- * rounded up to 8 MiB).
+ * class than the first ordinary GiB).  When mixed memory plus equal parts of two classes cover the output (and six GiB
+ * further), the candidate outputs -- mixed memory first, interleaved classes only -- are each timed as the target of a
+ * copy from the real input over the whole pair and the best is kept; while it is not good (copy within 2.22 x the input's
+ * read time) eight more GiB are scanned and the candidates tried again, up to four times and inside the budgets -- a quarter
+ * of the free memory (SMFFT_PAIR_BUDGET_FRAC), 2 s (SMFFT_PAIR_BUDGET_MS); whatever is missing then comes from ordinary
+ * chunks.  Typically 10-25 GiB and 80-550 ms for a 4 GiB output (two plain hipMalloc calls of that size: 270 ms).  The
+ * chosen handles are blended evenly into one virtual range (an ordinary device pointer for the caller), the rest is
+ * released at once.  Buffers are exactly `bytes` long (the output's range is rounded up to 8 MiB).
  * SMFFT_PAIR_POLICY=candidates: whole hipMallocAsync / hipMalloc blocks timed as copy targets inside the same budgets
  * (also the fallback where the virtual-memory API is unavailable); =plain: two plain allocations.  Nothing is kept after
  * smfft_free_pair unless SMFFT_PAIR_CACHE=1.  Requests below 256 MiB are served plainly.

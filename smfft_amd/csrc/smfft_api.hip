@@ -128,18 +128,21 @@ int timed(F&& launch, double* FFT_time) {
 //    ordinary GiB are of different classes if the pass over their interleaved halves is.
 // smfft_malloc_pair ("mixed" policy, the default) therefore takes the input from hipMalloc and BUILDS the output with
 // the virtual-memory API: physical memory is created in 8 MiB handles, 1 GiB at a time; each GiB is mapped at a slot of its
-// own and classified by those two passes (0.2 ms each); the scan ends as soon as mixed memory plus equal amounts of two
-// classes cover the output -- typically after 4-17 GiB and 30-250 ms for a 4 GiB output, where hunting for mixed memory
-// alone needed up to the whole byte budget and found none on some boxes -- or at the byte budget (default: a quarter of
-// the free memory) or the time budget (default 2 s), whatever is missing then coming from the last ordinary chunks
-// scanned.  The chosen handles are blended evenly into one virtual range -- the caller sees an ordinary device pointer --
-// a final write pass over it checks the result, and everything else is released.
+// own and classified by those two passes (0.2 ms each).  Once mixed memory plus equal amounts of two classes cover the
+// output (and six chunks further), candidate outputs are assembled -- mixed memory first / interleaved classes only -- and
+// each is TIMED as the target of a copy from the real input over the whole pair; the best is kept, and while it is not
+// good eight more chunks are scanned and the candidates tried again (build_mixed_output below).  Typically 10-25 GiB and
+// 80-550 ms for a 4 GiB output, where hunting for mixed memory alone needed up to the whole byte budget and found none on
+// some boxes; bounded by the byte budget (default: a quarter of the free memory) and the time budget (default 2 s),
+// whatever is missing then coming from the last ordinary chunks scanned.  The chosen handles are blended evenly into one
+// virtual range -- the caller sees an ordinary device pointer -- and everything else is released.
 //   SMFFT_PAIR_POLICY=mixed|candidates|plain   candidates: round-1 style, whole hipMalloc / hipMallocAsync blocks timed as
 //                                              copy targets inside the same budgets; plain: two plain allocations
 //   SMFFT_PAIR_BUDGET_FRAC=0.25                byte budget of the scan as a fraction of the free memory
 //   SMFFT_PAIR_BUDGET_MS=2000                  time budget
 //   SMFFT_PAIR_CACHE=1                         keep the last released pair for the next request of the same size
-//   SMFFT_PAIR_NO_MIXED=1 / SMFFT_PAIR_NO_INTERLEAVE=1   A/B and test switches: only interleaving / only mixed chunks count
+//   SMFFT_PAIR_NO_MIXED=1 / SMFFT_PAIR_NO_INTERLEAVE=1 / SMFFT_PAIR_NO_COMPARE=1   A/B and test switches: only interleaving /
+//                                              only mixed chunks count / the first recipe is taken unmeasured
 struct PairRec {
     void* a = nullptr;
     void* b = nullptr;
