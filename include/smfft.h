@@ -151,6 +151,9 @@ int smfft_free_pair(void* d_read);
  * another library): changing the allocation of the output is then the one-line way to the rates above.  Release with
  * smfft_free_written. */
 int smfft_malloc_written(unsigned long long bytes, void** d_written);
+/* the same with the caller's input buffer (at least `bytes` long; only read): the candidate outputs are then judged by
+ * timed copies from it, as in smfft_malloc_pair, instead of by write passes alone */
+int smfft_malloc_written_for(const void* d_read, unsigned long long bytes, void** d_written);
 int smfft_free_written(void* d_written);
 /* gives back the pair SMFFT_PAIR_CACHE=1 keeps */
 int smfft_pair_cache_release(void);

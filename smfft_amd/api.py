@@ -56,6 +56,7 @@ _SIGS = {
     "smfft_malloc_pair_budget": (_i, [_ull, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_double, ctypes.c_double]),
     "smfft_free_pair": (_i, [_vp]),
     "smfft_malloc_written": (_i, [_ull, ctypes.POINTER(_vp)]),
+    "smfft_malloc_written_for": (_i, [_vp, _ull, ctypes.POINTER(_vp)]),
     "smfft_free_written": (_i, [_vp]),
     "smfft_pair_cache_release": (_i, []),
     "smfft_last_pair_info": (_i, [_vp]),

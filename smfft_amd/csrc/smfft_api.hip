@@ -272,7 +272,8 @@ struct Budget {
 // class gains nothing, nor does interleaving in stripes of 128 MiB.  So every scanned chunk is classified twice: mixed or not
 // by its own write pass, and -- if not -- same or other class than the first ordinary chunk by the write pass over a test
 // range in which their handles alternate.  The scan ends as soon as mixed + 2 * min(same, other) covers the output.
-bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& budget, PairRec& rec, SmfftPairInfo& info) {
+// in_is_fresh: `in` is the pair's own new (still empty) input buffer and may be written by a probe; a caller's buffer is only read
+bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int device, const Budget& budget, PairRec& rec, SmfftPairInfo& info) {
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
@@ -297,7 +298,7 @@ bool build_mixed_output(size_t bytes, const void* in, int device, const Budget& 
     // less than the write pass over the input buffer itself (an ordinary hipMalloc block), so that a run of mixed chunks
     // at the start of the scan is recognised as such
     // (no input buffer -- smfft_malloc_written: the median alone)
-    const float in_write_ms = !in ? 0.f : probe_ms(nullptr, const_cast<void*>(in), bytes < kChunkBytes ? bytes : kChunkBytes, 3) * (float)((double)kChunkBytes / (double)(bytes < kChunkBytes ? bytes : kChunkBytes));
+    const float in_write_ms = !(in && in_is_fresh) ? 0.f : probe_ms(nullptr, const_cast<void*>(in), bytes < kChunkBytes ? bytes : kChunkBytes, 3) * (float)((double)kChunkBytes / (double)(bytes < kChunkBytes ? bytes : kChunkBytes));
     auto typical = [&] {
         std::vector<float> t;
         for (auto& c : chunks) if (c.write_ms < 1e29f) t.push_back(c.write_ms);
@@ -587,7 +588,10 @@ bool pick_candidate_output(size_t bytes, const void* in, const Budget& budget, f
 
 // with_input = false (smfft_malloc_written): only the written buffer, for a caller whose input exists already; the record is
 // kept under the written buffer's address
-int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search, double budget_frac = -1.0, double budget_ms = -1.0, bool with_input = true) {
+// caller_input (with_input = false only): the caller's own input buffer of at least `bytes`, read (never written) by the
+// timed copies that judge the candidate outputs
+int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search, double budget_frac = -1.0, double budget_ms = -1.0, bool with_input = true,
+               const void* caller_input = nullptr) {
     if (d_a) *d_a = nullptr;
     *d_b = nullptr;
     int device = -1;
@@ -619,10 +623,11 @@ int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search, double b
         budget.bytes = (size_t)((budget_frac >= 0.0 ? budget_frac : env_double("SMFFT_PAIR_BUDGET_FRAC", 0.25)) * (double)free_mem);
         budget.ms = budget_ms >= 0.0 ? budget_ms : env_double("SMFFT_PAIR_BUDGET_MS", 2000.0);
         const size_t window = bytes < kChunkBytes ? bytes : kChunkBytes;
-        if (in) info.read_ms = probe_ms(in, nullptr, window, 3);
-        bool done = !candidates_only && build_mixed_output(bytes, in, device, budget, rec, info);
+        const void* probe_in = in ? in : caller_input;
+        if (probe_in) info.read_ms = probe_ms(probe_in, nullptr, window, 3);
+        bool done = !candidates_only && build_mixed_output(bytes, probe_in, in != nullptr, device, budget, rec, info);
         if (!done && in) done = pick_candidate_output(bytes, in, budget, info.read_ms, rec, info);
-        if (done && in) info.copy_ms = probe_ms(in, rec.b, window, 3);
+        if (done && probe_in) info.copy_ms = probe_ms(probe_in, rec.b, window, 3);
         info.search_ms = budget.elapsed_ms();
     }
     if (!rec.b) {
@@ -923,6 +928,10 @@ const char* smfft_version(void) { return "smfft_amd 0.1 (gfx950)"; }
 
 int smfft_malloc_pair(unsigned long long bytes, void** d_read, void** d_written) { read_env(); return alloc_pair((size_t)bytes, d_read, d_written, true); }
 int smfft_malloc_written(unsigned long long bytes, void** d_written) { read_env(); return alloc_pair((size_t)bytes, nullptr, d_written, true, -1.0, -1.0, false); }
+int smfft_malloc_written_for(const void* d_read, unsigned long long bytes, void** d_written) {
+    read_env();
+    return alloc_pair((size_t)bytes, nullptr, d_written, true, -1.0, -1.0, false, d_read);
+}
 int smfft_free_written(void* d_written) { return free_pair(d_written); }
 int smfft_malloc_pair_budget(unsigned long long bytes, void** d_read, void** d_written, double budget_frac, double budget_ms) {
     read_env();

@@ -656,6 +656,18 @@ def test_malloc_written_with_a_callers_own_input(sm):
     assert sm.lib.smfft_free_pair(src.ptr) != 0                                 # not a pair
     assert sm.lib.smfft_free_written(out.value) == 0
     assert sm.lib.smfft_free_written(out.value) != 0
+    # the same with the caller's input as the source of the timed copies: the input is only read
+    big = sm.DeviceBuffer(nbytes)
+    sm.lib.smfft_memcpy_h2d(big.ptr, x.ctypes.data, x.nbytes)
+    assert sm.lib.smfft_malloc_written_for(big.ptr, nbytes, ctypes.byref(out)) == 0 and out.value
+    info = sm.last_pair_info()
+    print("smfft_malloc_written_for:", info)
+    assert info["read_ms"] > 0.0 and info["copy_ms"] > 0.0
+    rc, _ = sm.FFT_external_benchmark(big.ptr, out.value, 1024, 64)
+    sm.lib.smfft_memcpy_d2h(got.ctypes.data, out.value, x.nbytes)
+    ref.assert_close_fp32(got, ref.ct_c2c(x, False, True), "written buffer, input unchanged by the probes")
+    assert sm.lib.smfft_free_written(out.value) == 0
+    big.free()
     src.free()
     assert _settled_usage(sm, free0, 256 << 20) <= (256 << 20)
 
