@@ -21,6 +21,7 @@ Prints ONE JSON line on rank 0 (see the driver contract).  Objects beyond the co
                   with events on the launch stream over the timed region.
   roofline_plain  the same kernel, same pre-warm, same number of timed launches, on two PLAIN hipMalloc buffers
                   (what a caller of FFT_external_benchmark brings along, CT:850-853).
+  roofline_own_input  the same on a plain hipMalloc INPUT with only the output taken from smfft_malloc_written_for
   configs         config 3 (N = 32..4096 no-reorder, FFT_multiple_benchmark: ms, FFT/s, TFLOP/s) and config 4
                   (real N = 2048 R2C and C2R: ms, TB/s, fraction of peak), N = 1 only.
   cpu_baseline    FFTW-API batched C2C (MKL's FFTW3 interface; real FFTW is not in the image) on the host cores of
@@ -388,6 +389,17 @@ def main():
     pair_copy_ms = copy_ms(pa.value, pb.value)
     plain_copy_ms = copy_ms(p_in.ptr, p_out.ptr) if p_in else float("nan")
 
+    # a caller's own plain input with only the OUTPUT taken from the library (smfft_malloc_written_for): the one-line change
+    # for code that allocates its own buffers (N = 1 only; outside the contract's timed region, same pre-warm and step count)
+    own = None
+    if p_in and world == 1:
+        w = ctypes.c_void_p()
+        if sm.lib.smfft_malloc_written_for(p_in.ptr, nbytes, ctypes.byref(w)) == 0 and w.value:
+            w_info = sm.last_pair_info()
+            _, w_kernel_ms = run_timed(p_in.ptr, w.value, False)
+            own = {"kernel_ms": w_kernel_ms, "copy_ms": copy_ms(p_in.ptr, w.value), "search": w_info}
+            sm.lib.smfft_free_written(w.value)
+
     # the vendor library on the same buffers (N = 1 only; informational)
     vendor = None
     if world == 1 and not args.no_configs:
@@ -495,6 +507,7 @@ def main():
             "hbm_GBps_per_gpu": alg_bytes / (ms_per_step * 1e-3) / 1e9,
             "roofline": roof(kernel_ms_max, pair_copy_ms),
             "roofline_plain": roof(plain_kernel_ms_max, plain_copy_ms) if p_in else None,
+            "roofline_own_input": dict(roof(own["kernel_ms"], own["copy_ms"]), buffers="plain hipMalloc input + smfft_malloc_written_for output", search=own["search"]) if own else None,
             "value_plain": total_ffts / (plain_wall_max / args.steps) if p_in else None,
             "pair_alloc_s": alloc_s,
             "pair_search": pair_info,
