@@ -9,8 +9,9 @@
 // lane j owns slabs j, j+L, j+2L, ...  Lanes need no synchronisation with each other, their DMA
 // transfers in the two directions overlap on the two PCIe directions, and the lanes' host-side
 // memcpys into / out of the bounce buffers run in parallel, which is what makes pageable memory as
-// fast as pinned.  Pinned memory (smfft_host_malloc, or anything hipHostRegister'ed) skips the bounce
-// buffers: the DMA engines read and write the caller's buffers directly.
+// fast as pinned used to be.  Pinned memory (smfft_host_malloc, or anything hipHostRegister'ed) needs none of this: the
+// transform's kernel reads and writes the caller's buffers directly over PCIe (zero copy; the slab pipeline without bounce
+// buffers stays available with SMFFT_HOST_ZERO_COPY=0).
 //
 // The batch may be larger than device memory: the device only ever holds 2 slab pairs per lane.
 #include <hip/hip_runtime.h>
@@ -181,6 +182,28 @@ int smfft_host_transform(int family, const void* h_input, void* h_output, int FF
     job.slab_ffts = std::min<long long>(job.slab_ffts, std::min<long long>(nFFTs, (1LL << 31) / FFT_size));   // int count per launch
     job.nslabs = (nFFTs + job.slab_ffts - 1) / job.slab_ffts;
     job.bounce = !(is_pinned(h_input) && is_pinned(h_output));
+    // Both buffers pinned: no copies at all.  The external kernel reads the host buffer and writes the host buffer
+    // directly over PCIe -- loads and stores of thousands of waves in flight use the link in both directions at once:
+    // 97-98 GB/s in + out for the config-2 batch (49 GB/s each way; H2D or D2H alone 56-57) against 68-75 GB/s for the slab
+    // pipeline below, whose DMA copies do not overlap that well (tools/host_stream_probe.py, profiles/r02_host_stream.txt).
+    // SMFFT_HOST_ZERO_COPY=0 keeps the slab pipeline.  (For pageable memory the same kernel over the lanes' pinned bounce
+    // buffers measured no better than the DMA pipeline -- 62-75 against 69 GB/s: the host-side memcpys bound it.)
+    e = getenv("SMFFT_HOST_ZERO_COPY");
+    if (!job.bounce && !(e && atoi(e) == 0)) {
+        void *d_in = nullptr, *d_out = nullptr;
+        if (hipHostGetDevicePointer(&d_in, const_cast<void*>(h_input), 0) == hipSuccess && hipHostGetDevicePointer(&d_out, h_output, 0) == hipSuccess) {
+            const long long per_launch = std::max<long long>(1, ((1LL << 31) / FFT_size - 1) / 4096 * 4096);   // int count per launch, whole tiles
+            int rc = 0;
+            for (long long first = 0; first < nFFTs && rc == 0; first += per_launch) {
+                const long long count = std::min(per_launch, nFFTs - first);
+                rc = smfft_launch(family, 0, (const char*)d_in + (size_t)first * job.fft_bytes, (char*)d_out + (size_t)first * job.fft_bytes, FFT_size, (int)count, inverse, reorder, nullptr);
+            }
+            if (rc == 0) rc = (int)hipStreamSynchronize(nullptr);
+            if (elapsed_ms) *elapsed_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            return rc == 0 ? 0 : -5;
+        }
+        (void)hipGetLastError();
+    }
     // measured on the config-2 batch (tools/host_stream_probe.py): pageable memory needs the 8 lanes' parallel
     // memcpys (1 lane 328 ms, 2: 175, 4: 121, 8: 118); pinned memory is best with 2 (120 ms; 8: 130, 16: 289)
     e = getenv("SMFFT_HOST_LANES");

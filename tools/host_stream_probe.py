@@ -18,6 +18,10 @@ yp = sm.pinned_empty((nffts, n), np.complex64)
 x = np.array(xp)                 # pageable copies
 y = np.empty_like(x)
 print(f"batch: {nffts} FFTs of {n} = {gib:.1f} GiB in + {gib:.1f} GiB out, host resident")
+for rep in range(3):
+    _, ms = sm.host_transform(xp, out=yp)
+print(f"  pinned, zero copy (the kernel reads and writes the host buffers): {ms:8.1f} ms  = {2 * gib * 2**30 / ms / 1e6:6.1f} GB/s (in+out)  {nffts / ms * 1e3:.3e} FFT/s", flush=True)
+os.environ["SMFFT_HOST_ZERO_COPY"] = "0"          # the slab pipeline (DMA copies to and from device slabs) from here on
 for name, a, b in (("pinned", xp, yp), ("pageable", x, y)):
     for lanes, slab_mib in ((0, 32), (8, 32), (2, 32)):
         best = 1e9
