@@ -742,11 +742,14 @@ def test_stockham_forward_extension_golden(sm, golden, n):
 
 
 # ------------------------------------ host-resident batches streamed in slabs
-@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("pinned", [False, True, "slabs"])
 @pytest.mark.parametrize("n,inv,reo", [(1024, 0, 1), (64, 1, 1), (4096, 0, 0)])
-def test_host_transform_matches_device_path_and_oracle(sm, oracle_lib, n, inv, reo, pinned):
+def test_host_transform_matches_device_path_and_oracle(sm, oracle_lib, n, inv, reo, pinned, monkeypatch):
     """Ragged slabs (the batch is not a multiple of the slab, more slabs than lanes * slots so every ring slot is
-    reused): bit-identical to the one-launch device path, and within tolerance of the fp64 oracle."""
+    reused): bit-identical to the one-launch device path, and within tolerance of the fp64 oracle.  Pinned buffers:
+    zero copy (the kernel on the host buffers) by default, the slab pipeline with SMFFT_HOST_ZERO_COPY=0 ("slabs")."""
+    if pinned == "slabs":
+        monkeypatch.setenv("SMFFT_HOST_ZERO_COPY", "0")
     rng = np.random.default_rng(77 + n)
     nffts = 7 * (4096 // n) * 3 + 5
     x = (rng.random((nffts, n), dtype=np.float32) + 1j * rng.random((nffts, n), dtype=np.float32)).astype(np.complex64)
