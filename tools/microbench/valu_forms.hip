@@ -42,6 +42,16 @@ __global__ void __launch_bounds__(64) forms(float* out, int reps, float k) {
                     a[c + 8] = __uint_as_float(x[1]);
                 }
             }
+            if (FORM == 13) {        // the DPP lane-bit-2 swap of two registers (row_shr:4 / row_shl:4 with bank masks): 2 v_mov_b32_dpp
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int x = __float_as_int(a[c]), y = __float_as_int(a[c + 8]);
+                    const int nx = __builtin_amdgcn_update_dpp(x, y, 0x114, 0xF, 0xA, false);
+                    const int ny = __builtin_amdgcn_update_dpp(y, x, 0x104, 0xF, 0x5, false);
+                    a[c] = __int_as_float(nx);
+                    a[c + 8] = __int_as_float(ny);
+                }
+            }
             if (FORM == 12) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
@@ -67,8 +77,8 @@ int main() {
     hipEventCreate(&e1);
     const int reps = 20000;
     const double insts = (double)reps * 128.0;
-    const char* names[13] = {"fma1 a=a*s+1", "add2 a=a+b", "mul2 a=a*b", "fma2 a=a*s+b", "fma3 a=a*b+c", "fmamk a=a*K+b", "mul  a=a*K", "fmaak a=a*b+K", "fmac a+=b*c", "mul  a=a*s", "mul a=a*0.5", "permlane32_swap (x2)", "permlane16_swap (x2)"};
-    for (int form = 0; form < 13; ++form)
+    const char* names[14] = {"fma1 a=a*s+1", "add2 a=a+b", "mul2 a=a*b", "fma2 a=a*s+b", "fma3 a=a*b+c", "fmamk a=a*K+b", "mul  a=a*K", "fmaak a=a*b+K", "fmac a+=b*c", "mul  a=a*s", "mul a=a*0.5", "permlane32_swap of a register pair", "permlane16_swap of a register pair", "dpp bit-2 swap of a register pair"};
+    for (int form = 0; form < 14; ++form)
         for (int w : {1, 4}) {
             std::vector<float> t;
             for (int i = 0; i < 5; ++i) {
@@ -86,6 +96,7 @@ int main() {
                 if (form == 10) forms<10><<<1024 * w, 64>>>(out, reps, 0.9999f);
                 if (form == 11) forms<11><<<1024 * w, 64>>>(out, reps, 0.9999f);
                 if (form == 12) forms<12><<<1024 * w, 64>>>(out, reps, 0.9999f);
+                if (form == 13) forms<13><<<1024 * w, 64>>>(out, reps, 0.9999f);
                 hipEventRecord(e1, 0);
                 hipEventSynchronize(e1);
                 float ms;
@@ -93,7 +104,7 @@ int main() {
                 t.push_back(ms);
             }
             std::sort(t.begin(), t.end());
-            printf("%-22s %d wave(s) per SIMD: %.3f ms -> %.2f SIMD cycles per instruction at 2.3 GHz\n", names[form], w, t[2], t[2] * 1e-3 * 2.3e9 / ((form >= 11 ? insts / 8.0 : insts) * w));
+            printf("%-22s %d wave(s) per SIMD: %.3f ms -> %.2f SIMD cycles per instruction at 2.3 GHz\n", names[form], w, t[2], t[2] * 1e-3 * 2.3e9 / ((form >= 11 ? insts / 2.0 : insts) * w));
         }
     return 0;
 }
