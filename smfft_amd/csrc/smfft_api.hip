@@ -217,29 +217,37 @@ void free_buffer(void* p, bool pool) {
     else (void)hipFree(p);
 }
 
-// Virtual ranges for the VMM-backed outputs come from an arena that is never recycled.  Measured on ROCm 7.2 / MI355X
-// (tools/microbench/placement_study.hip vmm7, profiles/r02_vmm_remap_check.txt): after hipMemUnmap, a hipMemMap of ANOTHER
-// handle at the same virtual address leaves the GPU translating to the OLD physical memory (the second fill of the test
-// lands in the first handle).  So a virtual address is used for one mapping only, ever: every scanned chunk gets its own
-// slot, every output its own range, and freed ranges are not handed out again.
-std::mutex g_arena_mutex;
-char* g_arena = nullptr;
-size_t g_arena_size = 0, g_arena_used = 0;
+// Virtual ranges for the VMM-backed buffers: every range is a reservation of its own at an address that has NEVER been used
+// before in this process, and it is given back (hipMemAddressFree) as soon as its mapping is gone.  Two things measured on
+// ROCm 7.2 / MI355X force that shape (tools/microbench/placement_study.hip vmm7, profiles/r02_vmm_remap_check.txt,
+// r02_vmm_release_check.txt):
+//  * after hipMemUnmap -- and even after hipMemAddressFree and a new hipMemAddressReserve of the same address -- a hipMemMap
+//    of ANOTHER handle at that virtual address leaves the GPU translating to the OLD physical memory (the second fill of the
+//    test lands in the first handle): a virtual address is usable for one mapping only, ever;
+//  * the physical memory of handles that are unmapped and released is returned to the system only when the virtual range
+//    they were mapped at is freed: ranges kept for later (an arena) pin every byte ever mapped into them.
+// Addresses are handed out upwards from a base far below the runtime's own region (hints are honoured); a reservation that
+// comes back below the high-water mark is refused.  Every 4 GiB pair consumes 50-100 GiB of address space for good, so a
+// process can build one to two thousand of them; after that the allocator falls back to plain allocations.
+std::mutex g_va_mutex;
+uintptr_t g_va_next = 0x100000000000ull;            // 16 TiB: next address to ask for
+constexpr uintptr_t kVaLimit = 0x700000000000ull;   // 112 TiB: stay below the region the runtime itself allocates from
 char* arena_take(size_t bytes) {
     const size_t align = 1ull << 30;
     bytes = (bytes + align - 1) / align * align;
-    std::lock_guard<std::mutex> lock(g_arena_mutex);
-    if (!g_arena || g_arena_used + bytes > g_arena_size) {
-        const size_t want = std::max<size_t>(1ull << 40, 2 * bytes);     // 1 TiB of address space per arena (the GPU VM has 256 TiB)
-        char* p = nullptr;
-        if (hipMemAddressReserve((void**)&p, want, align, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        g_arena = p;
-        g_arena_size = want;
-        g_arena_used = 0;
+    std::lock_guard<std::mutex> lock(g_va_mutex);
+    for (int attempt = 0; attempt < 4 && g_va_next + bytes < kVaLimit; ++attempt) {
+        void* p = nullptr;
+        if (hipMemAddressReserve(&p, bytes, align, (void*)g_va_next, 0) != hipSuccess) { (void)hipGetLastError(); g_va_next += 64 * align; continue; }
+        if ((uintptr_t)p >= g_va_next && (uintptr_t)p + bytes < kVaLimit) { g_va_next = (uintptr_t)p + bytes; return (char*)p; }
+        (void)hipMemAddressFree(p, bytes);         // not where it was asked for, possibly an address used before: refuse it
+        g_va_next += 64 * align;
     }
-    char* r = g_arena + g_arena_used;
-    g_arena_used += bytes;
-    return r;
+    return nullptr;
+}
+void arena_give_back(char* p, size_t bytes) {
+    const size_t align = 1ull << 30;
+    if (p) (void)hipMemAddressFree(p, (bytes + align - 1) / align * align);
 }
 
 void release_output(PairRec& rec) {
@@ -247,7 +255,8 @@ void release_output(PairRec& rec) {
     if (rec.va_bytes) {
         (void)hipMemUnmap(rec.b, rec.va_bytes);
         for (auto h : rec.handles) (void)hipMemRelease(h);
-        rec.handles.clear();               // the virtual range is retired with the mapping (see arena_take)
+        rec.handles.clear();
+        arena_give_back((char*)rec.b, rec.va_bytes);   // the address is retired with the mapping (see arena_take)
         rec.va_bytes = 0;
     } else {
         free_buffer(rec.b, rec.pool_b);
@@ -284,8 +293,6 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
     const size_t need = (bytes + kHandleBytes - 1) / kHandleBytes, per_chunk = kChunkBytes / kHandleBytes;
-    char* out = arena_take(need * kHandleBytes);
-    if (!out) return false;
     enum Kind { kUnknown, kSameClass, kOtherClass };
     struct Chunk { std::vector<hipMemGenericAllocationHandle_t> hs; float write_ms; Kind kind; };
     std::vector<Chunk> chunks;
@@ -330,6 +337,7 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
         ok = ok && hipMemSetAccess(slot, kChunkBytes, &acc, 1) == hipSuccess;
         const float ms = ok ? probe_ms(nullptr, slot, kChunkBytes, 3) : 1e30f;
         (void)hipMemUnmap(slot, kChunkBytes);
+        arena_give_back(slot, kChunkBytes);
         if (!ok) (void)hipGetLastError();
         if (getenv("SMFFT_PAIR_DEBUG")) printf("smfft_malloc_pair: interleave probe %.3f ms (own passes %.3f, %.3f)\n", ms, x.write_ms, y.write_ms);
         return ms < kMixedWriteRatio * 0.5f * (x.write_ms + y.write_ms);
@@ -365,7 +373,7 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
             ok = ok && hipMemSetAccess(scratch, kChunkBytes, &acc, 1) == hipSuccess;
             if (!ok) {
                 (void)hipGetLastError();
-                if (scratch) (void)hipMemUnmap(scratch, kChunkBytes);
+                if (scratch) { (void)hipMemUnmap(scratch, kChunkBytes); arena_give_back(scratch, kChunkBytes); }
                 for (auto h : c.hs) (void)hipMemRelease(h);
                 api_ok = !chunks.empty();
                 budget_hit = true;
@@ -374,6 +382,7 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
             c.write_ms = probe_ms(nullptr, scratch, kChunkBytes, 3);
             if (chunks.empty() && in) info.first_copy_ms = probe_ms(in, scratch, bytes < kChunkBytes ? bytes : kChunkBytes, 3);   // copy into the first (almost surely ordinary) chunk
             (void)hipMemUnmap(scratch, kChunkBytes);
+            arena_give_back(scratch, kChunkBytes);
             chunks.push_back(std::move(c));
             Chunk& last = chunks.back();
             // only CLEARLY ordinary chunks are classified (and only such a chunk is the reference): one whose own pass lies
@@ -466,9 +475,10 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
     // scanned and the recipes tried again with what they add.
     auto measure = [&](const Built& b) {
         char* va = arena_take(need * kHandleBytes);
-        if (!va || b.hs.size() != need || !map_at(va, b.hs)) return 1e30f;
+        if (!va || b.hs.size() != need || !map_at(va, b.hs)) { arena_give_back(va, need * kHandleBytes); return 1e30f; }
         const float ms = in ? probe_ms(in, va, bytes, 3) : probe_ms(nullptr, va, bytes, 3);
         (void)hipMemUnmap(va, need * kHandleBytes);
+        arena_give_back(va, need * kHandleBytes);
         return ms;
     };
     const float read_whole_ms = in ? probe_ms(in, nullptr, bytes, 3) : 0.f;
@@ -528,8 +538,10 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
         std::set<hipMemGenericAllocationHandle_t> used(best.hs.begin(), best.hs.end());
         for (auto& c : chunks) for (auto h : c.hs) if (!used.count(h)) (void)hipMemRelease(h);      // everything that was not used
     }
-    if (best.hs.size() != need || !map_at(out, best.hs)) {
+    char* out = best.hs.size() == need ? arena_take(need * kHandleBytes) : nullptr;
+    if (!out || !map_at(out, best.hs)) {
         for (auto h : best.hs) (void)hipMemRelease(h);
+        arena_give_back(out, need * kHandleBytes);
         return false;
     }
     rec.handles = best.hs;

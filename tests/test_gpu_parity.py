@@ -672,6 +672,21 @@ def test_malloc_written_with_a_callers_own_input(sm):
     assert _settled_usage(sm, free0, 256 << 20) <= (256 << 20)
 
 
+def test_allocator_returns_memory_on_the_system_runtime():
+    """The allocator in a process WITHOUT torch -- the library then runs on the system's HIP runtime, as the C harness does,
+    where the physical memory of released handles comes back only when their virtual range is freed (ROCm 7.2): six pairs
+    in a row must not accumulate anything (this leaked the whole scan, 10-60 GiB per pair, before the ranges were freed)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "allocator_soak.py"), "1", "6"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stdout + p.stderr
+    missing = [float(line.split("right after free")[1].split("MiB")[0]) for line in p.stdout.splitlines() if "right after free" in line]
+    held = [float(line.split("held while allocated")[1].split("MiB")[0]) for line in p.stdout.splitlines() if "held while allocated" in line]
+    assert len(missing) == 6 and max(missing) < 512 and max(held) < 2 * 1024 + 512, p.stdout
+
+
 def test_malloc_pair_plain_policy_and_many_pairs(sm, monkeypatch):
     """SMFFT_PAIR_POLICY=plain: two plain allocations, no probing; the pair table grows as needed (more than the 64
     slots round 1 had) and every pair is released by its read pointer."""

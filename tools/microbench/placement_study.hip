@@ -575,6 +575,75 @@ static int vmm7_mode() {
     return 0;
 }
 
+// vmm8: when does the physical memory of VMM handles come back?  1 GiB in 8 MiB handles is created, mapped, written, unmapped
+// (one call over all mappings / one call per mapping) and released; the virtual range is kept or freed: hipMemGetInfo after
+// each step.  And: does hipMemAddressFree + a new reservation of the SAME address cure the stale translation of vmm7?
+static size_t free_mib() { size_t f = 0, t = 0; (void)hipMemGetInfo(&f, &t); return f >> 20; }
+static int vmm8_mode() {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    const size_t H = 8ull << 20, N = 128;
+    const size_t f0 = free_mib();
+    for (int variant = 0; variant < 4; ++variant) {
+        std::vector<hipMemGenericAllocationHandle_t> hs(N);
+        for (auto& h : hs) CK(hipMemCreate(&h, H, &prop, 0));
+        char* va = nullptr;
+        CK(hipMemAddressReserve((void**)&va, N * H, 0, nullptr, 0));
+        for (size_t k = 0; k < N; ++k) CK(hipMemMap(va + k * H, H, 0, hs[k], 0));
+        CK(hipMemSetAccess(va, N * H, &acc, 1));
+        CK(hipMemset(va, 1, N * H));
+        CK(hipDeviceSynchronize());
+        const size_t fm = free_mib();
+        if (variant == 0 || variant == 2) CK(hipMemUnmap(va, N * H));
+        else for (size_t k = 0; k < N; ++k) CK(hipMemUnmap(va + k * H, H));
+        for (auto& h : hs) CK(hipMemRelease(h));
+        const size_t fr = free_mib();
+        if (variant >= 2) CK(hipMemAddressFree(va, N * H));
+        CK(hipDeviceSynchronize());
+        printf("variant %d (%s unmap, virtual range %s): in use while mapped %zu MiB; after unmap + release %zu MiB; at the end %zu MiB\n", variant,
+               (variant & 1) ? "per-mapping" : "single-call", variant >= 2 ? "freed" : "kept", f0 - fm, f0 - fr, f0 - free_mib());
+    }
+    // the stale translation of vmm7 across hipMemAddressFree + hipMemAddressReserve of the same address
+    const size_t n = H / 4;
+    hipMemGenericAllocationHandle_t X, Y;
+    CK(hipMemCreate(&X, H, &prop, 0));
+    CK(hipMemCreate(&Y, H, &prop, 0));
+    char *S = nullptr, *S2 = nullptr, *FX = nullptr, *FY = nullptr;
+    CK(hipMemAddressReserve((void**)&S, H, 0, nullptr, 0));
+    CK(hipMemMap(S, H, 0, X, 0));
+    CK(hipMemSetAccess(S, H, &acc, 1));
+    fill_kernel<<<1024, 256>>>((float*)S, 1.0f, n);
+    CK(hipDeviceSynchronize());
+    CK(hipMemUnmap(S, H));
+    CK(hipMemAddressFree(S, H));
+    CK(hipMemAddressReserve((void**)&S2, H, 0, S, 0));
+    printf("a new reservation with the freed address as its hint comes back at %s address\n", S2 == S ? "the SAME" : "another");
+    CK(hipMemMap(S2, H, 0, Y, 0));
+    CK(hipMemSetAccess(S2, H, &acc, 1));
+    fill_kernel<<<1024, 256>>>((float*)S2, 2.0f, n);
+    CK(hipDeviceSynchronize());
+    CK(hipMemUnmap(S2, H));
+    CK(hipMemAddressFree(S2, H));
+    CK(hipMemAddressReserve((void**)&FX, H, 0, (void*)((size_t)S + (64ull << 30)), 0));
+    CK(hipMemAddressReserve((void**)&FY, H, 0, (void*)((size_t)S + (128ull << 30)), 0));
+    printf("reservations with hints 64 and 128 GiB above it: %s\n", ((size_t)FX == (size_t)S + (64ull << 30) && (size_t)FY == (size_t)S + (128ull << 30)) ? "exactly where asked" : "elsewhere");
+    CK(hipMemMap(FX, H, 0, X, 0));
+    CK(hipMemSetAccess(FX, H, &acc, 1));
+    CK(hipMemMap(FY, H, 0, Y, 0));
+    CK(hipMemSetAccess(FY, H, &acc, 1));
+    float hx = 0.f, hy = 0.f;
+    CK(hipMemcpy(&hx, FX + H / 2, 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&hy, FY + H / 2, 4, hipMemcpyDeviceToHost));
+    printf("X holds %.1f (expected 1.0), Y holds %.1f (expected 2.0) -> %s\n", hx, hy,
+           (hx == 1.0f && hy == 2.0f) ? "freeing and re-reserving the address cures it" : "STALE TRANSLATION survives hipMemAddressFree + hipMemAddressReserve of the same address");
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "map";
     const size_t chunk_gib = argc > 2 ? atol(argv[2]) : 4;
@@ -586,6 +655,7 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&g_e0));
     CK(hipEventCreate(&g_e1));
     if (mode == "vmm7") return vmm7_mode();
+    if (mode == "vmm8") return vmm8_mode();
     if (mode == "vmm_cls") return vmm_cls_mode(argc > 2 ? atol(argv[2]) : 8, argc > 3 ? atol(argv[3]) : 140);
     if (mode == "vmm_spacer") return vmm_spacer_mode(argc > 2 ? atol(argv[2]) : 8);
     if (mode == "vmm_il") return vmm_il_mode(argc > 2 ? atol(argv[2]) : 8, argc > 3 ? atol(argv[3]) : 120);
