@@ -213,7 +213,14 @@ double env_double(const char* name, double dflt) {
 
 void free_buffer(void* p, bool pool) {
     if (!p) return;
-    if (pool) { (void)hipFreeAsync(p, 0); (void)hipStreamSynchronize(0); }
+    if (pool) {
+        (void)hipFreeAsync(p, 0);
+        (void)hipStreamSynchronize(0);
+        int device = 0;
+        hipMemPool_t mempool = nullptr;      // the stream-ordered pool keeps freed blocks for itself: hand them back to the system
+        if (hipGetDevice(&device) == hipSuccess && hipDeviceGetDefaultMemPool(&mempool, device) == hipSuccess) (void)hipMemPoolTrimTo(mempool, 0);
+        (void)hipGetLastError();
+    }
     else (void)hipFree(p);
 }
 
