@@ -138,7 +138,7 @@ void* smfft_malloc(unsigned long long bytes);
  * chunks.  Typically 10-25 GiB and 80-550 ms for a 4 GiB output (two plain hipMalloc calls of that size: 270 ms).  The
  * chosen handles are blended evenly into one virtual range (an ordinary device pointer for the caller), the rest is
  * released at once.  Buffers are exactly `bytes` long (the output's range is rounded up to 8 MiB).
- * SMFFT_PAIR_POLICY=candidates: whole hipMallocAsync / hipMalloc blocks timed as copy targets inside the same budgets
+ * SMFFT_PAIR_POLICY=candidates: whole hipMalloc blocks timed as copy targets inside the same budgets
  * (also the fallback where the virtual-memory API is unavailable); =plain: two plain allocations.  Nothing is kept after
  * smfft_free_pair unless SMFFT_PAIR_CACHE=1.  Requests below 256 MiB are served plainly.
  * The L3 wrappers take their two buffers from this call; SMFFT_WRAPPER_PLACEMENT=0: two plain allocations as upstream (CT:850-853).

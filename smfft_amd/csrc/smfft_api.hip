@@ -136,7 +136,7 @@ int timed(F&& launch, double* FFT_time) {
 // some boxes; bounded by the byte budget (default: a quarter of the free memory) and the time budget (default 2 s),
 // whatever is missing then coming from the last ordinary chunks scanned.  The chosen handles are blended evenly into one
 // virtual range -- the caller sees an ordinary device pointer -- and everything else is released.
-//   SMFFT_PAIR_POLICY=mixed|candidates|plain   candidates: round-1 style, whole hipMalloc / hipMallocAsync blocks timed as
+//   SMFFT_PAIR_POLICY=mixed|candidates|plain   candidates: round-1 style, whole hipMalloc blocks timed as
 //                                              copy targets inside the same budgets; plain: two plain allocations
 //   SMFFT_PAIR_BUDGET_FRAC=0.25                byte budget of the scan as a fraction of the free memory
 //   SMFFT_PAIR_BUDGET_MS=2000                  time budget
@@ -147,7 +147,6 @@ struct PairRec {
     void* a = nullptr;
     void* b = nullptr;
     int device = -1;
-    bool pool_b = false;      // b came from hipMallocAsync
     size_t bytes = 0;
     bool searched = false;
     std::vector<hipMemGenericAllocationHandle_t> handles;   // b is a virtual range backed by these (mixed policy)
@@ -211,19 +210,6 @@ double env_double(const char* name, double dflt) {
     return e ? atof(e) : dflt;
 }
 
-void free_buffer(void* p, bool pool) {
-    if (!p) return;
-    if (pool) {
-        (void)hipFreeAsync(p, 0);
-        (void)hipStreamSynchronize(0);
-        int device = 0;
-        hipMemPool_t mempool = nullptr;      // the stream-ordered pool keeps freed blocks for itself: hand them back to the system
-        if (hipGetDevice(&device) == hipSuccess && hipDeviceGetDefaultMemPool(&mempool, device) == hipSuccess) (void)hipMemPoolTrimTo(mempool, 0);
-        (void)hipGetLastError();
-    }
-    else (void)hipFree(p);
-}
-
 // Virtual ranges for the VMM-backed buffers: every range is a reservation of its own at an address that has NEVER been used
 // before in this process, and it is given back (hipMemAddressFree) as soon as its mapping is gone.  Two things measured on
 // ROCm 7.2 / MI355X force that shape (tools/microbench/placement_study.hip vmm7, profiles/r02_vmm_remap_check.txt,
@@ -266,7 +252,7 @@ void release_output(PairRec& rec) {
         arena_give_back((char*)rec.b, rec.va_bytes);   // the address is retired with the mapping (see arena_take)
         rec.va_bytes = 0;
     } else {
-        free_buffer(rec.b, rec.pool_b);
+        (void)hipFree(rec.b);
     }
     rec.b = nullptr;
 }
@@ -565,41 +551,33 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
     return true;
 }
 
-// "candidates" policy: one block from the stream-ordered pool, then ordinary blocks one after the other, each timed as
-// a copy target; ends at the first candidate within kGoodRatio x the input's pure read time, or at the budgets.
+// "candidates" policy (the fallback where the virtual-memory API is not usable): whole hipMalloc blocks one after the other,
+// each timed as a copy target; ends at the first candidate within kGoodRatio x the input's pure read time, or at the budgets.
 bool pick_candidate_output(size_t bytes, const void* in, const Budget& budget, float read_ms, PairRec& rec, SmfftPairInfo& info) {
     const size_t window = bytes < kChunkBytes ? bytes : kChunkBytes;
-    struct Cand { void* p; bool pool; float ms; };
+    struct Cand { void* p; float ms; };
     std::vector<Cand> cands;
     size_t used = 0;
     int best = -1;
     bool good = false;
     while (!good) {
-        const bool pool = cands.empty();
         if (!cands.empty() && (used + bytes > budget.bytes || budget.elapsed_ms() > budget.ms)) break;
         void* p = nullptr;
-        hipError_t rc = pool ? hipMallocAsync(&p, bytes, 0) : hipMalloc(&p, bytes);
-        if (rc == hipSuccess && pool) rc = hipStreamSynchronize(0);
-        if (rc != hipSuccess) {
-            (void)hipGetLastError();
-            if (pool) { cands.push_back({nullptr, true, 1e30f}); continue; }   // no pool on this runtime: go on with plain candidates
-            break;
-        }
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
         used += bytes;
         const float ms = probe_ms(in, p, window, 3);
-        cands.push_back({p, pool, ms > 0.f ? ms : 1e30f});
+        cands.push_back({p, ms > 0.f ? ms : 1e30f});
         if (best < 0 || cands.back().ms < cands[best].ms) best = (int)cands.size() - 1;
         good = read_ms > 0.f && cands[best].ms <= kGoodRatio * read_ms;
     }
     info.candidates = (int)cands.size();
     info.candidate_bytes = used;
-    if (best < 0 || !cands[best].p) return false;
+    if (best < 0) return false;
     for (int i = 0; i < (int)cands.size(); ++i)
-        if (i != best) free_buffer(cands[i].p, cands[i].pool);
+        if (i != best) (void)hipFree(cands[i].p);
     rec.b = cands[best].p;
-    rec.pool_b = cands[best].pool;
     rec.searched = true;
-    info.first_copy_ms = cands.size() > 1 && cands[1].p ? cands[1].ms : cands[0].ms;
+    info.first_copy_ms = cands[0].ms;
     info.chosen = best;
     info.good_enough = good ? 1 : 0;
     return true;

@@ -551,16 +551,16 @@ def test_malloc_pair_bounded_search(sm, monkeypatch):
     use(a, b)
     assert info["bytes"] == nbytes and info["candidates"] >= 1 and 0 <= info["chosen"] <= info["candidates"]
     assert info["candidate_bytes"] <= 0.25 * free0 + (1 << 30)              # the byte budget (a quarter of the free memory) + one chunk
-    assert info["search_ms"] <= 2000 + 1500 and took < 6.0, (info, took)   # the time budget (+ the last chunk's creation)
+    assert info["search_ms"] <= 2000 + 2500 and took < 8.0, (info, took)   # the time budget (+ the last chunks and the timed candidates)
     assert info["copy_ms"] <= info["first_copy_ms"] * 1.03                  # never worse than the first chunk seen
     assert _settled_usage(sm, free0, 2 * nbytes + (256 << 20)) <= 2 * nbytes + (256 << 20)   # only the pair (+ page tables) is still allocated
     print("smfft_malloc_pair:", info)
     assert sm.lib.smfft_free_pair(a.value) == 0
     assert _settled_usage(sm, free0, 256 << 20) <= (256 << 20)               # nothing cached by default
     assert sm.lib.smfft_free_pair(a.value) != 0                              # unknown pointer: an error, nothing freed twice
-    # a zero budget: exactly one chunk is scanned; the round-1 style candidates policy: the pool block + one block at most
+    # a zero budget: exactly one chunk is scanned; the round-1 style candidates policy: one block
     monkeypatch.setenv("SMFFT_PAIR_BUDGET_FRAC", "0.0")
-    for policy, limit in (("mixed", 1), ("candidates", 2)):
+    for policy, limit in (("mixed", 1), ("candidates", 1)):
         monkeypatch.setenv("SMFFT_PAIR_POLICY", policy)
         assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
         assert 1 <= sm.last_pair_info()["candidates"] <= limit
