@@ -135,7 +135,7 @@ void* smfft_malloc(unsigned long long bytes);
  * copy from the real input over the whole pair and the best is kept; while it is not good (copy within 2.22 x the input's
  * read time) eight more GiB are scanned and the candidates tried again, up to four times and inside the budgets -- a quarter
  * of the free memory (SMFFT_PAIR_BUDGET_FRAC), 2 s (SMFFT_PAIR_BUDGET_MS); whatever is missing then comes from ordinary
- * chunks.  Typically 10-25 GiB and 80-550 ms for a 4 GiB output (two plain hipMalloc calls of that size: 270 ms).  The
+ * chunks.  Typically 10-25 GiB and 80-550 ms for a 4 GiB output (on the system runtime up to 1-2 s).  The
  * chosen handles are blended evenly into one virtual range (an ordinary device pointer for the caller), the rest is
  * released at once.  Buffers are exactly `bytes` long (the output's range is rounded up to 8 MiB).
  * SMFFT_PAIR_POLICY=candidates: whole hipMalloc blocks timed as copy targets inside the same budgets

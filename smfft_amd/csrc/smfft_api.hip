@@ -675,7 +675,7 @@ int release_pair_cache() {
 }
 
 // The L3 wrappers own their two device buffers (CT:850-853 allocates them, uses them once, frees them) and take them from
-// the pair allocator: it costs about what two plain allocations of that size cost (80-550 ms against 270 ms for 2 x 4 GiB) and the
+// the pair allocator: 80-550 ms per call (two plain allocations: under a millisecond, plus 150 ms of first touch once) and the
 // external kernel then runs at 0.80-0.83 of the HBM peak instead of 0.69-0.76.  SMFFT_WRAPPER_PLACEMENT=0: two plain
 // allocations, exactly as upstream (the hipFFT comparator of the harness follows the same switch, so that both libraries
 // are always timed on the same kind of buffers).
