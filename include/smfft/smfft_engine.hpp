@@ -166,26 +166,70 @@ __device__ __forceinline__ void fft_sync() {
 #ifndef SMFFT_SINGLE_READS
 #define SMFFT_SINGLE_READS 1
 #endif
-template <int STRIDE, bool SINGLE>
-__device__ __forceinline__ void lds_read16(float2 (&r)[16], const float2* base) {
-  if constexpr ((SINGLE && SMFFT_SINGLE_READS != 0) || SMFFT_SINGLE_READS == 2) {
-    static_assert(8 * STRIDE * 15 < 65536, "DS offset field is 16 bits");
+// Sixteen single ds_read_b64 off ONE address register with compile-time float2 offsets OFF(k), issued in the order the
+// caller names (k = 0 .. 15 -> v[k]).  SMFFT_LDS_WAITS selects who waits for them:
+//   2 (default)  `volatile` 64-bit LDS loads: hipcc neither merges them into ds_read2_b64 nor reorders them, and -- unlike
+//                inline assembly -- COUNTS them, so it places a stepped s_waitcnt lgkmcnt(n) in front of the first use of
+//                each value: the first butterflies start while the later reads are still in flight;
+//   0            one inline-assembly block that ends in a blanket s_waitcnt lgkmcnt(0) (rounds 1-2; kept for the A/B).
+#ifndef SMFFT_LDS_WAITS
+#define SMFFT_LDS_WAITS 2
+#endif
+template <class OFF>
+__device__ __forceinline__ void ds_read16_single(float2 (&v)[16], const float2* base) {
     typedef __attribute__((address_space(3))) const float2 lds_float2;
+#if SMFFT_LDS_WAITS == 2
+    typedef __attribute__((address_space(3))) const volatile unsigned long long lds_u64;
+    lds_u64* p = (lds_u64*)(lds_float2*)base;
+    unsigned long long w[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[k] = p[OFF::at(k)];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = make_float2(__uint_as_float((unsigned)w[k]), __uint_as_float((unsigned)(w[k] >> 32)));
+#else
     const unsigned a = (unsigned)(unsigned long)(lds_float2*)base;
-    unsigned long long v[16];   // 64-bit integers, not <2 x float>: vector-typed results invite v_pk_add_f32 (half rate) downstream
+    unsigned long long w[16];   // 64-bit integers, not <2 x float>: vector-typed results invite v_pk_add_f32 (half rate) downstream
     asm volatile(
         "ds_read_b64 %0, %16 offset:%17\n\tds_read_b64 %1, %16 offset:%18\n\tds_read_b64 %2, %16 offset:%19\n\tds_read_b64 %3, %16 offset:%20\n\t"
         "ds_read_b64 %4, %16 offset:%21\n\tds_read_b64 %5, %16 offset:%22\n\tds_read_b64 %6, %16 offset:%23\n\tds_read_b64 %7, %16 offset:%24\n\t"
         "ds_read_b64 %8, %16 offset:%25\n\tds_read_b64 %9, %16 offset:%26\n\tds_read_b64 %10, %16 offset:%27\n\tds_read_b64 %11, %16 offset:%28\n\t"
         "ds_read_b64 %12, %16 offset:%29\n\tds_read_b64 %13, %16 offset:%30\n\tds_read_b64 %14, %16 offset:%31\n\tds_read_b64 %15, %16 offset:%32\n\t"
         "s_waitcnt lgkmcnt(0)"
-        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
-          "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])
-        : "v"(a), "n"(0), "n"(8 * STRIDE), "n"(16 * STRIDE), "n"(24 * STRIDE), "n"(32 * STRIDE), "n"(40 * STRIDE), "n"(48 * STRIDE), "n"(56 * STRIDE),
-          "n"(64 * STRIDE), "n"(72 * STRIDE), "n"(80 * STRIDE), "n"(88 * STRIDE), "n"(96 * STRIDE), "n"(104 * STRIDE), "n"(112 * STRIDE), "n"(120 * STRIDE)
+        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]),
+          "=&v"(w[8]), "=&v"(w[9]), "=&v"(w[10]), "=&v"(w[11]), "=&v"(w[12]), "=&v"(w[13]), "=&v"(w[14]), "=&v"(w[15])
+        : "v"(a), "n"(8 * OFF::at(0)), "n"(8 * OFF::at(1)), "n"(8 * OFF::at(2)), "n"(8 * OFF::at(3)), "n"(8 * OFF::at(4)), "n"(8 * OFF::at(5)),
+          "n"(8 * OFF::at(6)), "n"(8 * OFF::at(7)), "n"(8 * OFF::at(8)), "n"(8 * OFF::at(9)), "n"(8 * OFF::at(10)), "n"(8 * OFF::at(11)),
+          "n"(8 * OFF::at(12)), "n"(8 * OFF::at(13)), "n"(8 * OFF::at(14)), "n"(8 * OFF::at(15))
         : "memory");
 #pragma unroll
-    for (int i = 0; i < 16; ++i) r[i] = make_float2(__uint_as_float((unsigned)v[i]), __uint_as_float((unsigned)(v[i] >> 32)));
+    for (int k = 0; k < 16; ++k) v[k] = make_float2(__uint_as_float((unsigned)w[k]), __uint_as_float((unsigned)(w[k] >> 32)));
+#endif
+}
+
+// issue order of sixteen reads that feed B butterflies of radix R = 16 / B (decimation in time: the innermost radix-2
+// pairs are (j, j + R/2), then (j + R/4, ...)): bit-reversed within each butterfly, so that every group of reads
+// completes the inputs of whole sub-butterflies
+template <int R>
+constexpr int dit_issue_slot(int k) {
+    const int b = k / R, j = k % R;
+    int rev = 0;
+    for (int m = 1, w = R >> 1; w >= 1; m <<= 1, w >>= 1) rev |= (j & m) ? w : 0;
+    return b * R + rev;
+}
+
+template <int STRIDE>
+struct StridedOffsets {
+    static constexpr int at(int k) { return STRIDE * dit_issue_slot<16>(k); }
+};
+
+template <int STRIDE, bool SINGLE>
+__device__ __forceinline__ void lds_read16(float2 (&r)[16], const float2* base) {
+  if constexpr ((SINGLE && SMFFT_SINGLE_READS != 0) || SMFFT_SINGLE_READS == 2) {
+    static_assert(8 * STRIDE * 15 < 65536, "DS offset field is 16 bits");
+    float2 v[16];
+    ds_read16_single<StridedOffsets<STRIDE>>(v, base);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r[dit_issue_slot<16>(k)] = v[k];
   } else {
 #pragma unroll
     for (int i = 0; i < 16; ++i) r[i] = base[STRIDE * i];
@@ -447,27 +491,14 @@ struct Engine {
         constexpr int PS = G::kPadShift;
         const int g16 = 16 * (int)(__brev((unsigned)t1) >> (32 - T_BITS));
         const float2* row = sf + g16 + (g16 >> PS);
-        {
-            typedef __attribute__((address_space(3))) const float2 lds_float2;
-            const unsigned a = (unsigned)(unsigned long)(lds_float2*)row;
-            unsigned long long v[16];   // see lds_read16
-            asm volatile(
-                "ds_read_b64 %0, %16 offset:%17\n\tds_read_b64 %1, %16 offset:%18\n\tds_read_b64 %2, %16 offset:%19\n\tds_read_b64 %3, %16 offset:%20\n\t"
-                "ds_read_b64 %4, %16 offset:%21\n\tds_read_b64 %5, %16 offset:%22\n\tds_read_b64 %6, %16 offset:%23\n\tds_read_b64 %7, %16 offset:%24\n\t"
-                "ds_read_b64 %8, %16 offset:%25\n\tds_read_b64 %9, %16 offset:%26\n\tds_read_b64 %10, %16 offset:%27\n\tds_read_b64 %11, %16 offset:%28\n\t"
-                "ds_read_b64 %12, %16 offset:%29\n\tds_read_b64 %13, %16 offset:%30\n\tds_read_b64 %14, %16 offset:%31\n\tds_read_b64 %15, %16 offset:%32\n\t"
-                "s_waitcnt lgkmcnt(0)"
-                : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
-                  "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])
-                : "v"(a), "n"(8 * slot_source(0)), "n"(8 * slot_source(1)), "n"(8 * slot_source(2)), "n"(8 * slot_source(3)), "n"(8 * slot_source(4)),
-                  "n"(8 * slot_source(5)), "n"(8 * slot_source(6)), "n"(8 * slot_source(7)), "n"(8 * slot_source(8)), "n"(8 * slot_source(9)),
-                  "n"(8 * slot_source(10)), "n"(8 * slot_source(11)), "n"(8 * slot_source(12)), "n"(8 * slot_source(13)), "n"(8 * slot_source(14)),
-                  "n"(8 * slot_source(15))
-                : "memory");
+        float2 v[16];
+        ds_read16_single<BitrevOffsets>(v, row);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) r[i] = make_float2(__uint_as_float((unsigned)v[i]), __uint_as_float((unsigned)(v[i] >> 32)));
-        }
+        for (int k = 0; k < 16; ++k) r[dit_issue_slot<R1>(k)] = v[k];
     }
+    struct BitrevOffsets {
+        static constexpr int at(int k) { return slot_source(dit_issue_slot<R1>(k)); }
+    };
     // pass-1 slot i = b*R1 + r1 takes element rev_B1(b)*R1 + rev_R1(r1) of the thread's row
     static constexpr int slot_source(int i) {
         const int b = i / R1, r1 = i % R1;

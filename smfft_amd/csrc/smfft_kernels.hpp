@@ -16,6 +16,7 @@
 // keeps twiddles in registers.
 #pragma once
 #include "smfft/smfft_device_functions.hpp"
+#include "smfft/smfft_planar.hpp"
 
 // external kernels stage through LDS with wave-coalesced global access up to this length
 #ifndef SMFFT_STAGED_MAX_N
@@ -219,6 +220,9 @@ __device__ __forceinline__ void lds_to_tile(float2* __restrict__ g, const float2
 // (round 1: 64 LDS instructions per N = 1024 FFT against 32 for reorder; now 32 + 32 either way; for N <= 64, whose
 // device-function form does the bit reversal as a DPP register transposition, the read from the padded image replaces
 // that transposition too).
+#ifndef SMFFT_MULT_FORWARD
+#define SMFFT_MULT_FORWARD 1
+#endif
 template <int N, int DIR, int REORDER>
 __device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, float2* s) {
     using G = Geometry<N>;
@@ -232,24 +236,83 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_i
         fft_sync<G::kMultiWave>();
         tile_to_lds<N, kPaddedImage>(d_input + first * N, s, first, nSlots);
         fft_sync<G::kMultiWave>();
-        for (int f = 0; f < nreuses; ++f) {
-            float2 r[16];
-            if constexpr (kPaddedImage) {
+        if constexpr (kPaddedImage) {
+            for (int f = 0; f < nreuses; ++f) {
+                float2 r[16];
                 eng.bitrev_read(r, sf);
                 fft_sync<G::kMultiWave>();          // all inputs are in registers before the region is reused
                 eng.template transform_from_pass1_slots<true>(r, sf);
                 fft_sync<G::kMultiWave>();          // all exchange reads done before the results overwrite them
                 eng.bitrev_write(r, sf);
-            } else {
+                fft_sync<G::kMultiWave>();          // the reference omits this (latent race, CT:563-565)
+            }
+        } else if constexpr (SMFFT_MULT_FORWARD) {
+            // Natural-order image: what a thread stores at the end of an application (r[q] -> sf[u + T*q]) is exactly what
+            // it would load at the start of the next one (r[c] <- sf[u + T*c]).  Every result is still stored (the data
+            // are in LDS, natural order, after every application, as the device function's contract has it); the re-load
+            // of the thread's own stores is forwarded from its registers: 16 of the 64 LDS operations per application.
+            float2 r[16];
+            eng.template load_lds<true>(r, sf);
+            for (int f = 0; f < nreuses; ++f) {
+                fft_sync<G::kMultiWave>();
+                eng.template transform<true>(r, sf);
+                fft_sync<G::kMultiWave>();
+                eng.store_lds(r, sf);
+                fft_sync<G::kMultiWave>();          // the reference omits this (latent race, CT:563-565)
+            }
+        } else {
+            for (int f = 0; f < nreuses; ++f) {
+                float2 r[16];
                 eng.template load_lds<true>(r, sf);
                 fft_sync<G::kMultiWave>();
                 eng.template transform<true>(r, sf);
                 fft_sync<G::kMultiWave>();
                 eng.store_lds(r, sf);
+                fft_sync<G::kMultiWave>();
             }
-            fft_sync<G::kMultiWave>();   // the reference omits this (latent race, CT:563-565)
         }
         lds_to_tile<N, kPaddedImage>(d_output + first * N, s, first, nSlots);
+    }
+}
+
+// The same kernel on the planar engine (smfft_planar.hpp): every LDS image as two planes of dwords, stored with
+// ds_write_addtid_b32 and read back in contiguous runs.  The image between applications is the natural-order image in
+// planar form (row c, dword of thread u = x[u + T*c]); the no-reorder variants read their bit-reversed rows from it,
+// the reorder variants store every result and forward their own registers into the next application.
+#ifndef SMFFT_PLANAR
+#define SMFFT_PLANAR 1          // 0: the float2-image engine for every length (A/B)
+#endif
+#define SMFFT_PLANAR_SIZES(N) (SMFFT_PLANAR && (N) == 1024)
+template <int N, int DIR, int REORDER>
+__device__ __forceinline__ void c2c_multiple_body_planar(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, float* planes) {
+    using G = Geometry<N>;
+    PlanarEngine<N, DIR, REORDER> eng;
+    eng.init(threadIdx.x, planes);
+    const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long first = (long)tile * G::kCompactFfts;
+        fft_sync<G::kMultiWave>();
+        tile_to_planes<N, DIR, REORDER>(d_input + first * N, planes, first, nSlots);
+        fft_sync<G::kMultiWave>();
+        float2 r[16];
+        if constexpr (REORDER) {
+            eng.image_load_own(r, planes);
+            for (int f = 0; f < nreuses; ++f) {
+                eng.transform_from_pass1_slots(r, planes);
+                fft_sync<G::kMultiWave>();          // the last pass's reads are done before the result overwrites them
+                eng.image_store(r);
+            }
+        } else {
+            for (int f = 0; f < nreuses; ++f) {
+                eng.image_load_bitrev(r, planes);
+                eng.transform_from_pass1_slots(r, planes);
+                fft_sync<G::kMultiWave>();
+                eng.image_store(r);
+                fft_sync<G::kMultiWave>();          // the reference omits this (latent race, CT:563-565)
+            }
+        }
+        fft_sync<G::kMultiWave>();
+        planes_to_tile<N, DIR, REORDER>(d_output + first * N, planes, first, nSlots);
     }
 }
 
@@ -537,8 +600,14 @@ SMFFT_DIT_external_occ3(const float2* d_input, float2* d_output, int nFFTs, int 
 
 template <class const_params>
 __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_size) SMFFT_DIT_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
-    __shared__ float2 s_input[smfft::Geometry<const_params::fft_size>::kCompactLds];
-    smfft::c2c_multiple_body<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nSlots, nreuses, s_input);
+    constexpr int N = const_params::fft_size;
+    if constexpr (SMFFT_PLANAR_SIZES(N)) {
+        __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<N, const_params::fft_reorder>::kLdsFloats];
+        smfft::c2c_multiple_body_planar<N, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nSlots, nreuses, s_planes);
+    } else {
+        __shared__ float2 s_input[smfft::Geometry<N>::kCompactLds];
+        smfft::c2c_multiple_body<N, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nSlots, nreuses, s_input);
+    }
 }
 
 // Stockham C2C program: un-normalised INVERSE (+i) transform, natural order (ST:76, :429).
