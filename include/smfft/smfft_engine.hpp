@@ -544,7 +544,8 @@ struct Engine {
     // N = 512 / 1024.  After pass 1 lane (t2, row r2) holds element (t1 = t2 + 16*r2, q1) in r[q1];
     // the middle pass wants lane (t2, row a) to hold (t2 + 16*r2, q1 = a*BM + c) in r[c*RM + r2]:
     // transpose the row bits with the top log2(RM) bits of q1, then rename registers.
-    __device__ __forceinline__ void exchange1_registers(float2 (&r)[16]) const {
+    __device__ __forceinline__ void exchange1_registers(float2 (&r)[16]) const { exchange1_registers_static(r); }
+    __device__ static __forceinline__ void exchange1_registers_static(float2 (&r)[16]) {
         if constexpr (RM == 4) {
 #pragma unroll
             for (int q = 0; q < 16; ++q)

@@ -48,25 +48,83 @@ __device__ __forceinline__ void addtid_store4(unsigned m0, float2 a, float2 b, f
         : "memory");
 }
 
+// Row placement.  A row holds TW dwords (one per thread of the workgroup); row j of an exchange starts at
+// TW * rank(j) + 4 * q[j] dwords, rank = the row's place in the order of the residues q (so rows never overlap and a plane
+// is at most 16 * TW + 60 dwords).  Only q[j] (the row's base / 4 mod 16) matters for bank conflicts; the residues per
+// length and exchange are the ones tools/soa_model.py found conflict free (N = 4096: 2-way on three of its reads, see there).
+struct RowTable {
+    int base[16];
+    int span;
+};
+constexpr RowTable place_rows(int tw, int q0, int q1, int q2, int q3, int q4, int q5, int q6, int q7, int q8, int q9, int q10, int q11, int q12, int q13, int q14, int q15) {
+    const int q[16] = {q0, q1, q2, q3, q4, q5, q6, q7, q8, q9, q10, q11, q12, q13, q14, q15};
+    RowTable t{};
+    int span = 0;
+    for (int j = 0; j < 16; ++j) {
+        int rank = 0;
+        for (int k = 0; k < 16; ++k) rank += (q[k] < q[j] || (q[k] == q[j] && k < j)) ? 1 : 0;
+        t.base[j] = tw * rank + 4 * q[j];
+        span = t.base[j] + tw > span ? t.base[j] + tw : span;
+    }
+    t.span = span;
+    return t;
+}
+constexpr int bit_of(int j, int b) { return (j >> b) & 1; }
+// residue of row j as a function of (j's bits): the tables of tools/soa_model.py in closed form
+enum class RowKind { image, x1, x2 };
+template <int N, int REORDER>
+constexpr int row_residue(RowKind kind, int j) {
+    switch (kind) {
+        case RowKind::image:    // read by the bit-reversed loads of the no-reorder variants (lane linear in the reorder variants)
+            return N == 128 ? bit_of(j, 2) + 8 * bit_of(j, 3) : N == 256 ? j : N == 512 ? bit_of(j, 0) + 2 * bit_of(j, 2) + 8 * bit_of(j, 3) : N == 4096 ? 2 * bit_of(j, 3) : (j >> 2);
+        case RowKind::x1:       // after pass 1 (three-pass lengths)
+            return N == 2048 ? bit_of(j, 1) : N == 4096 ? bit_of(j, 0) : 0;      // (N = 512 exchanges in registers)
+        default:                // in front of the last pass
+            if (N == 128) return bit_of(j, 0) + 8 * bit_of(j, 1);
+            if (N == 256) return (j & 3) + 8 * bit_of(j, 3);
+            if (REORDER && N != 512) return (j & 3) + 8 * bit_of(j, 3);           // klow = pass-1 role
+            return N == 512 ? bit_of(j, 0) + 2 * bit_of(j, 1) + 8 * bit_of(j, 2) : N == 1024 ? (j >> 2) : N == 2048 ? bit_of(j, 0) + 2 * bit_of(j, 3) : bit_of(j, 0);
+    }
+}
+template <int N, int REORDER>
+constexpr RowTable make_rows(RowKind k) {
+    constexpr int tw = Geometry<N>::kCompactThreads;
+    return place_rows(tw, row_residue<N, REORDER>(k, 0), row_residue<N, REORDER>(k, 1), row_residue<N, REORDER>(k, 2), row_residue<N, REORDER>(k, 3),
+                      row_residue<N, REORDER>(k, 4), row_residue<N, REORDER>(k, 5), row_residue<N, REORDER>(k, 6), row_residue<N, REORDER>(k, 7),
+                      row_residue<N, REORDER>(k, 8), row_residue<N, REORDER>(k, 9), row_residue<N, REORDER>(k, 10), row_residue<N, REORDER>(k, 11),
+                      row_residue<N, REORDER>(k, 12), row_residue<N, REORDER>(k, 13), row_residue<N, REORDER>(k, 14), row_residue<N, REORDER>(k, 15));
+}
+// the same tables in device memory, for the rows a thread picks at run time (once, at set-up)
+template <int N, int REORDER>
+struct PlanarRows {
+    RowTable image, x1, x2;
+    constexpr PlanarRows() : image(make_rows<N, REORDER>(RowKind::image)), x1(make_rows<N, REORDER>(RowKind::x1)), x2(make_rows<N, REORDER>(RowKind::x2)) {}
+};
+template <int N, int REORDER>
+static __device__ const PlanarRows<N, REORDER> planar_rows = PlanarRows<N, REORDER>();
+
+// Synchronisation between the threads of an FFT.  The compiler does not count the stores issued from inline assembly, so a
+// multi-wave FFT drains them itself in front of the workgroup barrier; inside one wave DS operations execute in order.
+template <bool MULTI_WAVE>
+__device__ __forceinline__ void planar_sync() {
+    if (MULTI_WAVE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    fft_sync<MULTI_WAVE>();
+}
+
 template <int N, int REORDER>
 struct PlanarGeometry {
     using G = Geometry<N>;
     static constexpr int T = G::T, RM = G::RM, BM = G::BM, R1 = G::R1, B1 = G::B1;
     static constexpr int TW = G::kCompactThreads;
     static constexpr int F = TW / T;
-    // Row bases (dwords inside a plane; closed forms found by tools/soa_model.py, every read below conflict free).
-    // Rows are TW dwords long; the shifts are multiples of 4 dwords (ds_read_b128 needs 16-byte alignment).
-    static constexpr int image_row(int j) { return TW * j + 4 * ((j >> 1) & 3) + 16 * (j >> 3); }
-    static constexpr int x1_row(int j) { return TW * j; }
-    // no reorder: klow = position; reorder: klow = pass-1 role
-    static constexpr int x2_row(int j) { return REORDER ? TW * j + 4 * (j & 3) + 32 * (j >> 2) : TW * j + 4 * (j >> 2); }
-    static constexpr int span(int (*row)(int)) {
-        int m = 0;
-        for (int j = 0; j < 16; ++j) m = row(j) + TW > m ? row(j) + TW : m;
-        return m;
-    }
+    static constexpr RowTable kImage = make_rows<N, REORDER>(RowKind::image), kX1 = make_rows<N, REORDER>(RowKind::x1), kX2 = make_rows<N, REORDER>(RowKind::x2);
+    static constexpr int image_row(int j) { return kImage.base[j]; }
+    static constexpr int x1_row(int j) { return kX1.base[j]; }
+    static constexpr int x2_row(int j) { return kX2.base[j]; }
     static constexpr int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
-    static constexpr int kPlane = max3(span(image_row), span(x1_row), span(x2_row));   // dwords per plane (a multiple of 4)
+    static constexpr int kPlane = max3(kImage.span, RM > 1 ? kX1.span : 0, kX2.span);   // dwords per plane (a multiple of 4)
+    // (N = 4096 with its fifteen middle-pass twiddles read from a table in LDS instead of 30 registers measured 7 % slower:
+    //  profiles/r03_ab_planar_c.txt)
     static constexpr int kLdsFloats = 2 * kPlane;
 };
 
@@ -75,19 +133,47 @@ struct PlanarEngine {
     using G = Geometry<N>;
     using P = PlanarGeometry<N, REORDER>;
     static constexpr int T = G::T, RM = G::RM, BM = G::BM, R1 = G::R1, B1 = G::B1, TW = P::TW;
-    static constexpr int T_BITS = ilog2c(T);
-    static_assert(RM > 1, "three-pass sizes only (so far)");
-    static constexpr bool kForward = REORDER;   // last-pass thread v computes klow = pass-1 role of v
+    static constexpr int T_BITS = ilog2c(T), R1_BITS = ilog2c(R1), B1_BITS = ilog2c(B1), RM_BITS = ilog2c(RM);
+    static_assert(N >= 128, "N = 32 / 64 keep the register engine");
+    static constexpr bool kThreePass = RM > 1;
+    // N = 512 (RM = 2): exchange 1 moves data between two threads only -- sixteen v_permlane16_swap (Engine::exchange1_registers)
+    // measured faster than a third trip through LDS (profiles/r03_ab_planar_all.txt); its roles are the register engine's (t1 = v)
+    static constexpr bool kRegisterX1 = (RM == 2);
+    static constexpr bool kForward = REORDER;   // the last-pass thread computes klow = its own pass-1 role
+    // no reorder, RM >= 8: the RM threads that share t2 take r2 in bit-reversed order, so that the blocks of a row their
+    // bit-reversed loads touch are neighbours (conflict free for N = 2048, 2-way instead of 4-way for N = 4096)
+    static constexpr bool kReverseR2 = !REORDER && RM >= 8;
+    static constexpr int r2_of(int m) {
+        if (!kReverseR2) return m;
+        int r = 0;
+        for (int i = 0; i < RM_BITS; ++i) r |= ((m >> i) & 1) << (RM_BITS - 1 - i);
+        return r;
+    }
 
     int v, fft;          // position inside the FFT, FFT inside the workgroup
     int t1;              // pass-1 role
-    int t2, a;           // middle role
+    int t2, a;           // middle role (three-pass lengths)
     int klow;            // last-pass output index: r[q3] = X[klow + T * q3]
     unsigned m0;         // LDS byte address of (plane 0, dword 64 * wave)
+    // dword offsets of the thread's runs (set-up, loop invariant)
+    static constexpr int kImageRuns = T >= 16 ? 1 : 16 / T;
+    int off_image[kImageRuns], off_x1, off_x2[B1];
     Twiddles<N, DIR> tw;
 
-    __device__ static __forceinline__ int pass1_role(int pos) { return (pos / RM) + 16 * (pos % RM); }
-    __device__ static __forceinline__ int position_of_role(int role) { return RM * (role % 16) + role / 16; }
+    static constexpr bool x1_rows_regular() {
+        for (int aa = 0; aa < RM; ++aa)
+            for (int c = 0; c < BM; ++c)
+                if (P::x1_row(aa * BM + c) - P::x1_row(aa * BM) != P::x1_row(c) - P::x1_row(0)) return false;
+        return true;
+    }
+    __device__ static __forceinline__ int pass1_role(int pos) {
+        if constexpr (!kThreePass || kRegisterX1) return pos;
+        else return (pos / RM) + 16 * (kReverseR2 ? (int)(__brev((unsigned)(pos % RM)) >> (32 - RM_BITS)) : pos % RM);
+    }
+    __device__ static __forceinline__ int position_of_role(int role) {
+        if constexpr (!kThreePass || kRegisterX1) return role;
+        else return RM * (role % 16) + (kReverseR2 ? (int)(__brev((unsigned)(role / 16)) >> (32 - RM_BITS)) : role / 16);
+    }
 
     __device__ __forceinline__ void init(int tid, const float* planes) {
         v = tid % T;
@@ -95,10 +181,30 @@ struct PlanarEngine {
         t1 = pass1_role(v);
         t2 = v % 16;
         a = v / 16;
-        klow = kForward ? t1 : v;
+        klow = (kThreePass && kForward) ? t1 : v;
         typedef __attribute__((address_space(3))) const float lds_float;
         m0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_float*)planes + 4u * (tid & ~63));
         tw.init(t1, t2);
+        const PlanarRows<N, REORDER>& rows = planar_rows<N, REORDER>;
+        // bit-reversed load: the sixteen contiguous elements p = 16 * rho + i of the natural image, rho = rev_T(t1):
+        // element p is dword fft * T + p % T of row p / T
+        const int rho = (int)(__brev((unsigned)t1) >> (32 - T_BITS));
+        if constexpr (T >= 16) {
+            off_image[0] = rows.image.base[rho / (T / 16)] + fft * T + 16 * (rho % (T / 16));
+        } else {
+#pragma unroll
+            for (int h = 0; h < kImageRuns; ++h) off_image[h] = rows.image.base[kImageRuns * rho + h] + fft * T;   // T dwords of each row
+        }
+        if constexpr (kThreePass) {
+            static_assert(x1_rows_regular(), "x1_load takes the rows a*BM + c at compile-time distances from row a*BM");
+            off_x1 = kRegisterX1 ? 0 : rows.x1.base[a * BM] + fft * T + RM * t2;
+            const int c = klow % BM, aa = (klow % 16) / BM, q2 = klow / 16;
+            off_x2[0] = rows.x2.base[c * RM + q2] + fft * T + 16 * aa;
+        } else {
+            off_x1 = 0;
+#pragma unroll
+            for (int b = 0; b < B1; ++b) off_x2[b] = rows.x2.base[b * R1 + v] + fft * T;
+        }
     }
 
     // ---- sixteen registers -> rows ROW(j), dword tid, both planes -------------------------------------------------
@@ -108,6 +214,24 @@ struct PlanarEngine {
         addtid_store4<ROW(4), ROW(5), ROW(6), ROW(7), P::kPlane>(m0, r[4], r[5], r[6], r[7]);
         addtid_store4<ROW(8), ROW(9), ROW(10), ROW(11), P::kPlane>(m0, r[8], r[9], r[10], r[11]);
         addtid_store4<ROW(12), ROW(13), ROW(14), ROW(15), P::kPlane>(m0, r[12], r[13], r[14], r[15]);
+    }
+    // a run of RUN (4, 8, 16: ds_read_b128; 2: ds_read_b64) contiguous dwords of both planes -> out[0 .. RUN)
+    template <int RUN>
+    __device__ static __forceinline__ void load_run(float2* out, const float* p) {
+        if constexpr (RUN == 2) {
+            const f2v re = *reinterpret_cast<const f2v*>(p);
+            const f2v im = *reinterpret_cast<const f2v*>(p + P::kPlane);
+            out[0] = make_float2(re[0], im[0]);
+            out[1] = make_float2(re[1], im[1]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < RUN / 4; ++k) {
+                const f4v re = *reinterpret_cast<const f4v*>(p + 4 * k);
+                const f4v im = *reinterpret_cast<const f4v*>(p + P::kPlane + 4 * k);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) out[4 * k + m] = make_float2(re[m], im[m]);
+            }
+        }
     }
 
     // ---- the image between applications: row c, dword (fft, position of the thread whose natural index is u) holds x[u + T*c]
@@ -120,56 +244,63 @@ struct PlanarEngine {
         for (int c = 0; c < 16; ++c) r[c] = make_float2(p[P::image_row(c)], p[P::kPlane + P::image_row(c)]);
     }
 
-    // no reorder: the thread with pass-1 role t1 needs x[bitrev(t1 + T1*r1)] = element 16 * rho + rev4(r1), rho = rev_T(t1):
-    // sixteen contiguous elements p = 16 * rho + i of the natural image = dwords 16 * (rho % (T/16)) + i of row rho / (T/16)
+    // pass-1 slot b*R1 + r1 holds x'[t1 + T*b + T1*r1]; without reorder x' = x o bitrev, which makes it element
+    // i = rev_B1(b) * R1 + rev_R1(r1) of the thread's sixteen contiguous ones
+    static constexpr int slot_of_element(int i) {
+        const int hb = i / R1, lr = i % R1;
+        int b = 0, r1 = 0;
+        for (int k = 0; k < B1_BITS; ++k) b |= ((hb >> k) & 1) << (B1_BITS - 1 - k);
+        for (int k = 0; k < R1_BITS; ++k) r1 |= ((lr >> k) & 1) << (R1_BITS - 1 - k);
+        return b * R1 + r1;
+    }
     __device__ __forceinline__ void image_load_bitrev(float2 (&r)[16], const float* planes) const {
-        static_assert(T >= 16, "");
-        const int rho = (int)(__brev((unsigned)t1) >> (32 - T_BITS));
-        const int row = rho / (T / 16);
-        const float* p = planes + P::image_row(row) + fft * T + 16 * (rho % (T / 16));
+        float2 e[16];
+        if constexpr (T >= 16) {
+            load_run<16>(e, planes + off_image[0]);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const f4v re = *reinterpret_cast<const f4v*>(p + 4 * k);
-            const f4v im = *reinterpret_cast<const f4v*>(p + P::kPlane + 4 * k);
+            for (int h = 0; h < kImageRuns; ++h) load_run<T>(&e[T * h], planes + off_image[h]);   // T = 8: rows 2 * rho, 2 * rho + 1
+        }
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                r[rev4(4 * k + m)] = make_float2(re[m], im[m]);
-            }
+        for (int i = 0; i < 16; ++i) r[slot_of_element(i)] = e[i];
+    }
+    // reorder: natural registers r[c] = x[t1 + T*c] -> pass-1 slots r[b*R1 + r1] = x[t1 + T*b + T1*r1] (c = b + B1*r1): a renaming
+    __device__ static __forceinline__ void natural_to_slots(float2 (&r)[16]) {
+        if constexpr (B1 > 1) {
+            float2 t[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) t[c] = r[c];
+#pragma unroll
+            for (int b = 0; b < B1; ++b)
+#pragma unroll
+                for (int r1 = 0; r1 < R1; ++r1) r[b * R1 + r1] = t[b + B1 * r1];
         }
     }
-    static constexpr int rev4(int i) { return ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3); }
 
-    // ---- pass 1 (registers hold the pass-1 slots r[r1] = x'[t1 + T1*r1]) --------------------------------------------
+    // ---- pass 1: B1 radix-R1 butterflies, then W_N^{(t1 + T*b) * q1} -----------------------------------------------
     __device__ __forceinline__ void pass1(float2 (&r)[16]) const {
-        float2 y[16];
-        SmallDft<16, 1, DIR>::run(r, y);
-        r[0] = y[0];
 #pragma unroll
-        for (int q1 = 1; q1 < 16; ++q1) r[q1] = cmul(y[q1], tw.w1[q1]);
+        for (int b = 0; b < B1; ++b) {
+            float2 y[R1];
+            SmallDft<R1, 1, DIR>::run(&r[b * R1], y);
+            r[b * R1] = y[0];
+#pragma unroll
+            for (int q1 = 1; q1 < R1; ++q1) r[b * R1 + q1] = cmul(y[q1], tw.w1[b * R1 + q1]);
+        }
     }
 
-    // ---- exchange 1: (t1, q1) in row q1 at the dword of the thread with role t1 ------------------------------------
+    // ---- exchange 1 (three-pass): (t1, q1) in row q1 at the dword of the thread with role t1 -------------------------
     __device__ __forceinline__ void x1_store(const float2 (&r)[16]) const { store_rows<P::x1_row>(r); }
-    // middle thread (t2, a): r[c*RM + r2] = element (t2 + 16*r2, q1 = a*BM + c) = row a*BM + c, dwords RM*t2 + r2
+    // middle thread (t2, a): r[c*RM + r2] = element (t2 + 16*r2, q1 = a*BM + c) = row a*BM + c, dwords RM*t2 + m, r2 = r2_of(m)
     __device__ __forceinline__ void x1_load(float2 (&r)[16], const float* planes) const {
-        const float* p = planes + P::x1_row(a * BM) + fft * T + RM * t2;     // x1_row is linear in the row index
-        static_assert(P::x1_row(5) - P::x1_row(4) == TW && P::x1_row(0) == 0, "");
+        const float* p = planes + off_x1;
 #pragma unroll
         for (int c = 0; c < BM; ++c) {
-            if constexpr (RM == 2) {
-                const f2v re = *reinterpret_cast<const f2v*>(p + TW * c);
-                const f2v im = *reinterpret_cast<const f2v*>(p + P::kPlane + TW * c);
-                r[c * RM + 0] = make_float2(re[0], im[0]);
-                r[c * RM + 1] = make_float2(re[1], im[1]);
-            } else {
+            float2 e[RM];
+            // rows a*BM + c for c < BM are consecutive in the placement (same residue class order), so their distance is constant
+            load_run<RM>(e, p + (P::x1_row(c) - P::x1_row(0)));
 #pragma unroll
-                for (int k = 0; k < RM / 4; ++k) {
-                    const f4v re = *reinterpret_cast<const f4v*>(p + TW * c + 4 * k);
-                    const f4v im = *reinterpret_cast<const f4v*>(p + P::kPlane + TW * c + 4 * k);
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) r[c * RM + 4 * k + m] = make_float2(re[m], im[m]);
-                }
-            }
+            for (int m = 0; m < RM; ++m) r[c * RM + r2_of(m)] = e[m];
         }
     }
 
@@ -185,35 +316,37 @@ struct PlanarEngine {
         }
     }
 
-    // ---- exchange 2: register j = c*RM + q2 of thread (t2, a) is element (t2, klow = a*BM + c + 16*q2) --------------
-    __device__ __forceinline__ void x2_store(const float2 (&r)[16]) const {
-        store_rows<P::x2_row>(r);
-    }
-    // last-pass thread klow reads t2 = 0..15: row c*RM + q2, dwords 16*a + t2  (c = klow % BM, a = (klow % 16) / BM, q2 = klow / 16)
+    // ---- exchange in front of the last pass ---------------------------------------------------------------------------
+    // three-pass: register j = c*RM + q2 of thread (t2, a) is element (t2, klow = a*BM + c + 16*q2); the last-pass thread klow
+    //             reads t2 = 0..15 = dwords 16*a + t2 of row c*RM + q2  (c = klow % BM, a = (klow % 16) / BM, q2 = klow / 16)
+    // two-pass:   register b*R1 + q1 of thread t1 is element (n1 = t1 + T*b, q1); the last-pass thread q1 = v reads
+    //             n1 = 0..15 = dwords t1 of rows b*R1 + v
+    __device__ __forceinline__ void x2_store(const float2 (&r)[16]) const { store_rows<P::x2_row>(r); }
     __device__ __forceinline__ void x2_load(float2 (&x)[16], const float* planes) const {
-        const int c = klow % BM, aa = (klow % 16) / BM, q2 = klow / 16;
-        const int j = c * RM + q2;
-        const float* p = planes + P::x2_row(j) + fft * T + 16 * aa;
+        if constexpr (kThreePass || B1 == 1) {
+            load_run<16>(x, planes + off_x2[0]);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const f4v re = *reinterpret_cast<const f4v*>(p + 4 * k);
-            const f4v im = *reinterpret_cast<const f4v*>(p + P::kPlane + 4 * k);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) x[4 * k + m] = make_float2(re[m], im[m]);
+            for (int b = 0; b < B1; ++b) load_run<T>(&x[T * b], planes + off_x2[b]);
         }
     }
 
     // ---- one application: pass-1 slots in r -> natural result r[q3] = X[klow + T*q3] --------------------------------
     __device__ __forceinline__ void transform_from_pass1_slots(float2 (&r)[16], float* planes) const {
         pass1(r);
-        fft_sync<G::kMultiWave>();       // every read of the previous image is done
-        x1_store(r);
-        fft_sync<G::kMultiWave>();
-        x1_load(r, planes);
-        middle(r);
-        fft_sync<G::kMultiWave>();
+        planar_sync<G::kMultiWave>();       // every read of the previous image is done
+        if constexpr (kRegisterX1) {
+            Engine<N, DIR, 1>::exchange1_registers_static(r);
+            middle(r);
+        } else if constexpr (kThreePass) {
+            x1_store(r);
+            planar_sync<G::kMultiWave>();
+            x1_load(r, planes);
+            middle(r);
+            planar_sync<G::kMultiWave>();
+        }
         x2_store(r);
-        fft_sync<G::kMultiWave>();
+        planar_sync<G::kMultiWave>();
         float2 x[16];
         x2_load(x, planes);
         SmallDft<16, 1, DIR>::run(x, r);

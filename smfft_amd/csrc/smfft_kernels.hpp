@@ -282,7 +282,10 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_i
 #ifndef SMFFT_PLANAR
 #define SMFFT_PLANAR 1          // 0: the float2-image engine for every length (A/B)
 #endif
-#define SMFFT_PLANAR_SIZES(N) (SMFFT_PLANAR && (N) == 1024)
+#ifndef SMFFT_PLANAR_MIN_N
+#define SMFFT_PLANAR_MIN_N 128  // N = 32 / 64 (an FFT is 2 / 4 lanes) keep the register engine and its float2 image
+#endif
+#define SMFFT_PLANAR_SIZES(N) (SMFFT_PLANAR && (N) >= SMFFT_PLANAR_MIN_N)
 template <int N, int DIR, int REORDER>
 __device__ __forceinline__ void c2c_multiple_body_planar(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, float* planes) {
     using G = Geometry<N>;
@@ -291,27 +294,28 @@ __device__ __forceinline__ void c2c_multiple_body_planar(const float2* __restric
     const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long first = (long)tile * G::kCompactFfts;
-        fft_sync<G::kMultiWave>();
+        planar_sync<G::kMultiWave>();
         tile_to_planes<N, DIR, REORDER>(d_input + first * N, planes, first, nSlots);
-        fft_sync<G::kMultiWave>();
+        planar_sync<G::kMultiWave>();
         float2 r[16];
         if constexpr (REORDER) {
             eng.image_load_own(r, planes);
             for (int f = 0; f < nreuses; ++f) {
+                eng.natural_to_slots(r);
                 eng.transform_from_pass1_slots(r, planes);
-                fft_sync<G::kMultiWave>();          // the last pass's reads are done before the result overwrites them
+                planar_sync<G::kMultiWave>();       // the last pass's reads are done before the result overwrites them
                 eng.image_store(r);
             }
         } else {
             for (int f = 0; f < nreuses; ++f) {
                 eng.image_load_bitrev(r, planes);
                 eng.transform_from_pass1_slots(r, planes);
-                fft_sync<G::kMultiWave>();
+                planar_sync<G::kMultiWave>();
                 eng.image_store(r);
-                fft_sync<G::kMultiWave>();          // the reference omits this (latent race, CT:563-565)
+                planar_sync<G::kMultiWave>();       // the reference omits this (latent race, CT:563-565)
             }
         }
-        fft_sync<G::kMultiWave>();
+        planar_sync<G::kMultiWave>();
         planes_to_tile<N, DIR, REORDER>(d_output + first * N, planes, first, nSlots);
     }
 }
@@ -595,7 +599,9 @@ SMFFT_DIT_external_occ3(const float2* d_input, float2* d_output, int nFFTs, int 
 #ifdef SMFFT_MULT_MINWAVES
 #define SMFFT_COMPACT_BOUNDS(N) __launch_bounds__(smfft::Geometry<N>::kCompactThreads, SMFFT_MULT_MINWAVES)
 #else
-#define SMFFT_COMPACT_BOUNDS(N) __launch_bounds__(smfft::Geometry<N>::kCompactThreads)
+// N = 2048 / 4096: compiled for 4 waves per SIMD (what their LDS allows, 8-9 / 4 workgroups per CU); left alone the planar
+// engine takes 133-170 registers = 3 or 2 waves per SIMD (profiles/r03_ab_planar_b.txt: +6 % / +3-17 % with the target stated)
+#define SMFFT_COMPACT_BOUNDS(N) __launch_bounds__(smfft::Geometry<N>::kCompactThreads, (N) >= 2048 ? 4 : 1)
 #endif
 
 template <class const_params>

@@ -7,9 +7,10 @@ ds_write_b64), so all freedom is in WHO READS WHAT: each exchange is arranged so
 runs of contiguous dwords of few rows (ds_read_b128 / ds_read_b64: full LDS rate) and the row bases are padded so
 that those reads are bank-conflict free under the gfx950 rules (MI355X_MICROARCH.md, LDS table).
 
-This script (1) emulates the whole choreography thread by thread for every N and both orderings and checks the
-result against numpy.fft, and (2) counts bank conflicts of every read instruction.  It also prints the row-base
-tables the header uses.
+This script states the read pattern of every exchange (who reads which dwords of which rows), counts the bank
+conflicts of every read instruction and searches, per length and exchange, the shift of each row (its base / 4 mod 16:
+the "residue") that makes all of them conflict free.  It prints the residue tables pasted into the header.  (That the
+index maps compute the right transform is checked on the GPU by the parity tests of the `multiple` path.)
     python tools/soa_model.py [N ...]"""
 import sys
 
@@ -68,75 +69,11 @@ class Geometry:
         self.tb = ilog2(self.T)
 
 
-# ---- row bases (dwords inside a plane).  A row holds TW dwords (one per thread). ------------------------------------
-def row_bases(G, kind):
-    """kind: 'image' (16 rows, natural registers), 'x1' (exchange after pass 1), 'x2' (exchange before the last pass)."""
-    TW = G.TW
-    if G.RM > 1:
-        if kind == "x1":
-            return [TW * j for j in range(16)]
-        if kind == "x2":
-            return [TW * j + 4 * (j // G.RM) for j in range(16)] if G.RM >= 4 else [TW * j + 4 * ((j // 2) % 4) + 16 * (j // 8) for j in range(16)]
-        if kind == "image":
-            return IMAGE_BASES[G.N]
-    else:
-        if kind == "x2":
-            return LAST_BASES[G.N]
-        if kind == "image":
-            return IMAGE_BASES[G.N]
-    raise ValueError(kind)
-
-
-IMAGE_BASES = {}
-LAST_BASES = {}
-
-
 def pass1_role(G, v):
     """thread position v inside its FFT -> pass-1 role t1 (three-pass sizes: v = RM * t2 + r2 -> t1 = t2 + 16 * r2)"""
     if G.RM > 1:
         return (v // G.RM) + 16 * (v % G.RM)
     return v
-
-
-def search_bases(G, kind, addr_fn, widths, tries):
-    """find row bases (multiples of 4 dwords, rows of TW dwords, not overlapping) that make every read conflict free"""
-    best = None
-    for name, bases in tries:
-        total = 0
-        for instr in addr_fn(bases):
-            total += conflict_cycles(instr[0], instr[1])
-        if best is None or total < best[0]:
-            best = (total, name, bases)
-        if total == 0:
-            break
-    return best
-
-
-def bases_from_residues(TW, q):
-    """row j gets quad residue q[j] (its base / 4 mod 16): rows are placed in the order of their residues, so the shifts
-    never make rows overlap and the plane is at most 16 * TW + 60 dwords"""
-    order = sorted(range(16), key=lambda j: (q[j], j))
-    bases = [0] * 16
-    for rank, j in enumerate(order):
-        bases[j] = TW * rank + 4 * q[j]
-    return bases
-
-
-def candidate_bases(TW):
-    """GF(2)-linear maps of the row index to the quad residue, simplest first"""
-    out = [("q = 0", [TW * j for j in range(16)])]
-    seen = set()
-    import itertools
-    # each residue bit is the XOR of a subset of the row-index bits: 16 choices per bit, tried in order of total weight
-    masks = sorted(range(16), key=lambda m: (bin(m).count("1"), m))
-    combos = sorted(itertools.product(masks, repeat=4), key=lambda ms: (sum(bin(m).count("1") for m in ms), ms))
-    for ms in combos:
-        q = tuple(sum(((bin(j & ms[b]).count("1") & 1) << b) for b in range(4)) for j in range(16))
-        if q in seen:
-            continue
-        seen.add(q)
-        out.append((f"q bits = parity(j & {ms})", bases_from_residues(TW, q)))
-    return out
 
 
 # ---- the reads of each exchange, as (addresses per lane of the wave, width) -------------------------------------------
@@ -196,49 +133,93 @@ def x2_reads(G, bases, klow_of, wave=0):
 def last_reads_two_pass(G, bases, wave=0):
     """two-pass sizes: last-pass thread q1 (= position v'') reads n1 = 0..15: n1 = t1 + T * b in row b * R1 + q1, dword fft * T + t1"""
     T, R1, B1 = G.T, G.R1, G.B1
+    width = min(T, 4)
     instrs = []
     for b in range(B1):
-        for start in range(0, T, 4):
+        for start in range(0, T, width):
             addrs = []
             for lane in range(64):
                 tid = 64 * wave + lane
                 fft, v = tid // T, tid % T
                 addrs.append(bases[b * R1 + v] + fft * T + start)
-            instrs.append((addrs, 4))
+            instrs.append((addrs, width))
     return instrs
 
 
-def pick_bases(N):
+def bases_from_residues(TW, q):
+    """row j gets quad residue q[j] (its base / 4 mod 16): rows are placed in the order of their residues, so the shifts
+    never make rows overlap and the plane is at most 16 * TW + 60 dwords"""
+    order = sorted(range(16), key=lambda j: (q[j], j))
+    bases = [0] * 16
+    for rank, j in enumerate(order):
+        bases[j] = TW * rank + 4 * q[j]
+    return bases
+
+
+def total_conflicts(TW, q, instr_fn):
+    bases = bases_from_residues(TW, q)
+    return sum(conflict_cycles(a, w) for a, w in instr_fn(bases))
+
+
+def search_residues(TW, instr_fn, seed=0):
+    """coordinate descent over the sixteen residues, from a few structured starts and random restarts"""
+    rng = np.random.default_rng(seed)
+    starts = [[0] * 16, [j % 16 for j in range(16)], [(j >> 2) for j in range(16)], [(j >> 1) & 3 for j in range(16)],
+              [(j & 3) + 8 * (j >> 3) for j in range(16)], [(j & 3) + 4 * ((j >> 2) & 1) for j in range(16)]]
+    best = None
+    for attempt in range(40):
+        q = list(starts[attempt]) if attempt < len(starts) else [int(x) for x in rng.integers(0, 16, 16)]
+        cur = total_conflicts(TW, q, instr_fn)
+        improved = True
+        while improved and cur > 0:
+            improved = False
+            for j in range(16):
+                for val in range(16):
+                    if val == q[j]:
+                        continue
+                    old = q[j]
+                    q[j] = val
+                    t = total_conflicts(TW, q, instr_fn)
+                    if t < cur:
+                        cur, improved = t, True
+                    else:
+                        q[j] = old
+        if best is None or cur < best[0] or (cur == best[0] and max(q) < max(best[1])):
+            best = (cur, list(q))
+        if cur == 0 and attempt >= len(starts) - 1:
+            break
+        if cur == 0 and max(q) <= 3:
+            break
+    return best
+
+
+def exchanges(N):
+    """name -> function(bases) -> list of (addresses, width) over every wave of the workgroup"""
     G = Geometry(N)
     waves = G.TW // 64
-    cands = candidate_bases(G.TW)
 
-    def over_waves(fn):
-        return lambda bases: [i for w in range(waves) for i in fn(G, bases, w)]
+    def over_waves(fn, *extra):
+        return lambda bases: [i for w in range(waves) for i in fn(G, bases, *extra, wave=w)]
 
-    res = {}
-    best = search_bases(G, "image", over_waves(image_bitrev_reads), None, cands)
-    IMAGE_BASES[N] = best[2]
-    res["image"] = best
+    ex = {"image (bit-reversed rows)": over_waves(image_bitrev_reads)}
     if G.RM > 1:
-        res["x1"] = search_bases(G, "x1", over_waves(x1_reads), None, cands)
-        for name, klow_of in (("x2 (klow = position)", lambda v: v), ("x2 (klow = pass-1 role)", lambda v: pass1_role(G, v))):
-            res[name] = search_bases(G, "x2", lambda bases: [i for w in range(waves) for i in x2_reads(G, bases, klow_of, w)], None, cands)
+        ex["x1"] = over_waves(x1_reads)
+        ex["x2, klow = position (no reorder)"] = over_waves(x2_reads, lambda v: v)
+        ex["x2, klow = pass-1 role (reorder)"] = over_waves(x2_reads, lambda v: pass1_role(G, v))
     else:
-        best = search_bases(G, "x2", over_waves(last_reads_two_pass), None, cands)
-        LAST_BASES[N] = best[2]
-        res["last"] = best
-    return G, res
+        ex["last (two-pass)"] = over_waves(last_reads_two_pass)
+    return G, ex
 
 
 def main():
     sizes = [int(a) for a in sys.argv[1:]] or [128, 256, 512, 1024, 2048, 4096]
     for N in sizes:
-        G, res = pick_bases(N)
+        G, ex = exchanges(N)
         print(f"N={N}: T={G.T} TW={G.TW} RM={G.RM}")
-        for k, (extra, name, bases) in res.items():
-            span = max(bases) + G.TW
-            print(f"  {k:28s}: extra LDS cycles {extra:3d}  bases {name}  plane span {span} dwords")
+        for name, fn in ex.items():
+            extra, q = search_residues(G.TW, fn)
+            span = max(bases_from_residues(G.TW, q)) + G.TW
+            print(f"  {name:36s}: extra LDS cycles {extra:3d}  residues {{{', '.join(str(x) for x in q)}}}  plane span {span} dwords", flush=True)
 
 
 if __name__ == "__main__":
