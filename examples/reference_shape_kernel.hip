@@ -84,3 +84,18 @@ extern "C" int smfft_example_reference_shape_multiple(void* d_in, void* d_out, i
     SMFFT_DIT_multiple<FFT_1024_forward><<<dim3(nFFTs), dim3(256), 0, st>>>((float2*)d_in, (float2*)d_out);
     return (int)hipGetLastError();
 }
+
+// one of them alone, for timing (tools/reference_contract.py, bench.py): which = 0 SMFFT_DIT_multiple<FFT_1024_forward>,
+// 1 SMFFT_DIT_multiple<FFT_1024_forward_noreorder>, 2 FFT_GPU_multiple<FFT_1024>, 3 FFT_GPU_R2C_C2R_multiple<FFT_1024, FFT_forward>
+extern "C" int smfft_example_reference_shape_multiple_one(void* d_in, void* d_out, int nBlocks, int which, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    float2 *in = (float2*)d_in, *out = (float2*)d_out;
+    switch (which) {
+        case 0: SMFFT_DIT_multiple<FFT_1024_forward><<<dim3(nBlocks), dim3(256), 0, st>>>(in, out); break;
+        case 1: SMFFT_DIT_multiple<FFT_1024_forward_noreorder><<<dim3(nBlocks), dim3(256), 0, st>>>(in, out); break;
+        case 2: FFT_GPU_multiple<FFT_1024><<<dim3(nBlocks), dim3(256), 1024 * 8, st>>>(in, out); break;
+        case 3: FFT_GPU_R2C_C2R_multiple<FFT_1024, FFT_forward><<<dim3(nBlocks), dim3(256), 0, st>>>(in, out); break;
+        default: return -1;
+    }
+    return (int)hipGetLastError();
+}

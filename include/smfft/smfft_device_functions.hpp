@@ -15,12 +15,15 @@
 //     s[0 .. fft_length) contiguous and in natural order before and after, in place, EVERY thread of the block calls,
 //     the caller barriers before the call (CT also after it).  LDS the caller provides: CT P::fft_sm_required
 //     (= 17 * fft_length / 16 here); Stockham exactly N float2, R2C/C2R L + 1 (as upstream: ST:319, RC:351).
-//     How it runs on a 64-lane wave: the engine needs N / 16 threads per FFT, a quarter of what the contract
-//     launches, so for N <= 1024 the block's first wave does the work (lanes beyond N / 16 repeat it, which the
-//     lane-exchange instructions need) and the other waves return at once; for N = 2048 / 4096 every wave runs
-//     the transform of thread (threadIdx.x mod N/16), so that all waves meet at the same workgroup barriers.
-//     That is a compatibility path -- a quarter of the lanes do useful work; kernels that want the engine's speed
-//     use form (2) or the Engine directly (examples/fft_convolution.hip).
+//     How it runs on a 64-lane wave: EVERY thread of the block works on four elements, as upstream -- the reference's own
+//     radix-2 decimation-in-time ladder with two stages fused per pass (quarter_fft_inplace below): in place, one
+//     synchronisation per pass (a compiler fence while the N/4 threads share a wave), the bit reversal of the
+//     natural-order variants folded into the first pass.  Measured against this library's tiled kernels on the same
+//     buffers (tools/reference_contract.py, profiles/r03_reference_contract_after.txt): external path 0.59-0.95 of their
+//     rate (round 2, one working wave per block: 0.14-0.55), in-LDS path 0.27-0.36 -- five LDS round trips of the
+//     whole FFT per transform (4 reads + 4 writes per thread and pass, 2-4-way bank conflicts in the first three passes
+//     because the data must stay contiguous) against two of the 16-elements-per-thread engine.  Kernels that want the
+//     engine's speed use form (2) or the Engine directly (examples/fft_convolution.hip).
 //
 // (2) THE ENGINE'S TILED CONTRACT (namespace smfft::tiled; what this library's own kernels are built on):
 //     256-thread workgroups own 4096 float2 = P::fft_per_block FFTs; `s` is an LDS array of P::tile_sm_required
@@ -75,37 +78,154 @@ __device__ __forceinline__ void hermitian_pass(float2* sf, int u) {
     }
 }
 
-// In place on LDS, natural layout (device-function form; RC:269-344).  `hermitian_thread`: this thread takes part in
-// the split / merge pass (false for the repeated threads of the reference-shaped form: the pass reads and rewrites
-// the same cells, so exactly one thread may own each pair).
+// In place on LDS, natural layout (device-function form; RC:269-344).
 template <int L, int DIR, bool PAD>
-__device__ __forceinline__ void r2c_c2r_lds_inplace(float2* s, const Engine<L, DIR, 1, PAD>& eng, int stride = Geometry<L, PAD>::SF, bool hermitian_thread = true) {
+__device__ __forceinline__ void r2c_c2r_lds_inplace(float2* s, const Engine<L, DIR, 1, PAD>& eng, int stride = Geometry<L, PAD>::SF) {
     using G = Geometry<L, PAD>;
     float2* sf = s + eng.fft * stride;
     if (DIR == 0) {
         fft_lds_inplace(s, eng, stride);
         fft_sync<G::kMultiWave>();
-        if (hermitian_thread) hermitian_pass<L, 0>(sf, eng.u);
+        hermitian_pass<L, 0>(sf, eng.u);
     } else {
-        if (hermitian_thread) hermitian_pass<L, 1>(sf, eng.u);
+        hermitian_pass<L, 1>(sf, eng.u);
         fft_sync<G::kMultiWave>();
         fft_lds_inplace(s, eng, stride);
     }
 }
 
-// Engine set up for a thread of a reference-shaped block (see the header comment).  Returns false for the threads
-// that have nothing to do (the waves after the first one, N <= 1024).  NF = FFTs the block holds, packed contiguously.
-template <int N, int DIR, int REORDER, bool PAD, int NF>
-__device__ __forceinline__ bool reference_shape_init(Engine<N, DIR, REORDER, PAD>& eng) {
-    using G = Geometry<N, PAD>;
-    if constexpr (G::kMultiWave) {
-        eng.init((int)(threadIdx.x % G::T));
-    } else {
-        if (threadIdx.x >= 64) return false;     // wave-uniform
-        eng.init((int)threadIdx.x);
-        eng.fft %= NF;
+// ------------------------------------------------------------------------------------------------
+// The reference's contract on ALL of its threads: blockDim.x = fft_length / 4, four elements per thread.
+// (Round 2 ran the 16-elements-per-thread engine on the block's first wave and let the other waves wait at the
+// caller's barrier: 0.14-0.55 of the tiled kernels' rate, profiles/r03_reference_contract_before.txt.)
+//
+// Plan: the reference's own radix-2 decimation-in-time ladder (CT:334-532), two stages fused per pass so that a
+// thread's four elements {a, a+P, a+2P, a+3P} make one radix-2^2 butterfly IN PLACE -- no exchange inside a pass, one
+// synchronisation between passes (nothing but a compiler fence while the FFT's N/4 threads share a wave, N <= 256):
+//   pass p (P = 4^p):  k = t mod P, a = (t / P) * 4P + k
+//        (e0, e1) <- (e0 + w1 e1, e0 - w1 e1), (e2, e3) likewise      w1 = W_2P^k  = (W_4P^k)^2
+//        (e0, e2) <- (e0 + w2 e2, e0 - w2 e2)                          w2 = W_4P^k
+//        (e1, e3) <- (e1 + w3 e3, e1 - w3 e3)                          w3 = W_4P^(k+P) = -+i w2
+//   log2 N odd: a last radix-2 pass on (t, t + N/2) and (t + N/4, t + 3N/4) with W_N^t and -+i W_N^t (CT:493-531).
+// Applied to natural-order data that ladder computes DFT(x o bitrev) -- the no-reorder transform S2 -- as it stands.
+// Natural order (S1, Stockham S3/S4): the bit reversal is folded into pass 0, whose twiddles are trivial: thread t loads
+// x[t + m N/4] (m = 0..3), which are the inputs bitrev(4j + i), i = rev2(m), of butterfly j = rev(t), and stores its
+// four results at 4j + i: one scattered store instead of the reference's three-barrier reorder (CT:126-329).
+// One twiddle load per thread and pass, from per-length rows (consecutive threads -> consecutive values).
+// ------------------------------------------------------------------------------------------------
+template <int N>
+struct QuarterTwiddleRows {
+    // row of pass p >= 1 (P = 4^p): W_4P^k, k < P; then, for odd log2 N, the row of the last radix-2 pass: W_N^t, t < N/4
+    static constexpr int kBits = ilog2c(N);
+    static constexpr int kPasses = kBits / 2;                 // fused radix-2^2 passes (pass 0 has no twiddles)
+    static constexpr bool kOdd = (kBits & 1) != 0;
+    static constexpr int row_start(int p) {                   // p = 1 .. kPasses (kPasses = the radix-2 row)
+        int o = 0;
+        for (int q = 1, P = 4; q < p; ++q, P *= 4) o += P;
+        return o;
     }
-    return true;
+    static constexpr int kCount = row_start(kPasses) + (kOdd ? N / 4 : 0);
+    TwiddleValue w[kCount > 0 ? kCount : 1];
+    constexpr QuarterTwiddleRows() : w{} {
+        int P = 4;
+        for (int p = 1; p < kPasses; ++p, P *= 4)
+            for (int k = 0; k < P; ++k) w[row_start(p) + k] = twiddle_values[(k * (4096 / (4 * P))) & 4095];
+        if (kOdd)
+            for (int t = 0; t < N / 4; ++t) w[row_start(kPasses) + t] = twiddle_values[(t * (4096 / N)) & 4095];
+    }
+};
+template <int N>
+static __device__ const QuarterTwiddleRows<N> quarter_twiddle_rows = QuarterTwiddleRows<N>();
+
+// BLOCK_THREADS: threads the caller's block has (what decides between a wave-level fence and a workgroup barrier)
+template <int N, int DIR, int REORDER, int BLOCK_THREADS>
+__device__ __forceinline__ void quarter_fft_inplace(float2* sf, int t) {
+    using R = QuarterTwiddleRows<N>;
+    constexpr int Q = N / 4;
+    constexpr bool kBarrier = BLOCK_THREADS > 64;
+    constexpr int T_BITS = ilog2c(Q);
+    float2 e[4];
+    // ---- pass 0 (P = 1): twiddles 1, 1, -+i -----------------------------------------------------------------------
+    int a;
+    if constexpr (REORDER) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) e[((m & 1) << 1) | (m >> 1)] = sf[t + m * Q];      // e[i] = x[bitrev(4j + i)], i = rev2(m)
+        a = 4 * (int)(T_BITS ? __brev((unsigned)t) >> (32 - (T_BITS ? T_BITS : 1)) : 0);
+        fft_sync<kBarrier>();                                                           // every load precedes the scattered stores
+    } else {
+        a = 4 * t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = sf[a + i];
+    }
+    {
+        const float2 s0 = cadd(e[0], e[1]), d0 = csub(e[0], e[1]), s1 = cadd(e[2], e[3]), d1 = csub(e[2], e[3]);
+        const float2 jd1 = DIR ? make_float2(-d1.y, d1.x) : make_float2(d1.y, -d1.x);   // -+i * d1
+        sf[a + 0] = cadd(s0, s1);
+        sf[a + 2] = csub(s0, s1);
+        sf[a + 1] = cadd(d0, jd1);
+        sf[a + 3] = csub(d0, jd1);
+    }
+    // ---- passes 1 .. (P = 4, 16, ...) -----------------------------------------------------------------------------
+    if constexpr (R::kPasses > 1) {
+        int P = 4;
+#pragma unroll
+        for (int p = 1; p < R::kPasses; ++p, P *= 4) {
+            fft_sync<kBarrier>();
+            const int k = t & (P - 1);
+            const int base = ((t - k) << 2) + k;
+            const TwiddleValue tv = quarter_twiddle_rows<N>.w[R::row_start(p) + k];
+            const float2 w2 = make_float2(tv.x, DIR ? -tv.y : tv.y);
+            const float2 w1 = make_float2(w2.x * w2.x - w2.y * w2.y, 2.f * w2.x * w2.y);
+            float2 x0 = sf[base], x1 = sf[base + P], x2 = sf[base + 2 * P], x3 = sf[base + 3 * P];
+            const float2 t1 = cmul(x1, w1), t3 = cmul(x3, w1);
+            const float2 y0 = cadd(x0, t1), y1 = csub(x0, t1), y2 = cadd(x2, t3), y3 = csub(x2, t3);
+            const float2 u2 = cmul(y2, w2), v3 = cmul(y3, w2);
+            const float2 u3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);  // y3 * w2 * (-+i)
+            sf[base] = cadd(y0, u2);
+            sf[base + 2 * P] = csub(y0, u2);
+            sf[base + P] = cadd(y1, u3);
+            sf[base + 3 * P] = csub(y1, u3);
+        }
+    }
+    // ---- odd log2 N: the last radix-2 stage (span N/2), two butterflies per thread ----------------------------------
+    if constexpr (R::kOdd) {
+        fft_sync<kBarrier>();
+        const TwiddleValue tv = quarter_twiddle_rows<N>.w[R::row_start(R::kPasses) + t];
+        const float2 w = make_float2(tv.x, DIR ? -tv.y : tv.y);
+        const float2 x0 = sf[t], x1 = sf[t + N / 2], x2 = sf[t + Q], x3 = sf[t + 3 * Q];
+        const float2 t1 = cmul(x1, w), v3 = cmul(x3, w);
+        const float2 t3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);
+        sf[t] = cadd(x0, t1);
+        sf[t + N / 2] = csub(x0, t1);
+        sf[t + Q] = cadd(x2, t3);
+        sf[t + 3 * Q] = csub(x2, t3);
+    }
+}
+
+// Hermitian split / merge on the reference's thread shape (L/4 threads, two pairs each: i = t + 1 and t + 1 + L/4, RC:289-328)
+template <int L, int DIR>
+__device__ __forceinline__ void hermitian_pass_quarter(float2* sf, int t) {
+    constexpr float ohx = DIR ? -0.5f : 0.5f;
+    if (DIR && t == 0) {
+        const float2 z = sf[0];
+        sf[0] = make_float2(0.5f * (z.x + z.y), 0.5f * (z.x - z.y));
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = 1 + t + h * (L / 4);
+        const float2 A = sf[i], B = sf[L - i];
+        const float2 W = twiddle<DIR>(i * (4096 / (2 * L)));
+        const float2 Wh = make_float2(ohx * W.x, ohx * W.y);
+        const float2 S = make_float2(A.x + B.x, A.y - B.y);
+        const float2 D = make_float2(A.y + B.y, A.x - B.x);
+        const float2 WH = make_float2(fmaf(Wh.x, D.x, Wh.y * D.y), fmaf(Wh.y, D.x, -Wh.x * D.y));
+        sf[i] = make_float2(fmaf(0.5f, S.x, WH.x), fmaf(0.5f, S.y, WH.y));
+        sf[L - i] = make_float2(fmaf(0.5f, S.x, -WH.x), fmaf(-0.5f, S.y, WH.y));   // i == L/2 (t = L/4 - 1, h = 1): this value stays (RC:308)
+    }
+    if (!DIR && t == 0) {
+        const float2 z = sf[0];
+        sf[0] = make_float2(z.x + z.y, z.x - z.y);
+    }
 }
 
 namespace tiled {
@@ -154,33 +274,38 @@ __device__ void do_FFT_Stockham_R2C_C2R(float2* s_input) {
 template <class const_params>
 __device__ void do_SMFFT_CT_DIT(float2* s_input) {
     constexpr int N = const_params::fft_size;
-    smfft::Engine<N, const_params::fft_direction, const_params::fft_reorder> eng;
-    if (!smfft::reference_shape_init<N, const_params::fft_direction, const_params::fft_reorder, true, const_params::fft_length / N>(eng)) return;
-    smfft::fft_lds_inplace(s_input, eng, N);
+    constexpr int kBlock = const_params::fft_length / 4;                 // 32 threads hold 128 / N transforms for N <= 128 (CT:586-595)
+    const int f = threadIdx.x / (N / 4), t = threadIdx.x % (N / 4);
+    smfft::quarter_fft_inplace<N, const_params::fft_direction, const_params::fft_reorder, kBlock>(s_input + f * N, t);
 }
 
 template <class const_params>
 __device__ void do_FFT_Stockham_mk6(float2* s_input) {
     constexpr int N = const_params::fft_length;
-    smfft::Engine<N, 1, 1, false> eng;
-    if (smfft::reference_shape_init<N, 1, 1, false, 1>(eng)) smfft::fft_lds_inplace(s_input, eng, N);
+    smfft::quarter_fft_inplace<N, 1, 1, N / 4>(s_input, threadIdx.x);
     __syncthreads();   // upstream's function ends with a barrier (ST:239) and its kernels store right after the call (ST:253)
 }
 
 template <class const_params, class const_direction>
 __device__ void do_FFT_Stockham_C2C(float2* s_input) {
     constexpr int N = const_params::fft_length;
-    smfft::Engine<N, const_direction::fft_direction, 1, false> eng;
-    if (smfft::reference_shape_init<N, const_direction::fft_direction, 1, false, 1>(eng)) smfft::fft_lds_inplace(s_input, eng, N);
+    smfft::quarter_fft_inplace<N, const_direction::fft_direction, 1, N / 4>(s_input, threadIdx.x);
     __syncthreads();   // upstream's function ends with a barrier (RC:265) and its callers rely on it (RC:360-361)
 }
 
 template <class const_params, class const_direction>
 __device__ void do_FFT_Stockham_R2C_C2R(float2* s_input) {
     constexpr int L = const_params::fft_length;
-    smfft::Engine<L, const_direction::fft_direction, 1, false> eng;
-    if (smfft::reference_shape_init<L, const_direction::fft_direction, 1, false, 1>(eng))
-        smfft::r2c_c2r_lds_inplace<L, const_direction::fft_direction, false>(s_input, eng, L, threadIdx.x < L / 16);
+    constexpr int D = const_direction::fft_direction;
+    if (D == 0) {
+        smfft::quarter_fft_inplace<L, 0, 1, L / 4>(s_input, threadIdx.x);
+        __syncthreads();
+        smfft::hermitian_pass_quarter<L, 0>(s_input, threadIdx.x);
+    } else {
+        smfft::hermitian_pass_quarter<L, 1>(s_input, threadIdx.x);
+        __syncthreads();
+        smfft::quarter_fft_inplace<L, 1, 1, L / 4>(s_input, threadIdx.x);
+    }
     __syncthreads();   // as upstream: the forward branch ends behind a barrier (RC:330), the inverse one in do_FFT_Stockham_C2C
 }
 

@@ -76,10 +76,12 @@ template <int N, int REORDER>
 constexpr int row_residue(RowKind kind, int j) {
     switch (kind) {
         case RowKind::image:    // read by the bit-reversed loads of the no-reorder variants (lane linear in the reorder variants)
-            return N == 128 ? bit_of(j, 2) + 8 * bit_of(j, 3) : N == 256 ? j : N == 512 ? bit_of(j, 0) + 2 * bit_of(j, 2) + 8 * bit_of(j, 3) : N == 4096 ? 2 * bit_of(j, 3) : (j >> 2);
+            return N == 32 ? 8 * bit_of(j, 3) : N == 64 ? 4 * (j >> 2) : N == 128 ? bit_of(j, 2) + 8 * bit_of(j, 3) : N == 256 ? j : N == 512 ? bit_of(j, 0) + 2 * bit_of(j, 2) + 8 * bit_of(j, 3) : N == 4096 ? 2 * bit_of(j, 3) : (j >> 2);
         case RowKind::x1:       // after pass 1 (three-pass lengths)
             return N == 2048 ? bit_of(j, 1) : N == 4096 ? bit_of(j, 0) : 0;      // (N = 512 exchanges in registers)
         default:                // in front of the last pass
+            if (N == 32) return 8 * bit_of(j, 0);
+            if (N == 64) return 4 * (j & 3);
             if (N == 128) return bit_of(j, 0) + 8 * bit_of(j, 1);
             if (N == 256) return (j & 3) + 8 * bit_of(j, 3);
             if (REORDER && N != 512) return (j & 3) + 8 * bit_of(j, 3);           // klow = pass-1 role
@@ -134,7 +136,6 @@ struct PlanarEngine {
     using P = PlanarGeometry<N, REORDER>;
     static constexpr int T = G::T, RM = G::RM, BM = G::BM, R1 = G::R1, B1 = G::B1, TW = P::TW;
     static constexpr int T_BITS = ilog2c(T), R1_BITS = ilog2c(R1), B1_BITS = ilog2c(B1), RM_BITS = ilog2c(RM);
-    static_assert(N >= 128, "N = 32 / 64 keep the register engine");
     static constexpr bool kThreePass = RM > 1;
     // N = 512 (RM = 2): exchange 1 moves data between two threads only -- sixteen v_permlane16_swap (Engine::exchange1_registers)
     // measured faster than a third trip through LDS (profiles/r03_ab_planar_all.txt); its roles are the register engine's (t1 = v)

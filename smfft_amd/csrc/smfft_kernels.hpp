@@ -283,7 +283,7 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_i
 #define SMFFT_PLANAR 1          // 0: the float2-image engine for every length (A/B)
 #endif
 #ifndef SMFFT_PLANAR_MIN_N
-#define SMFFT_PLANAR_MIN_N 128  // N = 32 / 64 (an FFT is 2 / 4 lanes) keep the register engine and its float2 image
+#define SMFFT_PLANAR_MIN_N 64   // N = 32 keeps the register engine and its float2 image (planar: -10 %, profiles/r03_ab_planar_small.txt)
 #endif
 #define SMFFT_PLANAR_SIZES(N) (SMFFT_PLANAR && (N) >= SMFFT_PLANAR_MIN_N)
 template <int N, int DIR, int REORDER>
