@@ -1,6 +1,6 @@
 // FFT_multi_gpu.c -- config 5 of BASELINE.json at the C level: a batch of N-point C2C FFTs sharded
 // across the GPUs of one node.  Usage:
-//     FFT_multi_gpu.exe <FFT length> <FFTs per GPU> <nRuns> <inverse 0|1> <reorder 0|1> [nGPUs] [exchange 0|1]
+//     FFT_multi_gpu.exe <FFT length> <FFTs per GPU> <nRuns> <inverse 0|1> <reorder 0|1> [nGPUs] [exchange 0|1] [virtual shards G]
 //
 // The path shards embarrassingly: GPU g owns the contiguous slab
 // [g*B, (g+1)*B) of the batch, generates it on its own host thread, uploads it, and runs the
@@ -14,7 +14,14 @@
 // xGMI link takes ~28 ms against 1.4 ms of compute), the two optional payload movements of a single-buffer
 // workflow: an ncclAllGather of the output slabs into one buffer on every GPU, and a scatter of that buffer's
 // slabs from GPU 0 back to their owners with a grouped ncclSend / ncclRecv; both are verified bit for bit
-// against the GPU's own output.
+// against the GPU's own output.  With exchange = 1 the slabs live in plain hipMalloc memory: the allocator's built outputs are
+// virtual-memory ranges with access granted to their own device only, which RCCL's peer-to-peer paths need not accept.
+//
+// virtual shards G > 0 ("test without 8 GPUs"): the second argument is then the TOTAL batch, which is cut
+// into G contiguous slabs exactly as the real run cuts it over G GPUs -- ragged if G does not divide it: the first
+// (total mod G) slabs hold one FFT more -- and the slabs are transformed one after the other on device 0; the per-slab
+// statistics are reduced on the host the way the all-reduce does (MAX of the times, SUM of the errors) and the concatenated
+// output is compared bit for bit with ONE launch over the whole batch.
 #include "harness_common.h"
 #include <pthread.h>
 #include <rccl/rccl.h>
@@ -24,6 +31,8 @@ void FFT_init();
 // the library's placement-aware allocator (include/smfft.h): input and output in different memory regions
 extern "C" int smfft_malloc_pair(unsigned long long bytes, void **d_read, void **d_written);
 extern "C" int smfft_free_pair(void *d_read);
+extern "C" void *smfft_malloc(unsigned long long bytes);
+extern "C" int smfft_free(void *d_ptr);
 
 typedef struct {
 	int gpu, nGPUs, FFT_size, nFFTs, nRuns;
@@ -54,7 +63,11 @@ static void *worker(void *arg) {
 	if (ok) {
 		h_in = (float2 *) malloc(bytes);
 		h_out = (float2 *) malloc(bytes);
-		ok = h_in && h_out && smfft_malloc_pair(bytes, (void **) &d_in, (void **) &d_out) == 0
+		if (w->exchange) {   // buffers that go into collectives: plain allocations (see the header comment)
+			d_in = (float2 *) smfft_malloc(bytes);
+			d_out = (float2 *) smfft_malloc(bytes);
+		}
+		ok = h_in && h_out && (w->exchange ? (d_in && d_out) : smfft_malloc_pair(bytes, (void **) &d_in, (void **) &d_out) == 0)
 		     && hipMalloc((void **) &d_stats, 4*sizeof(float)) == hipSuccess && hipStreamCreate(&stream) == hipSuccess;
 		if (ok && w->exchange)
 			ok = hipMalloc((void **) &d_all, bytes*w->nGPUs) == hipSuccess && hipMalloc((void **) &d_back, bytes) == hipSuccess
@@ -145,7 +158,8 @@ static void *worker(void *arg) {
 	}
 
 	// every path releases what it got
-	if (d_in) (void) smfft_free_pair(d_in);
+	if (w->exchange) { if (d_in) (void) smfft_free(d_in); if (d_out) (void) smfft_free(d_out); }
+	else if (d_in) (void) smfft_free_pair(d_in);
 	if (d_stats) (void) hipFree(d_stats);
 	if (d_all) (void) hipFree(d_all);
 	if (d_back) (void) hipFree(d_back);
@@ -158,9 +172,50 @@ static void *worker(void *arg) {
 	return NULL;
 }
 
+// contiguous, balanced split (smfft_amd/sharding.py shard_range): the first total % G slabs get one FFT more
+static void shard_range(long total, int g, int G, long *first, long *count) {
+	const long base = total/G, extra = total % G;
+	*first = g*base + (g < extra ? g : extra);
+	*count = base + (g < extra ? 1 : 0);
+}
+
+static int run_virtual_shards(int FFT_size, long total, int nRuns, bool inverse, bool reorder, int G) {
+	const size_t count = (size_t) FFT_size*total, bytes = count*sizeof(float2);
+	float2 *h_in = (float2 *) malloc(bytes), *h_whole = (float2 *) malloc(bytes), *h_cat = (float2 *) malloc(bytes);
+	float2 *d_in = (float2 *) smfft_malloc(bytes), *d_whole = (float2 *) smfft_malloc(bytes), *d_cat = (float2 *) smfft_malloc(bytes);
+	if (!h_in || !h_whole || !h_cat || !d_in || !d_whole || !d_cat) { printf("allocation failed\n"); return 1; }
+	for (size_t i = 0; i < 2*count; i++) ((float *) h_in)[i] = harness_uniform((unsigned long long) i);
+	bool ok = hipMemcpy(d_in, h_in, bytes, hipMemcpyHostToDevice) == hipSuccess && hipMemset(d_cat, 0xFF, bytes) == hipSuccess;
+	FFT_init();
+	double whole_ms = 0, job_ms = 0, errors = 0;
+	FFT_external_benchmark(d_in, d_whole, FFT_size, (int) total, inverse, reorder, &whole_ms);
+	long covered = 0;
+	for (int g = 0; g < G && ok; g++) {
+		long first, n;
+		shard_range(total, g, G, &first, &n);
+		if (first != covered) { printf("shard %d does not start where shard %d ended\n", g, g - 1); errors += 1; }
+		covered = first + n;
+		double ms = 0;
+		if (n > 0) for (int r = 0; r < nRuns; r++) FFT_external_benchmark(d_in + (size_t) first*FFT_size, d_cat + (size_t) first*FFT_size, FFT_size, (int) n, inverse, reorder, &ms);
+		ms /= (nRuns > 0 ? nRuns : 1);
+		printf("  shard %d of %d: FFTs [%ld, %ld): SH FFT normal = %0.4f ms\n", g, G, first, first + n, ms);
+		if (ms > job_ms) job_ms = ms;            // what ncclAllReduce(MAX) leaves on every rank
+	}
+	if (covered != total) { printf("the shards cover %ld of %ld FFTs\n", covered, total); errors += 1; }
+	ok = ok && hipMemcpy(h_whole, d_whole, bytes, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(h_cat, d_cat, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+	const bool identical = ok && memcmp(h_whole, h_cat, bytes) == 0;
+	if (!identical) errors += 1;
+	printf("  %d virtual shard(s) on device 0, %ld FFTs of %d: job time (MAX over shards) = %0.4f ms; one launch over the whole batch = %0.4f ms\n", G, total, FFT_size, job_ms, whole_ms);
+	printf("  concatenated shard outputs vs one launch over the whole batch: %s\n", identical ? "bit-identical" : "DIFFERENT");
+	smfft_free(d_in); smfft_free(d_whole); smfft_free(d_cat);
+	free(h_in); free(h_whole); free(h_cat);
+	print_verdict((int) errors);
+	return ok && errors == 0 ? 0 : 1;
+}
+
 int main(int argc, char *argv[]) {
-	if (argc < 6 || argc > 8) {
-		printf("Argument error!\n 1) FFT length\n 2) number of FFTs per GPU\n 3) the number of kernel executions\n 4) do inverse FFT 1=yes 0=no\n 5) reorder 1=yes 0=no\n 6) [number of GPUs, default (or 0) all]\n 7) [exchange 1 = also time an all-gather of the outputs and a scatter from GPU 0]\n");
+	if (argc < 6 || argc > 9) {
+		printf("Argument error!\n 1) FFT length\n 2) number of FFTs per GPU\n 3) the number of kernel executions\n 4) do inverse FFT 1=yes 0=no\n 5) reorder 1=yes 0=no\n 6) [number of GPUs, default (or 0) all]\n 7) [exchange 1 = also time an all-gather of the outputs and a scatter from GPU 0]\n 8) [virtual shards G: argument 2 is the TOTAL batch, cut into G slabs run one after the other on device 0]\n");
 		printf("For example: FFT_multi_gpu.exe 1024 524288 20 0 1\n");
 		return 1;
 	}
@@ -169,9 +224,13 @@ int main(int argc, char *argv[]) {
 	int devCount = 0;
 	if (hipGetDeviceCount(&devCount) != hipSuccess || devCount < 1) { printf("No HIP device.\n"); return 1; }
 	int nGPUs = (argc >= 7) ? (int) strtol(argv[6], NULL, 10) : devCount;
-	const bool exchange = (argc == 8) && strtol(argv[7], NULL, 10) == 1;
+	const bool exchange = (argc >= 8) && strtol(argv[7], NULL, 10) == 1;
 	if (nGPUs < 1 || nGPUs > devCount) nGPUs = devCount;
 	harness_seed_value = getenv("SMFFT_SEED") ? strtoull(getenv("SMFFT_SEED"), NULL, 10) : 20200720ull;
+	if (argc == 9 && strtol(argv[8], NULL, 10) > 0) {
+		if (hipSetDevice(0) != hipSuccess) { printf("No HIP device.\n"); return 1; }
+		return run_virtual_shards(FFT_size, nFFTs, nRuns, inverse, reorder, (int) strtol(argv[8], NULL, 10));
+	}
 
 	ncclComm_t *comms = (ncclComm_t *) malloc(nGPUs*sizeof(ncclComm_t));
 	int *devs = (int *) malloc(nGPUs*sizeof(int));

@@ -158,19 +158,29 @@ int smfft_malloc_written_for(const void* d_read, unsigned long long bytes, void*
 int smfft_free_written(void* d_written);
 /* gives back the pair SMFFT_PAIR_CACHE=1 keeps */
 int smfft_pair_cache_release(void);
+/* the pair the L3 wrappers (and the harness's hipFFT comparator) take: as smfft_malloc_pair unless SMFFT_WRAPPER_PLACEMENT=0
+   (two plain allocations, as upstream), and the pair released last is kept for the next wrapper call of the same size */
+int smfft_malloc_pair_for_wrapper(unsigned long long bytes, void** d_read, void** d_written);
 /* what the last smfft_malloc_pair of this process did (telemetry for bench.py and the tests) */
 typedef struct SmfftPairInfo {
     unsigned long long bytes;            /* size of each buffer */
     unsigned long long candidate_bytes;  /* physical memory the scan held at its end (<= max(byte budget + 1 GiB, bytes)) */
     int candidates;                      /* mixed policy: GiB chunks scanned (+1 if a remainder was created unprobed); candidates policy: blocks probed; 0: plain */
     int chosen;                          /* mixed policy: GiB of mixed memory in the output; candidates policy: index of the block kept */
-    int good_enough;                     /* 1: the output is all mixed or interleaved memory (mixed) / met the 2.3 x read-time criterion (candidates) */
+    int good_enough;                     /* 1: a pass into the output beats the same pass into ordinary memory measured in the same scan by the margin mixed memory shows on this device */
     float read_ms, copy_ms, first_copy_ms;   /* over min(bytes, 1 GiB): pure read of the input; copy into the output; copy into the first chunk / block seen */
     double search_ms;
     unsigned long long mixed_bytes;        /* mixed policy: bytes of the output that are mixed memory ... */
     unsigned long long interleaved_bytes;  /* ... and bytes that are ordinary memory of two classes interleaved in 8 MiB handles */
+    float first_ordinary_copy_ms;        /* over min(bytes, 1 GiB): copy into the first clearly ordinary chunk of the scan (the yardstick of good_enough) */
+    int classification;                  /* 1: the scan's write times split into a fast (mixed) and a slow (ordinary) cluster; 0: inconclusive -- nothing was called mixed */
 } SmfftPairInfo;
 int smfft_last_pair_info(SmfftPairInfo* out);
+/* the window of virtual addresses the allocator has handed out and retired so far: [*first, *next); returns the number of
+   retired ranges it holds re-reserved (never mapped), so that no other reservation of the process can land in them */
+int smfft_va_window(unsigned long long* first, unsigned long long* next);
+/* K >= 0: the external kernels of THIS host thread run their rate limiter with K loads whatever the output buffer; < 0: automatic */
+void smfft_set_pacing(int k);
 int smfft_free(void* d_ptr);
 int smfft_memcpy_h2d(void* d_dst, const void* h_src, unsigned long long bytes);
 int smfft_memcpy_d2h(void* h_dst, const void* d_src, unsigned long long bytes);

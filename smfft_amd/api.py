@@ -47,12 +47,15 @@ _SIGS = {
     "smfft_set_grid_cap": (None, [_i]),
     "smfft_get_grid_cap": (_i, []),
     "smfft_set_nreuses": (None, [_i]),
+    "smfft_set_pacing": (None, [_i]),
+    "smfft_va_window": (_i, [ctypes.POINTER(_ull), ctypes.POINTER(_ull)]),
     "smfft_get_nreuses": (_i, []),
     "smfft_device_count": (_i, []),
     "smfft_set_device": (_i, [_i]),
     "smfft_version": (ctypes.c_char_p, []),
     "smfft_malloc": (_vp, [_ull]),
     "smfft_malloc_pair": (_i, [_ull, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    "smfft_malloc_pair_for_wrapper": (_i, [_ull, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "smfft_malloc_pair_budget": (_i, [_ull, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_double, ctypes.c_double]),
     "smfft_free_pair": (_i, [_vp]),
     "smfft_malloc_written": (_i, [_ull, ctypes.POINTER(_vp)]),
@@ -99,7 +102,8 @@ class SmfftPairInfo(ctypes.Structure):
     """mirror of include/smfft.h SmfftPairInfo"""
     _fields_ = [("bytes", ctypes.c_ulonglong), ("candidate_bytes", ctypes.c_ulonglong), ("candidates", ctypes.c_int), ("chosen", ctypes.c_int),
                 ("good_enough", ctypes.c_int), ("read_ms", ctypes.c_float), ("copy_ms", ctypes.c_float), ("first_copy_ms", ctypes.c_float),
-                ("search_ms", ctypes.c_double), ("mixed_bytes", ctypes.c_ulonglong), ("interleaved_bytes", ctypes.c_ulonglong)]
+                ("search_ms", ctypes.c_double), ("mixed_bytes", ctypes.c_ulonglong), ("interleaved_bytes", ctypes.c_ulonglong),
+                ("first_ordinary_copy_ms", ctypes.c_float), ("classification", ctypes.c_int)]
 
 
 def last_pair_info():

@@ -9,7 +9,10 @@
 #include <cstring>
 #include <algorithm>
 #include <chrono>
+#include <atomic>
+#include <climits>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <set>
 #include <string>
@@ -19,23 +22,33 @@
 #include "../../include/smfft_reference_api.h"
 #include "smfft_host_util.hpp"
 #include "smfft_launch.hpp"
+#include "smfft_state.hpp"
 
 namespace {
 
-int g_device = 0;       // the reference's global `int device = 0` (CT:15)
-int g_grid_cap = 12288; // workgroups per launch (grid-stride over tiles; 12288 = 12 or 16 rounds of the 4 or 3
-                        // resident workgroups per CU; measured sweet spot); <= 0: one per tile
-int g_nreuses = SMFFT_NREUSES;  // applications per slot in the `multiple` kernels (tests lower it)
+// Launch state.  Upstream has process globals (`int device = 0`, CT:15) and one host thread.  Here every host thread has
+// its own device / grid cap / applications-per-slot / pacing, so that N threads can drive N GPUs through the unchanged
+// prototypes (GPU_smFFT_4elements and friends included); a value a thread has not set falls back to the process default
+// (environment: SMFFT_DEVICE, SMFFT_GRID_CAP, SMFFT_PACING, read once).  The lanes of smfft_host_transform inherit the
+// state of the thread that called it (smfft_state.hpp).
+smfft::LaunchState g_defaults = {0, 12288, SMFFT_NREUSES, -1};   // 12288 workgroups per launch: grid-stride over tiles, 12 or 16
+                                                                 // rounds of the 4 or 3 resident workgroups per CU (measured sweet spot)
+thread_local smfft::LaunchState t_state = {-1, smfft::kUnsetGridCap, 0, -2};
 std::once_flag g_env_once;
 
 // launches may come from several host threads (per-GPU threads of a multi-GPU driver, the lanes of
 // smfft_host_transform): the environment is read exactly once
 void read_env() {
     std::call_once(g_env_once, [] {
-        if (const char* e = getenv("SMFFT_GRID_CAP")) g_grid_cap = atoi(e);
-        if (const char* e = getenv("SMFFT_DEVICE")) g_device = atoi(e);
+        if (const char* e = getenv("SMFFT_GRID_CAP")) g_defaults.grid_cap = atoi(e);
+        if (const char* e = getenv("SMFFT_DEVICE")) g_defaults.device = atoi(e);
+        if (const char* e = getenv("SMFFT_PACING")) g_defaults.pacing = atoi(e) > 0 ? atoi(e) : 0;
     });
 }
+int cur_device() { return t_state.device >= 0 ? t_state.device : g_defaults.device; }
+int cur_grid_cap() { return t_state.grid_cap != smfft::kUnsetGridCap ? t_state.grid_cap : g_defaults.grid_cap; }
+int cur_nreuses() { return t_state.nreuses > 0 ? t_state.nreuses : g_defaults.nreuses; }
+int cur_pacing() { return t_state.pacing != -2 ? t_state.pacing : g_defaults.pacing; }   // -1: chosen per launch from the output buffer
 
 // count of FFT slots the `multiple` path touches (CT:669-683; ST:351; RC:438)
 int ct_multiple_slots(int FFT_size, int nFFTs) {
@@ -61,28 +74,28 @@ using smfft::launch_st;
 int dispatch_ct(const float2* in, float2* out, int N, int count, int inverse, int reorder, int path, hipStream_t st) {
     const int pace = pacing_for(out, c2c_pacing(N).ordinary, c2c_pacing(N).mixed);
     switch (N) {
-        case 32:   return launch_ct<32>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, pace, st);
-        case 64:   return launch_ct<64>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, pace, st);
-        case 128:  return launch_ct<128>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, pace, st);
-        case 256:  return launch_ct<256>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, pace, st);
-        case 512:  return launch_ct<512>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, pace, st);
-        case 1024: return launch_ct<1024>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, pace, st);
-        case 2048: return launch_ct<2048>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, pace, st);
-        case 4096: return launch_ct<4096>(in, out, count, inverse, reorder, path, g_grid_cap, g_nreuses, pace, st);
+        case 32:   return launch_ct<32>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 64:   return launch_ct<64>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 128:  return launch_ct<128>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 256:  return launch_ct<256>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 512:  return launch_ct<512>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 1024: return launch_ct<1024>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 2048: return launch_ct<2048>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 4096: return launch_ct<4096>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, st);
         default:   return -1;
     }
 }
 int dispatch_st(const float2* in, float2* out, int N, int count, int path, hipStream_t st) {
     const int pace = pacing_for(out, c2c_pacing(N).ordinary, c2c_pacing(N).mixed);
     switch (N) {
-        case 32:   return launch_st<32>(in, out, count, path, g_grid_cap, g_nreuses, pace, st);
-        case 64:   return launch_st<64>(in, out, count, path, g_grid_cap, g_nreuses, pace, st);
-        case 128:  return launch_st<128>(in, out, count, path, g_grid_cap, g_nreuses, pace, st);
-        case 256:  return launch_st<256>(in, out, count, path, g_grid_cap, g_nreuses, pace, st);
-        case 512:  return launch_st<512>(in, out, count, path, g_grid_cap, g_nreuses, pace, st);
-        case 1024: return launch_st<1024>(in, out, count, path, g_grid_cap, g_nreuses, pace, st);
-        case 2048: return launch_st<2048>(in, out, count, path, g_grid_cap, g_nreuses, pace, st);
-        case 4096: return launch_st<4096>(in, out, count, path, g_grid_cap, g_nreuses, pace, st);
+        case 32:   return launch_st<32>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 64:   return launch_st<64>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 128:  return launch_st<128>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 256:  return launch_st<256>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 512:  return launch_st<512>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 1024: return launch_st<1024>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 2048: return launch_st<2048>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 4096: return launch_st<4096>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, st);
         default:   return -1;
     }
 }
@@ -90,10 +103,10 @@ int dispatch_st(const float2* in, float2* out, int N, int count, int path, hipSt
 int dispatch_rc(const float2* in, float2* out, int FFT_size, int count, int inverse, int path, hipStream_t st) {
     const int pace = pacing_for(out, rc_pacing(FFT_size / 2).ordinary, rc_pacing(FFT_size / 2).mixed);
     switch (FFT_size) {
-        case 512:  return launch_rc<256>(in, out, count, inverse, path, g_grid_cap, g_nreuses, pace, st);
-        case 1024: return launch_rc<512>(in, out, count, inverse, path, g_grid_cap, g_nreuses, pace, st);
-        case 2048: return launch_rc<1024>(in, out, count, inverse, path, g_grid_cap, g_nreuses, pace, st);
-        case 4096: return launch_rc<2048>(in, out, count, inverse, path, g_grid_cap, g_nreuses, pace, st);
+        case 512:  return launch_rc<256>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 1024: return launch_rc<512>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 2048: return launch_rc<1024>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 4096: return launch_rc<2048>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, st);
         default:   return -1;
     }
 }
@@ -152,30 +165,77 @@ struct PairRec {
     std::vector<hipMemGenericAllocationHandle_t> handles;   // b is a virtual range backed by these (mixed policy)
     size_t va_bytes = 0;
     bool mixed = false;       // at least half of b is mixed memory
+    bool from_wrapper = false;   // taken by an L3 wrapper / the harness's comparator: kept for the next one when released
 };
 std::map<void*, PairRec> g_pairs;      // keyed by the read buffer; grows as needed
-PairRec g_pair_cache;                  // SMFFT_PAIR_CACHE=1 only: the last searched pair that was released
+PairRec g_pair_cache;                  // the last searched pair that was released: the wrappers' pairs, everybody's with SMFFT_PAIR_CACHE=1
 std::mutex g_pairs_mutex;              // shared by the per-GPU host threads of a multi-GPU driver
 SmfftPairInfo g_last_pair_info = {};
 
 // Pacing per launch (smfft_kernels.hpp, vmem_throttle): K serialised loads between a wave's loads and its stores.  Into
 // ordinary memory the paced kernels are 2-8 % faster, most when input and output lie in different memory classes (K = 12 for N <= 1024, 8 above; R2C / C2R of real N = 1024 / 2048:
 // 6 / 8), into the mixed outputs smfft_malloc_pair builds a light K = 4 is worth 0.3-1.6 % and more costs
-// (profiles/r02_pacing_sweep_*.txt).  SMFFT_PACING=K forces K loads for every length (0: off); the variable is read at
-// every launch so that one process can sweep it.
+// (profiles/r02_pacing_sweep_*.txt).
+// The lookup runs at every launch: it reads an immutable snapshot of the built outputs' address ranges (sorted by start;
+// republished under g_pairs_mutex whenever a pair is built or freed) and takes no lock (nFFTs = 4 launch latency before /
+// after: profiles/r03_launch_latency.txt).  smfft_set_pacing(K) / SMFFT_PACING=K (read once) force K loads for every length.
+struct OutRange { uintptr_t lo, hi; bool mixed; };
+std::shared_ptr<const std::vector<OutRange>> g_out_ranges = std::make_shared<const std::vector<OutRange>>();
+void publish_out_ranges_locked() {          // caller holds g_pairs_mutex
+    auto v = std::make_shared<std::vector<OutRange>>();
+    for (auto& kv : g_pairs)
+        if (kv.second.va_bytes) v->push_back({(uintptr_t)kv.second.b, (uintptr_t)kv.second.b + kv.second.va_bytes, kv.second.mixed});
+    std::sort(v->begin(), v->end(), [](const OutRange& x, const OutRange& y) { return x.lo < y.lo; });
+    std::atomic_store(&g_out_ranges, std::shared_ptr<const std::vector<OutRange>>(v));
+}
 int pacing_for(const void* d_output, int k_ordinary, int k_mixed) {
-    if (const char* e = getenv("SMFFT_PACING")) return atoi(e) > 0 ? atoi(e) : 0;
-    std::lock_guard<std::mutex> lock(g_pairs_mutex);
-    for (auto& kv : g_pairs) {
-        const PairRec& r = kv.second;
-        if (r.va_bytes && (const char*)d_output >= (const char*)r.b && (const char*)d_output < (const char*)r.b + r.va_bytes) return r.mixed ? k_mixed : k_ordinary;
-    }
+    const int forced = cur_pacing();
+    if (forced >= 0) return forced;
+    const auto ranges = std::atomic_load(&g_out_ranges);
+    const uintptr_t p = (uintptr_t)d_output;
+    auto it = std::upper_bound(ranges->begin(), ranges->end(), p, [](uintptr_t v, const OutRange& r) { return v < r.lo; });
+    if (it != ranges->begin() && p < (it - 1)->hi) return (it - 1)->mixed ? k_mixed : k_ordinary;
     return k_ordinary;
 }
 
-constexpr double kGoodRatio = 2.22;    // a good write target: copy of the whole pair within 2.22 x the input's own read time (mixed / interleaved 2.18-2.24; other class 2.5; same class 2.6)
-constexpr float kMixedWriteRatio = 0.91f;   // mixed policy: a chunk is mixed if its write pass takes < 0.91 x the typical one (mixed: 0.79-0.88)
-constexpr float kOrdinaryWriteRatio = 0.96f;   // ... and clearly ordinary above 0.96 x (ordinary chunks scatter by +-3 %)
+// What counts as "mixed", "clearly ordinary" and "a good write target" is read off the scan's OWN measurements (round 2 had
+// three constants tuned on this pool: 0.91, 0.96, 2.22):
+//  * the write times of the scanned chunks are split into a fast and a slow cluster at the widest gap of their sorted
+//    values (split_write_times); the split is accepted when that gap is at least 4 % of the slow cluster's median and at
+//    least three times the slow cluster's own spread -- ordinary chunks scatter by +-1.5 %, mixed ones sit 12-20 % lower.
+//    A chunk is mixed below the gap, clearly ordinary inside the slow cluster's spread, and in between neither;
+//  * without an accepted split (too few chunks, or no mixed memory in what was scanned) nothing is called mixed, and a
+//    chunk is clearly ordinary within +-3 % of the median; SmfftPairInfo.classification says which case it was;
+//  * a candidate output is good when a pass into it beats the same pass into ORDINARY memory measured in this scan (the
+//    first clearly ordinary chunk) by the margin mixed memory shows against ordinary memory on this device -- half-way
+//    between the two cluster medians -- or, without a split, by 7 %.
+struct WriteSplit { bool accepted = false; float mixed_below = 0.f, ordinary_above = 0.f, fast_median = 0.f, slow_median = 0.f; };
+WriteSplit split_write_times(std::vector<float> t) {
+    WriteSplit w;
+    std::sort(t.begin(), t.end());
+    if (t.empty()) return w;
+    w.slow_median = t[t.size() / 2];
+    w.ordinary_above = 0.97f * w.slow_median;
+    if (t.size() < 4) return w;
+    size_t cut = 0;
+    float gap = 0.f;
+    for (size_t i = 1; i < t.size(); ++i)
+        if (t[i] - t[i - 1] > gap) { gap = t[i] - t[i - 1]; cut = i; }
+    if (cut == 0) return w;
+    const float slow_med = t[cut + (t.size() - cut) / 2], fast_med = t[cut / 2];
+    const float slow_spread = t.back() - t[cut];
+    // the slow cluster must be the majority (six chunks in seven are ordinary) for its median to mean "ordinary"
+    if (t.size() - cut < cut || gap < 0.04f * slow_med || gap < 3.f * slow_spread / std::max<size_t>(1, t.size() - cut - 1) * 1.0f) {
+        w.slow_median = t[t.size() / 2];
+        return w;
+    }
+    w.accepted = true;
+    w.slow_median = slow_med;
+    w.fast_median = fast_med;
+    w.mixed_below = t[cut - 1] + 0.5f * gap;
+    w.ordinary_above = t[cut] - 0.25f * gap;
+    return w;
+}
 #ifndef SMFFT_PAIR_HANDLE_MIB
 #define SMFFT_PAIR_HANDLE_MIB 8
 #endif
@@ -222,8 +282,14 @@ double env_double(const char* name, double dflt) {
 // Addresses are handed out upwards from a base far below the runtime's own region (hints are honoured); a reservation that
 // comes back below the high-water mark is refused.  Every 4 GiB pair consumes 50-100 GiB of address space for good, so a
 // process can build one to two thousand of them; after that the allocator falls back to plain allocations.
+// A retired range must never be handed to anybody else either (a hint-less reservation of another component -- PyTorch's
+// expandable segments, RCCL -- that landed in it would map new memory at an address the GPU still translates to old pages):
+// right after the range has been freed (which is what returns the physical memory) the SAME address range is reserved again
+// and never mapped -- a tombstone.  It costs address space only, which was spent anyway.
 std::mutex g_va_mutex;
-uintptr_t g_va_next = 0x100000000000ull;            // 16 TiB: next address to ask for
+constexpr uintptr_t kVaBase = 0x100000000000ull;    // 16 TiB
+uintptr_t g_va_next = kVaBase;                      // next address to ask for
+size_t g_tombstones = 0, g_tombstones_missed = 0;
 constexpr uintptr_t kVaLimit = 0x700000000000ull;   // 112 TiB: stay below the region the runtime itself allocates from
 char* arena_take(size_t bytes) {
     const size_t align = 1ull << 30;
@@ -240,7 +306,17 @@ char* arena_take(size_t bytes) {
 }
 void arena_give_back(char* p, size_t bytes) {
     const size_t align = 1ull << 30;
-    if (p) (void)hipMemAddressFree(p, (bytes + align - 1) / align * align);
+    if (!p) return;
+    bytes = (bytes + align - 1) / align * align;
+    std::lock_guard<std::mutex> lock(g_va_mutex);
+    (void)hipMemAddressFree(p, bytes);
+    void* q = nullptr;
+    if (hipMemAddressReserve(&q, bytes, align, p, 0) == hipSuccess && q == (void*)p) { ++g_tombstones; return; }
+    (void)hipGetLastError();
+    if (q) (void)hipMemAddressFree(q, bytes);
+    ++g_tombstones_missed;
+    static bool warned = false;
+    if (!warned) { warned = true; fprintf(stderr, "smfft: could not re-reserve a retired address range at %p (%zu bytes); it is left unprotected\n", (void*)p, bytes); }
 }
 
 void release_output(PairRec& rec) {
@@ -299,17 +375,24 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
     // at the start of the scan is recognised as such
     // (no input buffer -- smfft_malloc_written: the median alone)
     const float in_write_ms = !(in && in_is_fresh) ? 0.f : probe_ms(nullptr, const_cast<void*>(in), bytes < kChunkBytes ? bytes : kChunkBytes, 3) * (float)((double)kChunkBytes / (double)(bytes < kChunkBytes ? bytes : kChunkBytes));
-    auto typical = [&] {
+    auto split = [&] {
         std::vector<float> t;
         for (auto& c : chunks) if (c.write_ms < 1e29f) t.push_back(c.write_ms);
-        std::sort(t.begin(), t.end());
-        const float med = t.empty() ? 0.f : (t.size() < 3 ? t.back() : t[t.size() / 2]);
-        return med > in_write_ms ? med : in_write_ms;
+        WriteSplit w = split_write_times(t);
+        // a run of mixed chunks at the start of the scan: the pair's own (ordinary, hipMalloc) input buffer is the yardstick
+        if (!w.accepted && in_write_ms > 0.f && !t.empty() && w.slow_median < 0.92f * in_write_ms) {
+            w.accepted = true;
+            w.fast_median = w.slow_median;
+            w.slow_median = in_write_ms;
+            w.mixed_below = 0.94f * in_write_ms;
+            w.ordinary_above = 0.97f * in_write_ms;
+        }
+        return w;
     };
-    auto is_mixed = [&](const Chunk& c, float typ) { return use_mixed && c.write_ms < kMixedWriteRatio * typ; };
+    auto is_mixed = [&](const Chunk& c, const WriteSplit& w) { return use_mixed && w.accepted && c.write_ms < w.mixed_below; };
     struct Tally { size_t mixed, same, other; };
     auto tally = [&] {
-        const float typ = typical();
+        const WriteSplit typ = split();
         Tally t = {0, 0, 0};
         for (auto& c : chunks) {
             if (is_mixed(c, typ)) t.mixed += c.hs.size();
@@ -333,7 +416,10 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
         arena_give_back(slot, kChunkBytes);
         if (!ok) (void)hipGetLastError();
         if (getenv("SMFFT_PAIR_DEBUG")) printf("smfft_malloc_pair: interleave probe %.3f ms (own passes %.3f, %.3f)\n", ms, x.write_ms, y.write_ms);
-        return ms < kMixedWriteRatio * 0.5f * (x.write_ms + y.write_ms);
+        // two classes interleaved write like mixed memory: below the split's threshold, or (no split yet) 7 % under the two own passes
+        const WriteSplit w = split();
+        const float own = 0.5f * (x.write_ms + y.write_ms);
+        return ms < (w.accepted ? std::min(w.mixed_below, 0.96f * own) : 0.93f * own);
     };
     // Scans until the output is covered (mixed memory plus equal parts of two classes) and `lookahead` chunks further -- so
     // that either recipe alone, all mixed or all interleaved, may become complete and spare mixed chunks let the output take
@@ -380,7 +466,16 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
             Chunk& last = chunks.back();
             // only CLEARLY ordinary chunks are classified (and only such a chunk is the reference): one whose own pass lies
             // between the two kinds is partly mixed, its probes against other chunks come out between the two answers
-            if (interleave && last.write_ms > kOrdinaryWriteRatio * typical()) {
+            if (interleave && last.write_ms > split().ordinary_above) {
+                if (info.first_ordinary_copy_ms == 0.f && in) {       // the yardstick of "good": a pass into clearly ordinary memory
+                    char* again = arena_take(kChunkBytes);
+                    bool ok2 = again != nullptr;
+                    for (size_t h = 0; h < per_chunk && ok2; ++h) ok2 = hipMemMap(again + h * kHandleBytes, kHandleBytes, 0, last.hs[h], 0) == hipSuccess;
+                    ok2 = ok2 && hipMemSetAccess(again, kChunkBytes, &acc, 1) == hipSuccess;
+                    if (ok2) info.first_ordinary_copy_ms = probe_ms(in, again, bytes < kChunkBytes ? bytes : kChunkBytes, 3);
+                    else (void)hipGetLastError();
+                    if (again) { (void)hipMemUnmap(again, kChunkBytes); arena_give_back(again, kChunkBytes); }
+                }
                 if (reference < 0) { reference = (int)chunks.size() - 1; last.kind = kSameClass; }
                 else last.kind = other_class(chunks[reference], last) ? kOtherClass : kSameClass;
             }
@@ -394,7 +489,7 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
     // neighbouring handles alternate between the classes.  What the pools cannot cover comes from the remaining memory, at the end.
     struct Built { std::vector<hipMemGenericAllocationHandle_t> hs; size_t mixed_used = 0, interleaved_used = 0; };
     auto build = [&](size_t m_limit) {                        // m_limit: how much of the output mixed memory may provide
-        const float typ = typical();
+        const WriteSplit typ = split();
         std::vector<size_t> m_chunks, s_chunks, o_chunks;
         for (size_t i = 0; i < chunks.size(); ++i) {
             if (is_mixed(chunks[i], typ)) m_chunks.push_back(i);
@@ -464,7 +559,7 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
     // class of the input, which cannot be probed (a hipMalloc block has no handles): an output that shares no class with it is
     // 1.4 % better than one that does, and what a mixed chunk consists of is not known either (profiles/r02_vmm_classes.txt).
     // So the recipes -- mixed memory first, interleaved classes only -- are TIMED and the best candidate seen is kept; while
-    // it is not good (a copy within kGoodRatio x the input's own read time) and the budgets allow, eight more chunks are
+    // it is not good (see split_write_times above) and the budgets allow, eight more chunks are
     // scanned and the recipes tried again with what they add.
     auto measure = [&](const Built& b) {
         char* va = arena_take(need * kHandleBytes);
@@ -492,8 +587,18 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
             ms[k] = measure(cand[k]);
             if (ms[k] < best_ms) { best_ms = ms[k]; best = cand[k]; }
         }
-        const float typ_total = typical() * (float)((double)(need * kHandleBytes) / (double)kChunkBytes);
-        good = in ? best_ms <= (float)kGoodRatio * read_whole_ms : best_ms < kMixedWriteRatio * typ_total;
+        // good = clearly better than the same pass into ordinary memory, by half the distance this device shows between its
+        // ordinary and its mixed chunks (no split: by 7 %); passes are compared per byte
+        const WriteSplit w = split();
+        const float margin = w.accepted ? 0.5f * (1.f + w.fast_median / w.slow_median) : 0.93f;
+        const double whole = (double)(need * kHandleBytes);
+        if (in && info.first_ordinary_copy_ms > 0.f) {
+            const double window = (double)(bytes < kChunkBytes ? bytes : kChunkBytes);
+            good = best_ms <= margin * info.first_ordinary_copy_ms * (float)(whole / window);
+        } else {
+            good = best_ms < margin * w.slow_median * (float)(whole / (double)kChunkBytes);
+        }
+        info.classification = w.accepted ? 1 : 0;
         if (getenv("SMFFT_PAIR_DEBUG"))
             printf("smfft_malloc_pair: after %zu chunks: mixed first %.4f ms%s as the target of a %s pass over the whole buffer (input read %.4f ms): %s\n", chunks.size(), ms[0],
                    ncand > 1 ? (std::string(", interleaved only ") + std::to_string(ms[1]) + " ms").c_str() : "", in ? "copy" : "write", read_whole_ms, good ? "good" : "not good");
@@ -552,7 +657,8 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
 }
 
 // "candidates" policy (the fallback where the virtual-memory API is not usable): whole hipMalloc blocks one after the other,
-// each timed as a copy target; ends at the first candidate within kGoodRatio x the input's pure read time, or at the budgets.
+// each timed as a copy target; ends at the first candidate that beats the SLOWEST one seen by 10 % (two blocks of one memory
+// class against a mixed or other-class one: 1.55-1.60 against 1.30-1.34 ms per 4 GiB + 4 GiB), or at the budgets.
 bool pick_candidate_output(size_t bytes, const void* in, const Budget& budget, float read_ms, PairRec& rec, SmfftPairInfo& info) {
     const size_t window = bytes < kChunkBytes ? bytes : kChunkBytes;
     struct Cand { void* p; float ms; };
@@ -568,7 +674,9 @@ bool pick_candidate_output(size_t bytes, const void* in, const Budget& budget, f
         const float ms = probe_ms(in, p, window, 3);
         cands.push_back({p, ms > 0.f ? ms : 1e30f});
         if (best < 0 || cands.back().ms < cands[best].ms) best = (int)cands.size() - 1;
-        good = read_ms > 0.f && cands[best].ms <= kGoodRatio * read_ms;
+        float worst = 0.f;
+        for (auto& c : cands) if (c.ms < 1e29f && c.ms > worst) worst = c.ms;
+        good = cands.size() >= 2 && cands[best].ms <= 0.90f * worst;
     }
     info.candidates = (int)cands.size();
     info.candidate_bytes = used;
@@ -588,7 +696,7 @@ bool pick_candidate_output(size_t bytes, const void* in, const Budget& budget, f
 // caller_input (with_input = false only): the caller's own input buffer of at least `bytes`, read (never written) by the
 // timed copies that judge the candidate outputs
 int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search, double budget_frac = -1.0, double budget_ms = -1.0, bool with_input = true,
-               const void* caller_input = nullptr) {
+               const void* caller_input = nullptr, bool for_wrapper = false) {
     if (d_a) *d_a = nullptr;
     *d_b = nullptr;
     int device = -1;
@@ -598,12 +706,14 @@ int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search, double b
     const bool candidates_only = pol && strcmp(pol, "candidates") == 0;
     SmfftPairInfo info = {};
     info.bytes = bytes;
-    if (!plain && with_input && getenv("SMFFT_PAIR_CACHE")) {
+    if (!plain && with_input && (for_wrapper || getenv("SMFFT_PAIR_CACHE"))) {
         std::lock_guard<std::mutex> lock(g_pairs_mutex);
         if (g_pair_cache.a && g_pair_cache.device == device && g_pair_cache.bytes == bytes) {
             PairRec rec = g_pair_cache;
             g_pair_cache = PairRec();
+            rec.from_wrapper = for_wrapper;
             g_pairs[rec.a] = rec;
+            publish_out_ranges_locked();
             *d_a = rec.a;
             *d_b = rec.b;
             return 0;
@@ -612,17 +722,21 @@ int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search, double b
     void* in = nullptr;
     if (with_input && hipMalloc(&in, bytes) != hipSuccess) { (void)hipGetLastError(); return 1; }
     PairRec rec;
-    rec.a = in; rec.device = device; rec.bytes = bytes;
+    rec.a = in; rec.device = device; rec.bytes = bytes; rec.from_wrapper = for_wrapper;
     if (!plain) {
         Budget budget;
         size_t free_mem = 0, total_mem = 0;
         (void)hipMemGetInfo(&free_mem, &total_mem);
         budget.bytes = (size_t)((budget_frac >= 0.0 ? budget_frac : env_double("SMFFT_PAIR_BUDGET_FRAC", 0.25)) * (double)free_mem);
+        // the scan holds its chunks ON TOP of the pair's two buffers: never more than what is free after them, less 1 GiB of
+        // head room for whoever else uses the device; a scan that could not even hold the output's size is not started
+        const size_t after_pair = free_mem > bytes + (1ull << 30) ? free_mem - bytes - (1ull << 30) : 0;
+        if (budget.bytes > after_pair) budget.bytes = after_pair;
         budget.ms = budget_ms >= 0.0 ? budget_ms : env_double("SMFFT_PAIR_BUDGET_MS", 2000.0);
         const size_t window = bytes < kChunkBytes ? bytes : kChunkBytes;
         const void* probe_in = in ? in : caller_input;
         if (probe_in) info.read_ms = probe_ms(probe_in, nullptr, window, 3);
-        bool done = !candidates_only && build_mixed_output(bytes, probe_in, in != nullptr, device, budget, rec, info);
+        bool done = !candidates_only && budget.bytes >= bytes + kChunkBytes && build_mixed_output(bytes, probe_in, in != nullptr, device, budget, rec, info);
         if (!done && in) done = pick_candidate_output(bytes, in, budget, info.read_ms, rec, info);
         if (done && probe_in) info.copy_ms = probe_ms(probe_in, rec.b, window, 3);
         info.search_ms = budget.elapsed_ms();
@@ -634,6 +748,7 @@ int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search, double b
         std::lock_guard<std::mutex> lock(g_pairs_mutex);
         g_pairs[with_input ? rec.a : rec.b] = rec;
         g_last_pair_info = info;
+        publish_out_ranges_locked();
     }
     if (d_a) *d_a = rec.a;
     *d_b = rec.b;
@@ -649,7 +764,8 @@ int free_pair(void* d_a) {
         if (it == g_pairs.end()) return (int)hipErrorInvalidValue;   // not a pair of this allocator: nothing is freed
         rec = it->second;
         g_pairs.erase(it);
-        if (rec.searched && rec.a && getenv("SMFFT_PAIR_CACHE")) {
+        publish_out_ranges_locked();
+        if (rec.searched && rec.a && (rec.from_wrapper || getenv("SMFFT_PAIR_CACHE"))) {
             evicted = g_pair_cache;
             g_pair_cache = rec;
             rec = evicted;
@@ -679,20 +795,29 @@ int release_pair_cache() {
 // external kernel then runs at 0.80-0.83 of the HBM peak instead of 0.69-0.76.  SMFFT_WRAPPER_PLACEMENT=0: two plain
 // allocations, exactly as upstream (the hipFFT comparator of the harness follows the same switch, so that both libraries
 // are always timed on the same kind of buffers).
+// One search per process and buffer size: the wrappers (and the hipFFT comparator, which calls in here through
+// smfft_malloc_pair) keep the pair they release for the next wrapper call of the same size, so a harness run -- comparator,
+// then smFFT -- pays for one scan, not two; smfft_pair_cache_release() (or the end of the process) gives it back.
 int alloc_pair_for_wrapper(size_t bytes, void** d_a, void** d_b) {
     const char* e = getenv("SMFFT_WRAPPER_PLACEMENT");
-    return alloc_pair(bytes, d_a, d_b, !(e && atoi(e) == 0));
+    const bool search = !(e && atoi(e) == 0);
+    return alloc_pair(bytes, d_a, d_b, search, -1.0, -1.0, true, nullptr, search);
 }
 
 int select_device() {
     read_env();
     int devCount = 0;
     checkHipErrors(hipGetDeviceCount(&devCount));
-    if (devCount > g_device) checkHipErrors(hipSetDevice(g_device));
+    if (devCount > cur_device()) checkHipErrors(hipSetDevice(cur_device()));
     return devCount;
 }
 
 }  // namespace
+
+namespace smfft {
+LaunchState get_thread_state() { return t_state; }
+void set_thread_state(const LaunchState& s) { t_state = s; }
+}  // namespace smfft
 
 // =================================================================================================
 // C ABI
@@ -757,7 +882,7 @@ int smfft_launch(int family, int path, const void* d_input, void* d_output, int 
 
 int smfft_copy_launch(const void* d_input, void* d_output, long long n_float2, void* hip_stream) {
     read_env();
-    return smfft::launch_stream_copy((const float2*)d_input, (float2*)d_output, (long)n_float2, g_grid_cap, pacing_for(d_output, 16, 0), (hipStream_t)hip_stream);
+    return smfft::launch_stream_copy((const float2*)d_input, (float2*)d_output, (long)n_float2, cur_grid_cap(), pacing_for(d_output, 16, 0), (hipStream_t)hip_stream);
 }
 
 // ---- L3 wrappers ---------------------------------------------------------------------------------
@@ -915,15 +1040,24 @@ int smfft_gpu_c2r(float* h_output, const void* h_input, int FFT_size, int nFFTs,
 }
 
 // ---- tuning / introspection ------------------------------------------------------------------------
-void smfft_set_grid_cap(int max_workgroups) { read_env(); g_grid_cap = max_workgroups; }
-void smfft_set_nreuses(int n) { g_nreuses = n > 0 ? n : SMFFT_NREUSES; }
-int smfft_get_nreuses(void) { return g_nreuses; }
-int smfft_get_grid_cap(void) { read_env(); return g_grid_cap; }
+// the setters act on the CALLING host thread (see LaunchState above)
+void smfft_set_grid_cap(int max_workgroups) { read_env(); t_state.grid_cap = max_workgroups; }
+void smfft_set_nreuses(int n) { t_state.nreuses = n > 0 ? n : 0; }
+int smfft_get_nreuses(void) { read_env(); return cur_nreuses(); }
+int smfft_get_grid_cap(void) { read_env(); return cur_grid_cap(); }
+void smfft_set_pacing(int k) { t_state.pacing = k < 0 ? -2 : k; }
 int smfft_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
-int smfft_set_device(int device) { read_env(); g_device = device; return (int)hipSetDevice(device); }
+int smfft_set_device(int device) { read_env(); t_state.device = device; return (int)hipSetDevice(device); }
+int smfft_va_window(unsigned long long* first, unsigned long long* next) {
+    std::lock_guard<std::mutex> lock(g_va_mutex);
+    if (first) *first = kVaBase;
+    if (next) *next = g_va_next;
+    return (int)g_tombstones;
+}
 const char* smfft_version(void) { return "smfft_amd 0.1 (gfx950)"; }
 
 int smfft_malloc_pair(unsigned long long bytes, void** d_read, void** d_written) { read_env(); return alloc_pair((size_t)bytes, d_read, d_written, true); }
+int smfft_malloc_pair_for_wrapper(unsigned long long bytes, void** d_read, void** d_written) { read_env(); return alloc_pair_for_wrapper((size_t)bytes, d_read, d_written); }
 int smfft_malloc_written(unsigned long long bytes, void** d_written) { read_env(); return alloc_pair((size_t)bytes, nullptr, d_written, true, -1.0, -1.0, false); }
 int smfft_malloc_written_for(const void* d_read, unsigned long long bytes, void** d_written) {
     read_env();

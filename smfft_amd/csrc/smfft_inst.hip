@@ -1,4 +1,5 @@
 #include <cstdlib>
+#include <mutex>
 // smfft_inst.hip -- instantiates every kernel of ONE transform length; compiled once per length
 // with -DSMFFT_N=<32..4096> (see Makefile).
 #include "smfft_kernels.hpp"
@@ -55,11 +56,24 @@ int launch_stream_write(float2* d_output, long n_float2, int grid_cap, hipStream
     SMFFT_stream_write<0><<<dim3((unsigned)g), dim3(256), 0, stream>>>(d_output, ntiles);
     return (int)hipGetLastError();
 }
+// the read-only pass never stores (its guard cannot be true), but the kernel needs somewhere a store COULD go that is not the
+// caller's input buffer: 2 KiB per device, allocated at first use and kept
+static float2* stream_read_sink() {
+    static std::mutex mutex;
+    static float2* sinks[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mutex);
+    if (!sinks[dev] && hipMalloc((void**)&sinks[dev], 256 * sizeof(float2)) != hipSuccess) { (void)hipGetLastError(); sinks[dev] = nullptr; }
+    return sinks[dev];
+}
 int launch_stream_read(const float2* d_input, long n_float2, int grid_cap, hipStream_t stream) {
     long ntiles = n_float2 / 4096;
     if (ntiles <= 0) return 0;
+    float2* sink = stream_read_sink();
+    if (!sink) return (int)hipErrorOutOfMemory;
     long g = (grid_cap > 0 && ntiles > grid_cap) ? grid_cap : ntiles;
-    SMFFT_stream_read<0><<<dim3((unsigned)g), dim3(256), 0, stream>>>(d_input, const_cast<float2*>(d_input), ntiles);
+    SMFFT_stream_read<0><<<dim3((unsigned)g), dim3(256), 0, stream>>>(d_input, sink, ntiles);
     return (int)hipGetLastError();
 }
 #endif

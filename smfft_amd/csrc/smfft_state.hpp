@@ -1,0 +1,18 @@
+// smfft_state.hpp -- the per-host-thread launch state of libsmfft_amd.so (smfft_api.hip) and the hook through which the
+// lanes of smfft_host_transform (smfft_stream.hip) inherit it from the thread that called them.
+#pragma once
+#include <climits>
+
+namespace smfft {
+
+constexpr int kUnsetGridCap = INT_MIN;
+struct LaunchState {
+    int device;      // -1: the process default (SMFFT_DEVICE, else 0)
+    int grid_cap;    // kUnsetGridCap: the process default (SMFFT_GRID_CAP, else 12288); <= 0: one workgroup per tile
+    int nreuses;     // 0: NREUSES = 100
+    int pacing;      // -2: the process default; -1: chosen per launch from the output buffer; K >= 0: K loads
+};
+LaunchState get_thread_state();
+void set_thread_state(const LaunchState& s);
+
+}  // namespace smfft

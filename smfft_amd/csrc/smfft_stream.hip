@@ -15,6 +15,7 @@
 //
 // The batch may be larger than device memory: the device only ever holds 2 slab pairs per lane.
 #include <hip/hip_runtime.h>
+#include "smfft_state.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -99,6 +100,7 @@ bool is_pinned(const void* p) {
 }
 
 struct Job {
+    smfft::LaunchState state;   // of the thread that called smfft_host_transform: its lanes launch with the same settings
     int family, FFT_size, inverse, reorder, device;
     const char* h_in;
     char* h_out;
@@ -110,6 +112,7 @@ struct Job {
 
 void lane_main(Job* job, int lane_index, int nlanes) {
     if (hipSetDevice(job->device) != hipSuccess) { job->status = -2; return; }
+    smfft::set_thread_state(job->state);
     Lane& l = g_pipe.lanes[lane_index];
     struct Pending { long long first = -1, count = 0; } pending[kSlots];
     auto drain = [&](int k) {   // slab previously issued on slot k: wait for its D2H, hand the result to the caller
@@ -175,6 +178,7 @@ int smfft_host_transform(int family, const void* h_input, void* h_output, int FF
     job.h_in = (const char*)h_input; job.h_out = (char*)h_output; job.nFFTs = nFFTs;
     job.fft_bytes = (size_t)FFT_size * (family == 2 ? 4 : 8);
     if (hipGetDevice(&job.device) != hipSuccess) return -2;
+    job.state = smfft::get_thread_state();
     // defaults: 32 MiB slabs (1024 workgroup tiles: one full wave of the persistent grid), 8 lanes
     const char* e = getenv("SMFFT_HOST_SLAB_MIB");
     const long long slab_default = std::max<long long>(1, ((e ? atoll(e) : 32) << 20) / (long long)job.fft_bytes);

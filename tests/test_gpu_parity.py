@@ -439,13 +439,13 @@ def test_in_place_and_grid_cap_invariance(sm, oracle_lib):
         assert rc == 0 and np.array_equal(buf.to_host(np.complex64, x.shape).view(np.uint32), want.view(np.uint32))
 
 
-def test_pacing_count_does_not_change_results(sm, monkeypatch):
+def test_pacing_count_does_not_change_results(sm):
     """The external kernels' rate limiter (K discarded LDS loads per tile, a kernel argument chosen per launch) is
-    invisible in the results: SMFFT_PACING = 0, 5, 12, 33 give bit-identical outputs for C2C, Stockham, R2C and C2R."""
+    invisible in the results: smfft_set_pacing(0, 5, 12, 33) give bit-identical outputs for C2C, Stockham, R2C and C2R."""
     rng = np.random.default_rng(11)
     outs = {}
     for k in ("0", "5", "12", "33"):
-        monkeypatch.setenv("SMFFT_PACING", k)
+        sm.lib.smfft_set_pacing(int(k))
         got = []
         for n in (32, 256, 1024, 2048, 4096):
             x = (rng.random((37, n), dtype=np.float32) - 0.5 + 1j * rng.random((37, n), dtype=np.float32)).astype(np.complex64) if k == "0" else outs["x", n]
@@ -459,9 +459,107 @@ def test_pacing_count_does_not_change_results(sm, monkeypatch):
             got.append(spec)
             got.append(sm.c2r(spec))
         outs[k] = got
+    sm.lib.smfft_set_pacing(-1)
     for k in ("5", "12", "33"):
         for a, b in zip(outs["0"], outs[k]):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), k
+
+
+def test_launch_state_is_per_host_thread(sm, oracle_lib):
+    """Device, grid cap, applications per slot and pacing belong to the calling host thread (upstream: process globals and one
+    thread, CT:15): two threads that set different values and launch concurrently each get their own -- what N threads driving
+    N GPUs through the unchanged prototypes need ("Threading / state")."""
+    import threading
+    n, slots = 1024, 6
+    rng = np.random.default_rng(5)
+    x = (rng.random((slots, n), dtype=np.float32) - 0.5 + 1j * (rng.random((slots, n), dtype=np.float32) - 0.5)).astype(np.complex64)
+    want = {k: x.astype(np.complex128) for k in (1, 2)}
+    for k in (1, 2):
+        for _ in range(k):
+            want[k] = oa.ct_c2c(oracle_lib, want[k].astype(np.complex64), 0, 1, "f64")
+    errors = []
+
+    def work(k, cap):
+        try:
+            sm.lib.smfft_set_nreuses(k)
+            sm.lib.smfft_set_grid_cap(cap)
+            assert sm.lib.smfft_get_nreuses() == k and sm.lib.smfft_get_grid_cap() == cap
+            din, dout = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
+            for _ in range(20):
+                rc, _ms = sm.FFT_multiple_benchmark(din.ptr, dout.ptr, n, slots * 100, False, True)
+                assert rc == 0
+                got = dout.to_host(np.complex64, x.shape)
+                ref.assert_close_fp32(got, want[k], f"thread with nreuses={k}")
+            assert sm.lib.smfft_get_nreuses() == k and sm.lib.smfft_get_grid_cap() == cap
+        except Exception as e:       # noqa: BLE001  (reported to the main thread)
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(1, 3)), threading.Thread(target=work, args=(2, 7))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert sm.lib.smfft_get_nreuses() == 100      # the main thread never changed its own
+
+
+def test_retired_address_ranges_stay_reserved(sm):
+    """The allocator maps every virtual address at most once (ROCm 7.2 keeps stale translations) and gives its ranges back to
+    return their physical memory; each retired range is re-reserved at once and never mapped, so that no later reservation
+    of the process -- a hint-less hipMemAddressReserve, hipMalloc, PyTorch's expandable segments -- can land inside the
+    window of retired addresses [first, next)."""
+    import ctypes
+    size = 512 << 20
+    for _ in range(6):
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        assert sm.lib.smfft_malloc_pair(size, ctypes.byref(a), ctypes.byref(b)) == 0
+        assert sm.lib.smfft_free_pair(a.value) == 0
+    first, nxt = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+    tomb = sm.lib.smfft_va_window(ctypes.byref(first), ctypes.byref(nxt))
+    if nxt.value == first.value:
+        pytest.skip("the virtual-memory policy is not in use on this box")
+    assert tomb > 0, "no retired range is held reserved"
+
+    def outside(p):
+        return not (first.value <= p < nxt.value)
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemAddressReserve.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_ulonglong]
+    hip.hipMemAddressFree.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    got = []
+    for k in range(24):
+        p = ctypes.c_void_p()
+        assert hip.hipMemAddressReserve(ctypes.byref(p), 1 << 30, 1 << 21, None, 0) == 0
+        got.append(p.value)
+        assert outside(p.value), f"hint-less reservation {k} landed in the retired window: {p.value:#x}"
+    # a reservation ASKING for a retired address must not get it either
+    p = ctypes.c_void_p()
+    rc = hip.hipMemAddressReserve(ctypes.byref(p), 1 << 30, 1 << 30, ctypes.c_void_p(first.value), 0)
+    if rc == 0:
+        assert p.value != first.value, "a retired address was handed out again"
+        hip.hipMemAddressFree(p, 1 << 30)
+    for v in got:
+        hip.hipMemAddressFree(ctypes.c_void_p(v), 1 << 30)
+    bufs = [sm.DeviceBuffer(256 << 20) for _ in range(16)]
+    assert all(outside(bf.ptr) for bf in bufs)
+    for bf in bufs:
+        bf.free()
+
+
+@pytest.mark.parametrize("n,total,shards", [(1024, 1003, 7), (64, 4000, 3), (4096, 65, 8)])
+def test_virtual_shards_harness(sm, n, total, shards):
+    """harness/FFT_multi_gpu.exe ... <virtual shards G>: the batch cut into G ragged contiguous slabs as over G GPUs, run one
+    after the other on device 0, statistics reduced on the host; the concatenated output is bit-identical to one launch over
+    the whole batch ("test without 8 GPUs")."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "..", "harness", "FFT_multi_gpu.exe")
+    if not os.path.exists(exe):
+        pytest.skip("harness not built")
+    p = subprocess.run([exe, str(n), str(total), "2", "0", "1", "0", "0", str(shards)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "bit-identical" in p.stdout and "PASSED" in p.stdout and "FAILED" not in p.stdout, p.stdout
+    assert p.stdout.count("shard ") >= shards
 
 
 def test_mem_info(sm):
@@ -558,17 +656,21 @@ def test_malloc_pair_bounded_search(sm, monkeypatch):
     assert sm.lib.smfft_free_pair(a.value) == 0
     assert _settled_usage(sm, free0, 256 << 20) <= (256 << 20)               # nothing cached by default
     assert sm.lib.smfft_free_pair(a.value) != 0                              # unknown pointer: an error, nothing freed twice
-    # a zero budget: exactly one chunk is scanned; the round-1 style candidates policy: one block
+    # a zero byte budget: a scan that could not hold even the output's size is not started; what remains is the round-1
+    # style candidates policy, which looks at one block
     monkeypatch.setenv("SMFFT_PAIR_BUDGET_FRAC", "0.0")
-    for policy, limit in (("mixed", 1), ("candidates", 1)):
+    for policy, count in (("mixed", 1), ("candidates", 1)):
         monkeypatch.setenv("SMFFT_PAIR_POLICY", policy)
         assert sm.lib.smfft_malloc_pair(nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
-        assert 1 <= sm.last_pair_info()["candidates"] <= limit
+        assert sm.last_pair_info()["candidates"] == count
         use(a, b)
         assert sm.lib.smfft_free_pair(a.value) == 0
         assert _settled_usage(sm, free0, 256 << 20) <= (256 << 20)
-    # a budget smaller than the output: the scan's one chunk + the rest created unprobed, still one VMM-assembled buffer
+    # a scan that ends on its TIME budget before it holds the output's size: its one chunk + the rest created unprobed, still
+    # one VMM-assembled buffer
     monkeypatch.setenv("SMFFT_PAIR_POLICY", "mixed")
+    monkeypatch.delenv("SMFFT_PAIR_BUDGET_FRAC")
+    monkeypatch.setenv("SMFFT_PAIR_BUDGET_MS", "0")
     assert sm.lib.smfft_malloc_pair(3 * nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
     info = sm.last_pair_info()
     assert info["candidates"] == 2 and info["candidate_bytes"] == 3 * nbytes, info
@@ -576,7 +678,7 @@ def test_malloc_pair_bounded_search(sm, monkeypatch):
     use(a, b)
     assert sm.lib.smfft_free_pair(a.value) == 0
     assert _settled_usage(sm, free0, 256 << 20) <= (256 << 20)
-    monkeypatch.delenv("SMFFT_PAIR_BUDGET_FRAC")
+    monkeypatch.delenv("SMFFT_PAIR_BUDGET_MS")
     monkeypatch.delenv("SMFFT_PAIR_POLICY")
     # the output as ordinary memory of two classes interleaved handle by handle (mixed chunks not allowed to count): every
     # 8 MiB handle of the range is distinct memory (a pattern per handle survives all the other writes) and the pair works

@@ -1,4 +1,4 @@
-"""Sweep of the external kernels' rate limiter (SMFFT_PACING=K serialised LDS loads between a wave's loads and stores):
+"""Sweep of the external kernels' rate limiter (smfft_set_pacing(K): K serialised LDS loads between a wave's loads and stores):
 every length, C2C forward and R2C / C2R, on two plain allocations (default) or on a smfft_malloc_pair pair (--pair).
     python tools/pacing_sweep.py [--pair] [--ks 0,4,8,16] [--sizes 32,...,4096]"""
 import argparse
@@ -42,7 +42,7 @@ def sweep(label, call, gbytes):
     res = {k: [] for k in ks}
     order = [(rnd, k) for k in ks for rnd in range(args.rounds + 1)] if args.consecutive else [(rnd, k) for rnd in range(args.rounds + 1) for k in ks]
     for rnd, k in order:
-        os.environ["SMFFT_PACING"] = str(k)
+        sm.lib.smfft_set_pacing(k)
         t = ctypes.c_double(0)
         assert call(ctypes.byref(t)) == 0
         if rnd:
