@@ -22,8 +22,10 @@ Prints ONE JSON line on rank 0 (see the driver contract).  Objects beyond the co
   roofline_plain  the same kernel, same pre-warm, same number of timed launches, on two PLAIN hipMalloc buffers
                   (what a caller of FFT_external_benchmark brings along, CT:850-853).
   roofline_own_input  the same on a plain hipMalloc INPUT with only the output taken from smfft_malloc_written_for
-  configs         config 3 (N = 32..4096 no-reorder, FFT_multiple_benchmark: ms, FFT/s, TFLOP/s) and config 4
-                  (real N = 2048 R2C and C2R: ms, TB/s, fraction of peak), N = 1 only.
+  configs         N = 1 only, same buffers: config 2 at every length (forward / inverse x reorder / no reorder); config 3
+                  (N = 32..4096, FFT_multiple_benchmark: ms, FFT/s, fraction of the fp32 peak on the README batch and on a
+                  saturating batch of 8 x its slots); config 4 (real N = 512..4096, R2C and C2R); the Stockham program; and
+                  `reference_contract`: the two-argument kernels in the reference's own launch shape (blockDim = N/4).
   cpu_baseline    FFTW-API batched C2C (MKL's FFTW3 interface; real FFTW is not in the image) on the host cores of
                   this box over the SAME input as the GPU run; falls back to the oracle's C restatement.
 PyTorch is plumbing only (device memory, stream, torch.distributed); the transform is the HIP
@@ -102,16 +104,24 @@ def cpu_baseline(x, threads):
 def measured_traffic():
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
     (profiles/*_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x2 per the
-    gfx950 correction, calibrated on the same access shape).  None if no profile is committed."""
+    gfx950 correction, calibrated on the same access shape) and where the figure comes from: the counters cannot be
+    collected inside this run (rocprofv3 wraps a whole process), so the line names the profile it quotes.
+    (None, reason) if no profile is committed."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
-        return None
+        return None, "no profiles/r*_pmc_traffic.json committed"
     try:
         k = json.load(open(files[-1]))["kernels"]["void SMFFT_DIT_external<FFT_1024_forward>"]
-        return k["hbm_bytes_per_launch"]
+        commit = k.get("commit") or json.load(open(files[-1])).get("commit")     # written by tools/collect_profiles.py
+        try:
+            commit = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", files[-1]], capture_output=True, text=True, timeout=10).stdout.strip() or commit
+        except Exception:
+            pass
+        return k["hbm_bytes_per_launch"], {"file": os.path.relpath(files[-1], ROOT), "commit": commit,
+                                           "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not collected in this run"}
     except (KeyError, ValueError):
-        return None
+        return None, "profile unreadable"
 
 
 def hipfft_ms(torch, dev, stream, i_ptr, o_ptr, n, nffts, reps=10):
@@ -432,6 +442,7 @@ def main():
     if world == 1 and not args.no_configs:
         import math
         total = 1 << 29                  # README batches: 4 GiB of float2
+        SAT = 8                          # "saturating" batch of the in-LDS path: 8 x the README batch's slots (several rounds of resident waves)
         c3 = {}
         for fn_n in (32, 64, 128, 256, 512, 1024, 2048, 4096):
             bn = min(total // fn_n, nffts * n // fn_n)
@@ -440,35 +451,91 @@ def main():
             for name, reo in (("noreorder", 0), ("reorder", 1)):
                 ms = median_ms(lambda t, reo=reo: sm.lib.smfft_ct_multiple_benchmark(pa.value, pb.value, fn_n, bn, 0, reo, t))
                 tf = done * 5 * fn_n * math.log2(fn_n) / (ms * 1e-3) / 1e12
-                row[name] = {"ms": ms, "FFT/s": done / (ms * 1e-3), "TFLOP/s": tf, "frac_fp32_peak": tf / FP32_PEAK_TFLOPS}
+                # the multiple path touches only the first nFFTs/100 slots, so a "batch" of SAT x nFFTs stays inside the buffers
+                ms_sat = median_ms(lambda t, reo=reo: sm.lib.smfft_ct_multiple_benchmark(pa.value, pb.value, fn_n, SAT * bn, 0, reo, t), reps=7)
+                row[name] = {"ms": ms, "FFT/s": done / (ms * 1e-3), "TFLOP/s": tf, "frac_fp32_peak": tf / FP32_PEAK_TFLOPS,
+                             "saturating_batch": {"slots_x": SAT, "ms": ms_sat, "FFT/s": SAT * done / (ms_sat * 1e-3),
+                                                  "frac_fp32_peak": SAT * done * 5 * fn_n * math.log2(fn_n) / (ms_sat * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}}
             c3[str(fn_n)] = row
-        # config 4: real N = 2048, 262144 FFTs: 2 GiB of reals <-> 2 GiB packed spectrum, first halves of the pair
-        rn, rnffts = 2048, min(262144, nffts * n * 2 // 2048 // 2)
-        rbytes = rn * rnffts * 4
-        c4 = {"nFFTs": rnffts, "real_N": rn, "algorithmic_bytes_per_launch": 2 * rbytes}
-        # R2C: first half of the read buffer -> first half of the written buffer; the packed spectra are then copied into the
-        # read buffer's second half so that C2R, too, READS the read buffer and WRITES the written one (second halves)
+        # config 4: real N = 2048, 262144 FFTs (2 GiB of reals <-> 2 GiB packed spectrum) -- and the other three real lengths
+        # at the same byte count; first halves of the pair for R2C, second halves for C2R
         half = nbytes // 2
-        for name, inv, src, dst in (("r2c", 0, pa.value, pb.value), ("c2r", 1, pa.value + half, pb.value + half)):
-            if inv:
-                sm.lib.smfft_memcpy_d2d(src, pb.value, rbytes)
-            ms = median_ms(lambda t, inv=inv, src=src, dst=dst: sm.lib.smfft_rc_external_benchmark(src, dst, rn, rnffts, inv, t))
-            gbps = 2 * rbytes / (ms * 1e-3) / 1e9
-            c4[name] = {"ms": ms, "TB/s": gbps / 1e3, "frac": gbps / HBM_PEAK_GBPS}
-        # config 2's other half (inverse, reorder) and the external path at every length (forward, reorder), whole 4 GiB batch
+        c4 = {}
+        for rn in (512, 1024, 2048, 4096):
+            rnffts = min((1 << 29) // rn, nffts * n * 2 // rn // 2)      # 2 GiB of reals
+            rbytes = rn * rnffts * 4
+            row = {"nFFTs": rnffts, "algorithmic_bytes_per_launch": 2 * rbytes}
+            # R2C: first half of the read buffer -> first half of the written buffer; the packed spectra are then copied into the
+            # read buffer's second half so that C2R, too, READS the read buffer and WRITES the written one (second halves)
+            for name, inv, src, dst in (("r2c", 0, pa.value, pb.value), ("c2r", 1, pa.value + half, pb.value + half)):
+                if inv:
+                    sm.lib.smfft_memcpy_d2d(src, pb.value, rbytes)
+                ms = median_ms(lambda t, inv=inv, src=src, dst=dst, rn=rn, rnffts=rnffts: sm.lib.smfft_rc_external_benchmark(src, dst, rn, rnffts, inv, t))
+                gbps = 2 * rbytes / (ms * 1e-3) / 1e9
+                row[name] = {"ms": ms, "TB/s": gbps / 1e3, "frac": gbps / HBM_PEAK_GBPS}
+            c4[str(rn)] = row
+        c4.update({"real_N": 2048, "nFFTs": c4["2048"]["nFFTs"], "algorithmic_bytes_per_launch": c4["2048"]["algorithmic_bytes_per_launch"],
+                   "r2c": c4["2048"]["r2c"], "c2r": c4["2048"]["c2r"]})      # BASELINE's config 4 itself, as in round 2's line
+        # config 2 at every length: forward / inverse x reorder / no reorder, whole 4 GiB batch
         c2 = {}
         for fn_n in (32, 64, 128, 256, 512, 1024, 2048, 4096):
             bn = nffts * n // fn_n
             row = {"nFFTs": bn}
-            for name, inv in (("forward", 0), ("inverse", 1)):
-                if inv and fn_n != n:
-                    continue
-                ms = median_ms(lambda t, inv=inv: sm.lib.smfft_ct_external_benchmark(pa.value, pb.value, fn_n, bn, inv, 1, t))
+            for name, inv, reo in (("forward", 0, 1), ("inverse", 1, 1), ("forward_noreorder", 0, 0), ("inverse_noreorder", 1, 0)):
+                ms = median_ms(lambda t, inv=inv, reo=reo: sm.lib.smfft_ct_external_benchmark(pa.value, pb.value, fn_n, bn, inv, reo, t), reps=7)
                 gbps = 2 * fn_n * bn * 8 / (ms * 1e-3) / 1e9
                 row[name] = {"ms": ms, "TB/s": gbps / 1e3, "frac": gbps / HBM_PEAK_GBPS}
             c2[str(fn_n)] = row
-        configs = {"timing": "median of 11 event-timed launches after 3 warm-ups, buffers of `roofline`",
-                   "config2_external_by_length": c2, "config3_multiple": c3, "config4_r2c_c2r_external": c4}
+        # the Stockham program (ST:299-384: + sign, natural order): external and in-LDS path by length
+        cst = {}
+        for fn_n in (256, 512, 1024, 2048, 4096):
+            bn = nffts * n // fn_n
+            ms = median_ms(lambda t: sm.lib.smfft_st_external_benchmark(pa.value, pb.value, fn_n, bn, t), reps=7)
+            gbps = 2 * fn_n * bn * 8 / (ms * 1e-3) / 1e9
+            msm = median_ms(lambda t: sm.lib.smfft_st_multiple_benchmark(pa.value, pb.value, fn_n, bn, t), reps=7)
+            done = bn // 100 * 100
+            cst[str(fn_n)] = {"nFFTs": bn, "external": {"ms": ms, "TB/s": gbps / 1e3, "frac": gbps / HBM_PEAK_GBPS},
+                              "multiple": {"ms": msm, "FFT/s": done / (msm * 1e-3), "frac_fp32_peak": done * 5 * fn_n * math.log2(fn_n) / (msm * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}}
+        # the device functions in the REFERENCE'S OWN contract (blockDim.x = fft_length / 4, two-argument kernels launched in the
+        # reference's shape; examples/reference_shape_kernel.hip) next to the library's tiled / compact kernels, same buffers
+        cref = None
+        try:
+            ex = ctypes.CDLL(os.path.join(os.path.dirname(sm.LIB_PATH), "libsmfft_examples.so"))
+            vp, ci = ctypes.c_void_p, ctypes.c_int
+            ex.smfft_example_reference_shape_ct.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
+            ex.smfft_example_reference_shape_st.argtypes = [vp, vp, ci, ci, vp]
+            ex.smfft_example_reference_shape_multiple_one.argtypes = [vp, vp, ci, ci, vp]
+
+            def event_ms(fn, reps=7, warm=2):
+                for _ in range(warm):
+                    fn()
+                ts = []
+                for _ in range(reps):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    fn()
+                    e1.record(stream)
+                    torch.cuda.synchronize(dev)
+                    ts.append(e0.elapsed_time(e1))
+                return sorted(ts)[len(ts) // 2]
+            slots = (nffts // 100)
+            gb = 2 * n * nffts * 8 / 1e9
+            cref = {"kernels": "SMFFT_DIT_external<P>(in, out) <<<nFFTs, N/4>>> etc. of include/smfft/smfft_device_functions.hpp", "N": n}
+            for key, which_reo in (("ct_external_reorder", 1), ("ct_external_noreorder", 0)):
+                ms = event_ms(lambda r=which_reo: ex.smfft_example_reference_shape_ct(pa.value, pb.value, n, nffts, 0, r, 1, sh))
+                tiled = c2[str(n)]["forward" if which_reo else "forward_noreorder"]["ms"]
+                cref[key] = {"ms": ms, "TB/s": gb / ms, "frac": gb / ms * 1e3 / HBM_PEAK_GBPS, "ratio_to_tiled": tiled / ms}
+            ms = event_ms(lambda: ex.smfft_example_reference_shape_st(pa.value, pb.value, n, nffts, sh))
+            cref["stockham_external"] = {"ms": ms, "TB/s": gb / ms, "frac": gb / ms * 1e3 / HBM_PEAK_GBPS, "ratio_to_tiled": cst[str(n)]["external"]["ms"] / ms}
+            for key, which, compact in (("ct_multiple_reorder", 0, c3[str(n)]["reorder"]["ms"]), ("ct_multiple_noreorder", 1, c3[str(n)]["noreorder"]["ms"]),
+                                        ("stockham_multiple", 2, cst[str(n)]["multiple"]["ms"])):
+                ms = event_ms(lambda w=which: ex.smfft_example_reference_shape_multiple_one(pa.value, pb.value, slots, w, sh))
+                cref[key] = {"ms": ms, "FFT/s": slots * 100 / (ms * 1e-3), "ratio_to_compact": compact / ms}
+        except (OSError, AttributeError) as e:
+            cref = {"error": repr(e)}
+        configs = {"timing": "median of 11 (7 where many cases) event-timed launches after 3 warm-ups, buffers of `roofline`",
+                   "config2_external_by_length": c2, "config3_multiple": c3, "config4_r2c_c2r_external": c4,
+                   "stockham_program": cst, "reference_contract": cref}
 
     # release everything, then look at the driver's accounting once more: freed VRAM is returned asynchronously
     sm.lib.smfft_free_pair(pa.value)
@@ -485,8 +552,9 @@ def main():
 
         def roof(kms, cms):
             achieved = alg_bytes / (kms * 1e-3) / 1e9
+            traffic, traffic_source = measured_traffic()
             return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                    "traffic": measured_traffic(), "kernel": "SMFFT_DIT_external<FFT_1024_forward>", "kernel_ms": kms,
+                    "traffic": traffic, "traffic_source": traffic_source, "kernel": "SMFFT_DIT_external<FFT_1024_forward>", "kernel_ms": kms,
                     "algorithmic_bytes_per_launch": alg_bytes, "copy_ceiling": alg_bytes / (cms * 1e-3) / 1e9, "frac_of_copy": cms / kms}
         out = {
             "metric": "batched_ffts_per_sec_N1024_c2c_fwd_4GiB_external",

@@ -624,8 +624,14 @@ __global__ void __launch_bounds__(256) FFT_GPU_external(const float2* d_input, f
 }
 template <class const_params>
 __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_length) FFT_GPU_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
-    __shared__ float2 s_input[smfft::Geometry<const_params::fft_length>::kCompactLds];
-    smfft::c2c_multiple_body<const_params::fft_length, 1, 1>(d_input, d_output, nSlots, nreuses, s_input);
+    constexpr int N = const_params::fft_length;
+    if constexpr (SMFFT_PLANAR_SIZES(N)) {
+        __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<N, 1>::kLdsFloats];
+        smfft::c2c_multiple_body_planar<N, 1, 1>(d_input, d_output, nSlots, nreuses, s_planes);
+    } else {
+        __shared__ float2 s_input[smfft::Geometry<N>::kCompactLds];
+        smfft::c2c_multiple_body<N, 1, 1>(d_input, d_output, nSlots, nreuses, s_input);
+    }
 }
 
 // R2C/C2R program.

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 from oracle import np_reference as ref  # noqa: E402
 
 SEED = 20200720
-NFFT = 2  # FFTs per size (ragged batch sizes are covered by seeded inputs in tests/test_gpu_parity.py)
+NFFT = 9  # FFTs per size: eight plus one, so that every kernel shape (4096-element tiles, 1024-element waves) ends in a ragged tail
 C2C_SIZES = [32, 64, 128, 256, 512, 1024, 2048, 4096]
 R2C_SIZES = [512, 1024, 2048, 4096]
 

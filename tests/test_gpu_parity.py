@@ -235,7 +235,7 @@ def test_config4_r2c_c2r_roundtrip(sm, oracle_lib):
 @pytest.mark.parametrize("prog,args,expect", [
     ("FFT_CooleyTukey_C2C.exe", ["1024", "2000", "2", "0", "1"], 1),
     ("FFT_CooleyTukey_C2C.exe", ["32", "1001", "2", "1", "1"], 1),
-    ("FFT_CooleyTukey_C2C.exe", ["256", "1000", "1", "0", "0"], 0),
+    ("FFT_CooleyTukey_C2C.exe", ["256", "1000", "1", "0", "0"], 1),       # no reorder: checked against the vendor FFT of the bit-reversed input
     ("FFT_Stockham_C2C.exe", ["2048", "1500", "2"], 1),
     ("FFT_Stockham_R2C_C2R.exe", ["2048", "1200", "2"], 2),
     ("FFT_multi_gpu.exe", ["1024", "4100", "3", "0", "1"], 1),
@@ -253,8 +253,6 @@ def test_harness_programs(sm, prog, args, expect):
     p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600, env=dict(os.environ, SMFFT_SEED="7"))
     assert p.returncode == 0, p.stdout + p.stderr
     assert p.stdout.count("PASSED") == expect and "FAILED" not in p.stdout, p.stdout
-    if expect == 0:
-        assert "There is no verification of the results if FFT are not reordered." in p.stdout
     assert "SH FFT normal" in p.stdout or "smFFT R2C time" in p.stdout
     if prog == "FFT_multi_gpu.exe":
         assert "GPU(s), 4100 FFTs of 1024 each: job time" in p.stdout
@@ -965,3 +963,129 @@ def test_bench_two_ranks_on_one_device(sm):
     doc = json.loads(lines[0])
     assert doc["n_gpus"] == 2 and doc["ranks_seen"] == 2 and doc["comm_backend"] == "gloo"
     assert doc["value"] > 0 and doc["roofline"]["frac"] > 0 and doc["roofline_plain"]["frac"] > 0
+
+
+# ------------------------------------------------------------ analytic known-answer tests through the HIP path (8(c) item 3)
+def _kat_batch(n):
+    """Known-answer inputs of length n (complex128) and what they are: impulses, a constant, single tones, the harness's
+    two-tone Generate_signal (CT/FFT.c:14-21), plus two random rows for the identities."""
+    k = np.arange(n)
+    rows, names = [], []
+    for n0 in (0, 1, 5, n // 2, n - 1):
+        e = np.zeros(n, np.complex128)
+        e[n0] = 1
+        rows.append(e)
+        names.append(("impulse", n0))
+    rows.append(np.ones(n, np.complex128))
+    names.append(("constant", 0))
+    for k0 in (1, 7 % n, n // 4, n - 3):
+        rows.append(np.exp(2j * np.pi * k0 * k / n))
+        names.append(("tone", k0))
+    rows.append((1.0 * np.sin(2 * np.pi * k / 8) + 0.5 * np.sin(2 * np.pi * 2 * k / 8 + 3 * np.pi / 4)).astype(np.complex128))
+    names.append(("two_tone", 0))
+    rng = np.random.default_rng(1000 + n)
+    for _ in range(2):
+        rows.append(rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        names.append(("random", 0))
+    return np.stack(rows), names
+
+
+@pytest.mark.parametrize("reo", [1, 0])
+@pytest.mark.parametrize("inv", [0, 1])
+@pytest.mark.parametrize("n", C2C_SIZES)
+def test_kat_c2c_through_hip(sm, n, inv, reo):
+    """Impulse at n0 <-> e^{-+2 pi i k n0 / N}, constant <-> N delta[k], e^{+-2 pi i k0 n / N} <-> N delta[k - k0], the harness's
+    two-tone signal (peaks N/2 at bins N/8, N/4 at bins N/4 -- CT/FFT.c:14-21), Parseval, and (natural order) F(F(x))[m] =
+    N x[-m], inv(fwd(x)) = N x -- every length, direction and ordering, computed by the HIP path.  Without reorder the
+    transform is applied to x o bitrev (S2), so the inputs are fed through the inverse permutation."""
+    x, names = _kat_batch(n)
+    if inv:
+        x = np.conj(x)                       # e^{-2 pi i k0 n / N} is the tone the + sign transform maps to N delta[k - k0]
+    br = ref.bitrev_indices(n)
+    fed = x if reo else x[:, br]             # out = DFT(fed o bitrev) = DFT(x): bitrev is an involution
+    got = sm.c2c(fed.astype(np.complex64), bool(inv), bool(reo)).astype(np.complex128)
+    k = np.arange(n)
+    sign = +1 if inv else -1
+    for row, (kind, p) in zip(got, names):
+        if kind == "impulse":
+            want = np.exp(sign * 2j * np.pi * k * p / n)
+        elif kind == "constant":
+            want = np.zeros(n, np.complex128)
+            want[0] = n
+        elif kind == "tone":
+            want = np.zeros(n, np.complex128)
+            want[p] = n
+        elif kind == "two_tone":
+            mag = np.abs(row)
+            assert set(np.argsort(mag)[-4:].tolist()) == {n // 8, n - n // 8, n // 4, n - n // 4}
+            assert abs(mag[n // 8] - n / 2) < 2e-4 * n and abs(mag[n // 4] - n / 4) < 2e-4 * n
+            continue
+        else:
+            continue
+        assert np.abs(row - want).max() <= 2e-6 * n, (kind, p, np.abs(row - want).max())
+    # Parseval on every row: sum |X|^2 = N sum |x|^2
+    np.testing.assert_allclose((np.abs(got) ** 2).sum(-1), n * (np.abs(x) ** 2).sum(-1), rtol=2e-6)
+    if reo:
+        xr = x[-2:].astype(np.complex64)
+        once = sm.c2c(xr, bool(inv), True)
+        twice = sm.c2c(once, bool(inv), True).astype(np.complex128)
+        ref.assert_close_fp32(twice, n * np.roll(xr.astype(np.complex128)[:, ::-1], 1, axis=-1), f"F(F(x)) N={n}")
+        back = sm.c2c(once, not inv, True).astype(np.complex128)
+        ref.assert_close_fp32(back, n * xr.astype(np.complex128), f"inv(fwd(x)) N={n}")
+
+
+@pytest.mark.parametrize("n", R2C_SIZES)
+def test_kat_r2c_c2r_through_hip(sm, n):
+    """Real impulse, constant, cosine at bin k0 and at Nyquist through R2C (packed layout: element 0 = (DC, Nyquist), S5) and
+    back through C2R = (N/2) x (S6), by the HIP path."""
+    t = np.arange(n)
+    k0 = 9
+    x = np.stack([np.eye(1, n, 3)[0], np.ones(n), np.cos(2 * np.pi * k0 * t / n), np.cos(np.pi * t), np.random.default_rng(n).random(n)]).astype(np.float32)
+    spec = sm.r2c(x).astype(np.complex128)
+    k = np.arange(n // 2)
+    want0 = np.exp(-2j * np.pi * k * 3 / n)
+    want0[0] = 1 + 1j * np.cos(np.pi * 3)                       # (X[0], X[N/2]) of the impulse at 3
+    assert np.abs(spec[0] - want0).max() < 1e-5
+    want1 = np.zeros(n // 2, np.complex128)
+    want1[0] = n
+    assert np.abs(spec[1] - want1).max() < 2e-6 * n
+    want2 = np.zeros(n // 2, np.complex128)
+    want2[k0] = n / 2
+    assert np.abs(spec[2] - want2).max() < 2e-6 * n
+    want3 = np.zeros(n // 2, np.complex128)
+    want3[0] = 1j * n                                            # all of it at Nyquist, packed into element 0's imaginary part
+    assert np.abs(spec[3] - want3).max() < 2e-6 * n
+    back = sm.c2r(spec.astype(np.complex64)).astype(np.float64)
+    ref.assert_close_fp32(back, (n / 2) * x.astype(np.float64), f"C2R(R2C(x)) N={n}")
+
+
+@pytest.mark.parametrize("n", C2C_SIZES)
+def test_harness_per_length_readme_batch(sm, n):
+    """The harness program's own self-check (comparison with the vendor FFT under max_error = 1e-4, CT/FFT.c:148-160) once per
+    length at the README batch (2^29 / N FFTs, 4 GiB each way), forward with reorder."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "..", "harness", "FFT_CooleyTukey_C2C.exe")
+    if not os.path.exists(exe):
+        pytest.skip("harness not built")
+    p = subprocess.run([exe, str(n), str((1 << 29) // n), "2", "0", "1"], capture_output=True, text=True, timeout=900, env=dict(os.environ, SMFFT_SEED="11"))
+    assert p.returncode == 0, p.stdout + p.stderr
+    # N >= 2048 with U[0,1) data: the reference's metric flags fp32 round-off of the DC-heavy spectrum (tools/metric_probe.py);
+    # the gate there is that the program ran and compared, the stated tolerance is checked by the parity tests
+    if n <= 1024:
+        assert "PASSED" in p.stdout and "FAILED" not in p.stdout, p.stdout
+
+
+@pytest.mark.parametrize("n", [64, 512, 1024])
+def test_harness_noreorder_is_verified(sm, n):
+    """reorder = 0 upstream prints "no verification" (CT/FFT.c:162); the harness here checks it against the vendor FFT of the
+    bit-reversed input (S2).  (N <= 1024: above that the reference's max_error = 1e-4 metric flags fp32 round-off itself on
+    U[0,1) data, tools/metric_probe.py; the stated tolerance is checked by the parity tests at every length.)"""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "..", "harness", "FFT_CooleyTukey_C2C.exe")
+    if not os.path.exists(exe):
+        pytest.skip("harness not built")
+    p = subprocess.run([exe, str(n), str(4096 * 64 // n), "2", "0", "0"], capture_output=True, text=True, timeout=600, env=dict(os.environ, SMFFT_SEED="13"))
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "bit-reversed input" in p.stdout and "PASSED" in p.stdout and "FAILED" not in p.stdout, p.stdout
