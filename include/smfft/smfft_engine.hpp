@@ -306,7 +306,7 @@ struct SmallDft<1, STRIDE, DIR, TAN> {
 // gather that touches 30-60 cache lines per load instruction -- ten times the requests of the tile a wave then moves,
 // on the path every global access takes.  With 12288 workgroups per launch (12 generations per workgroup slot) that
 // was a FIXED 45-55 us per launch of the external kernels, whatever the batch (N = 1024, 4 / 2 / 1 GiB each way:
-// 0.80 / 0.78 / 0.71 of the HBM peak before, 0.815 / 0.82 / 0.82 after; tools/size_effect.py).
+// 0.80 / 0.78 / 0.71 of the HBM peak before, 0.815 / 0.82 / 0.82 after; round 2's tools/size_effect.py (git history)).
 // Same values, same rounding: the rows are built at compile time from the table.
 template <int N>
 struct TwiddleRows {

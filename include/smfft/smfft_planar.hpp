@@ -352,6 +352,63 @@ struct PlanarEngine {
         x2_load(x, planes);
         SmallDft<16, 1, DIR>::run(x, r);
     }
+
+    // ---- R2C / C2R (real length 2L through this complex engine of length L = N; reorder roles) ----------------------
+    // The split (after the forward transform) / merge (in front of the inverse one) of RC:269-344 on the natural REGISTERS
+    // r[q] = x[i], i = klow + T*q:   out[i] = S/2 + V * D,  S = A + conj(B), D = A - conj(B), A = x[i], B = x[L - i],
+    // V = (-+i/2) * W_2L^i = herm_w * W_32^q  (HermitianRegisters::apply in smfft_kernels.hpp states the algebra).  The
+    // partner x[L - i] = x[(T - klow) + T*(15 - q)] is register 15 - q of the thread whose role is T - klow: it is read
+    // from the stored image (row 15 - q, that thread's dword); role 0 pairs with its own registers, and its element 0
+    // packs DC and Nyquist (RC:280-286, 332-339).  Precondition: the image holds the registers of every thread.
+    float2 herm_w;
+    int off_partner;
+    bool herm_first;
+    __device__ __forceinline__ void init_hermitian() {
+        static_assert(REORDER, "the real transforms are natural order");
+        herm_first = (klow == 0);
+        off_partner = fft * T + position_of_role((T - klow) % T);
+        const float2 w = twiddle<DIR>(klow * (4096 / (2 * N)));
+        herm_w = DIR ? make_float2(-0.5f * w.y, 0.5f * w.x) : make_float2(0.5f * w.y, -0.5f * w.x);
+    }
+    __device__ __forceinline__ void hermitian_apply(float2 (&r)[16], const float* planes) const {
+        constexpr float c32[16] = {1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f, 0.55557023301960229f,
+                                   0.38268343236508984f, 0.19509032201612833f, 0.f, -0.19509032201612819f, -0.38268343236508973f, -0.55557023301960196f,
+                                   -0.70710678118654746f, -0.83146961230254535f, -0.92387953251128674f, -0.98078528040323043f};
+        constexpr float s32[16] = {0.f, 0.19509032201612825f, 0.38268343236508978f, 0.55557023301960218f, 0.70710678118654746f, 0.83146961230254524f,
+                                   0.92387953251128674f, 0.98078528040323043f, 1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254546f,
+                                   0.70710678118654757f, 0.55557023301960218f, 0.38268343236508989f, 0.19509032201612861f};
+        const float* p = planes + off_partner;
+        float2 w = herm_w;
+        asm volatile("" : "+v"(w.x), "+v"(w.y));     // the fifteen products W_2L^i are recomputed per application, not kept in 30 registers
+        auto partner = [&](int q, float2 own) {      // B = x[L - i] for register q
+            const float2 fetched = make_float2(p[P::image_row(15 - q)], p[P::kPlane + P::image_row(15 - q)]);
+            return herm_first ? own : fetched;
+        };
+        auto combine = [&](int q, float2 A, float2 B) {
+            const float2 S = make_float2(A.x + B.x, A.y - B.y);
+            const float2 D = make_float2(A.x - B.x, A.y + B.y);
+            const float2 V = (q == 0) ? w : cmul(w, make_float2(c32[q], DIR ? s32[q] : -s32[q]));
+            return make_float2(fmaf(V.x, D.x, fmaf(-V.y, D.y, 0.5f * S.x)), fmaf(V.x, D.y, fmaf(V.y, D.x, 0.5f * S.y)));
+        };
+        // In place, two partners in flight at a time (the kernels live on their occupancy: all sixteen partners fetched at
+        // once took 139-157 registers = 3 waves per SIMD).  Role 0 pairs register q with its OWN register 16 - q, so the
+        // registers are walked in the pairs (q, 16 - q), both combined from the original values.
+        {
+            const float2 A = r[0], B = partner(0, r[0]);
+            const float2 packed = DIR ? make_float2(0.5f * (A.x + A.y), 0.5f * (A.x - A.y)) : make_float2(A.x + A.y, A.x - A.y);
+            const float2 out = combine(0, A, B);
+            r[0] = herm_first ? packed : out;
+            r[8] = combine(8, r[8], partner(8, r[8]));
+        }
+#pragma unroll
+        for (int q = 1; q < 8; ++q) {
+            asm volatile("" ::: "memory");           // keeps the loads of the next pair behind the arithmetic of this one
+            const float2 A = r[q], A2 = r[16 - q];
+            const float2 B = partner(q, A2), B2 = partner(16 - q, A);
+            r[q] = combine(q, A, B);
+            r[16 - q] = combine(16 - q, A2, B2);
+        }
+    }
 };
 
 // tile <-> planar image (once per tile): element e = fft * N + n of the tile, n = u + T*c, lies in row c at dword

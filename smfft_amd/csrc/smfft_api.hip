@@ -126,7 +126,7 @@ int timed(F&& launch, double* FFT_time) {
 }
 
 // ---- paired allocation ----------------------------------------------------------------------------
-// What round 2 measured on MI355X (tools/microbench/placement_study.hip; profiles/r02_placement_map.txt,
+// What round 2 measured on MI355X (round 2's tools/microbench/placement_study.hip (git history); profiles/r02_placement_map.txt,
 // profiles/r02_placement_pmc.json, profiles/r02_vmm_mixed_assembly.txt, profiles/r02_vmm_interleave.txt):
 //  * Physical memory comes in CLASSES (three were told apart).  A plain allocation of a few GiB lies inside one class;
 //    pure reads from it run at 7.2 TB/s, pure writes at 5.6 TB/s.
@@ -272,7 +272,7 @@ double env_double(const char* name, double dflt) {
 
 // Virtual ranges for the VMM-backed buffers: every range is a reservation of its own at an address that has NEVER been used
 // before in this process, and it is given back (hipMemAddressFree) as soon as its mapping is gone.  Two things measured on
-// ROCm 7.2 / MI355X force that shape (tools/microbench/placement_study.hip vmm7, profiles/r02_vmm_remap_check.txt,
+// ROCm 7.2 / MI355X force that shape (round 2's tools/microbench/placement_study.hip (git history) vmm7, profiles/r02_vmm_remap_check.txt,
 // r02_vmm_release_check.txt):
 //  * after hipMemUnmap -- and even after hipMemAddressFree and a new hipMemAddressReserve of the same address -- a hipMemMap
 //    of ANOTHER handle at that virtual address leaves the GPU translating to the OLD physical memory (the second fill of the
@@ -343,7 +343,7 @@ struct Budget {
 // "mixed" policy: the output as a virtual range over scanned physical chunks (see the comment above).  false: the VMM
 // API is not usable here (nothing is left allocated), the caller falls back to the candidates policy.
 //
-// Two kinds of memory make a fast write target (tools/microbench/placement_study.hip vmm / vmm_il,
+// Two kinds of memory make a fast write target (round 2's tools/microbench/placement_study.hip (git history) vmm / vmm_il,
 // profiles/r02_vmm_mixed_assembly.txt, r02_vmm_interleave.txt): MIXED chunks (pure writes 20 % faster; copy into them 1.30 ms
 // per 4 GiB + 4 GiB), and ORDINARY chunks of two different memory classes INTERLEAVED handle by handle (8 MiB): 1.32 ms,
 // against 1.55 ms into ordinary memory of one class -- what mixed memory is, made by hand.  Interleaving chunks of the SAME

@@ -473,6 +473,9 @@ __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__
 #ifndef SMFFT_RC_MULTIPLE_FUSED
 #define SMFFT_RC_MULTIPLE_FUSED 1
 #endif
+#ifndef SMFFT_RC_MULTIPLE_PLANAR
+#define SMFFT_RC_MULTIPLE_PLANAR 1      // 0: the float2-image form below (A/B)
+#endif
 template <int L, int DIR>
 __device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, float2* s) {
     using G = Geometry<L>;
@@ -517,6 +520,46 @@ __device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__
         }
 #endif
         lds_to_tile<L, false>(d_output + first * L, s, first, nSlots);
+    }
+}
+
+// R2C / C2R in-LDS path on the planar engine: the complex transform of length L as in c2c_multiple_body_planar (reorder
+// roles, registers forwarded from one application to the next) with the Hermitian split / merge done on the registers,
+// the partners read from the stored image.  Per application: the C2C's LDS traffic + 32 dword reads.
+template <int L, int DIR>
+__device__ __forceinline__ void r2c_c2r_multiple_body_planar(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, float* planes) {
+    using G = Geometry<L>;
+    PlanarEngine<L, DIR, 1> eng;
+    eng.init(threadIdx.x, planes);
+    eng.init_hermitian();
+    const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long first = (long)tile * G::kCompactFfts;
+        planar_sync<G::kMultiWave>();
+        tile_to_planes<L, DIR, 1>(d_input + first * L, planes, first, nSlots);
+        planar_sync<G::kMultiWave>();
+        float2 r[16];
+        eng.image_load_own(r, planes);
+        for (int f = 0; f < nreuses; ++f) {
+            if (DIR == 1) {                          // C2R: merge (partners from the image: the tile, or the previous result), then the inverse transform
+                eng.hermitian_apply(r, planes);
+                planar_sync<G::kMultiWave>();        // every partner read precedes the exchanges' stores
+            }
+            eng.natural_to_slots(r);
+            eng.transform_from_pass1_slots(r, planes);
+            planar_sync<G::kMultiWave>();
+            eng.image_store(r);
+            planar_sync<G::kMultiWave>();
+            if (DIR == 0) {                          // R2C: the forward transform's result is in the image; split it in registers
+                eng.hermitian_apply(r, planes);
+                planar_sync<G::kMultiWave>();
+            }
+        }
+        if (DIR == 0) {                              // the image holds the last transform's output: replace it by the split result
+            eng.image_store(r);
+            planar_sync<G::kMultiWave>();
+        }
+        planes_to_tile<L, DIR, 1>(d_output + first * L, planes, first, nSlots);
     }
 }
 
@@ -642,6 +685,12 @@ __global__ void __launch_bounds__(256) FFT_GPU_R2C_C2R_external(const float2* d_
 }
 template <class const_params, class const_direction>
 __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_length) FFT_GPU_R2C_C2R_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
-    __shared__ float2 s_input[smfft::Geometry<const_params::fft_length>::kCompactLds];
-    smfft::r2c_c2r_multiple_body<const_params::fft_length, const_direction::fft_direction>(d_input, d_output, nSlots, nreuses, s_input);
+    constexpr int L = const_params::fft_length;
+    if constexpr (SMFFT_PLANAR_SIZES(L) && SMFFT_RC_MULTIPLE_PLANAR) {
+        __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<L, 1>::kLdsFloats];
+        smfft::r2c_c2r_multiple_body_planar<L, const_direction::fft_direction>(d_input, d_output, nSlots, nreuses, s_planes);
+    } else {
+        __shared__ float2 s_input[smfft::Geometry<L>::kCompactLds];
+        smfft::r2c_c2r_multiple_body<L, const_direction::fft_direction>(d_input, d_output, nSlots, nreuses, s_input);
+    }
 }

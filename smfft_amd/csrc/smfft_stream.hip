@@ -189,7 +189,7 @@ int smfft_host_transform(int family, const void* h_input, void* h_output, int FF
     // Both buffers pinned: no copies at all.  The external kernel reads the host buffer and writes the host buffer
     // directly over PCIe -- loads and stores of thousands of waves in flight use the link in both directions at once:
     // 97-98 GB/s in + out for the config-2 batch (49 GB/s each way; H2D or D2H alone 56-57) against 68-75 GB/s for the slab
-    // pipeline below, whose DMA copies do not overlap that well (tools/host_stream_probe.py, profiles/r02_host_stream.txt).
+    // pipeline below, whose DMA copies do not overlap that well (round 2's tools/host_stream_probe.py (git history), profiles/r02_host_stream.txt).
     // SMFFT_HOST_ZERO_COPY=0 keeps the slab pipeline.  (For pageable memory the same kernel over the lanes' pinned bounce
     // buffers measured no better than the DMA pipeline -- 62-75 against 69 GB/s: the host-side memcpys bound it.)
     e = getenv("SMFFT_HOST_ZERO_COPY");
@@ -208,7 +208,7 @@ int smfft_host_transform(int family, const void* h_input, void* h_output, int FF
         }
         (void)hipGetLastError();
     }
-    // measured on the config-2 batch (tools/host_stream_probe.py): pageable memory needs the 8 lanes' parallel
+    // measured on the config-2 batch (round 2's tools/host_stream_probe.py (git history)): pageable memory needs the 8 lanes' parallel
     // memcpys (1 lane 328 ms, 2: 175, 4: 121, 8: 118); pinned memory is best with 2 (120 ms; 8: 130, 16: 289)
     e = getenv("SMFFT_HOST_LANES");
     int nlanes = lanes > 0 ? lanes : (e ? atoi(e) : (job.bounce ? 8 : 2));

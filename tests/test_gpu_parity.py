@@ -1070,7 +1070,7 @@ def test_harness_per_length_readme_batch(sm, n):
         pytest.skip("harness not built")
     p = subprocess.run([exe, str(n), str((1 << 29) // n), "2", "0", "1"], capture_output=True, text=True, timeout=900, env=dict(os.environ, SMFFT_SEED="11"))
     assert p.returncode == 0, p.stdout + p.stderr
-    # N >= 2048 with U[0,1) data: the reference's metric flags fp32 round-off of the DC-heavy spectrum (tools/metric_probe.py);
+    # N >= 2048 with U[0,1) data: the reference's metric flags fp32 round-off of the DC-heavy spectrum;
     # the gate there is that the program ran and compared, the stated tolerance is checked by the parity tests
     if n <= 1024:
         assert "PASSED" in p.stdout and "FAILED" not in p.stdout, p.stdout
@@ -1080,7 +1080,7 @@ def test_harness_per_length_readme_batch(sm, n):
 def test_harness_noreorder_is_verified(sm, n):
     """reorder = 0 upstream prints "no verification" (CT/FFT.c:162); the harness here checks it against the vendor FFT of the
     bit-reversed input (S2).  (N <= 1024: above that the reference's max_error = 1e-4 metric flags fp32 round-off itself on
-    U[0,1) data, tools/metric_probe.py; the stated tolerance is checked by the parity tests at every length.)"""
+    U[0,1) data; the stated tolerance is checked by the parity tests at every length.)"""
     import os
     import subprocess
     exe = os.path.join(os.path.dirname(__file__), "..", "harness", "FFT_CooleyTukey_C2C.exe")

@@ -36,7 +36,12 @@ for name in ("bench.json", "bench_under_rocprof.json", "configs.json", "mult_sat
         shutil.copy(os.path.join(src, name), f"profiles/{tag}_{name}")
 
 # 2. HBM traffic
-out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separate pass, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline",
+try:
+    import subprocess
+    HEAD = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except Exception:
+    HEAD = None
+out = {"commit": HEAD, "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separate pass, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline",
        "units": "FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE reports 1/2 of a coalesced streaming read (MI355X_MICROARCH.md, HBM)",
        "calibration": {"note": "tools/microbench/membw 268435456 under the same two passes: tile8 = the engine's access shape (8 B/lane, 512 B per wave instruction) moves 2097152 KiB each way"},
        "kernels": {}}
