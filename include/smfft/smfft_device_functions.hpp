@@ -79,9 +79,9 @@ __device__ __forceinline__ void hermitian_pass(float2* sf, int u) {
 }
 
 // In place on LDS, natural layout (device-function form; RC:269-344).
-template <int L, int DIR, bool PAD>
-__device__ __forceinline__ void r2c_c2r_lds_inplace(float2* s, const Engine<L, DIR, 1, PAD>& eng, int stride = Geometry<L, PAD>::SF) {
-    using G = Geometry<L, PAD>;
+template <int L, int DIR>
+__device__ __forceinline__ void r2c_c2r_lds_inplace(float2* s, const Engine<L, DIR, 1>& eng, int stride = Geometry<L>::SF) {
+    using G = Geometry<L>;
     float2* sf = s + eng.fft * stride;
     if (DIR == 0) {
         fft_lds_inplace(s, eng, stride);
@@ -262,7 +262,7 @@ __device__ void do_FFT_Stockham_R2C_C2R(float2* s_input) {
     require_tiled_block();
     Engine<const_params::fft_length, const_direction::fft_direction, 1> eng;
     eng.init(threadIdx.x);
-    r2c_c2r_lds_inplace<const_params::fft_length, const_direction::fft_direction, true>(s_input, eng);
+    r2c_c2r_lds_inplace<const_params::fft_length, const_direction::fft_direction>(s_input, eng);
 }
 
 }  // namespace tiled

@@ -26,9 +26,8 @@
 // do_FFT_Stockham_*), in the reference's own launch shape and in the engine's tiled shape, are in
 // smfft_device_functions.hpp; include/smfft_device.hpp pulls in everything a user kernel needs.
 //
-// LDS layout the engine works on: every FFT owns a REGION of Geometry::SF float2 (17N/16 with padding,
-// N without); its data sit at region[0 .. N) in natural order before and after a transform, the rest
-// of the region is exchange space.
+// LDS layout the engine works on: every FFT owns a REGION of Geometry::SF = 17N/16 float2; its data sit at
+// region[0 .. N) in natural order before and after a transform, the rest of the region is exchange space.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "SM_FFT_parameters.hpp"
@@ -45,10 +44,7 @@ static constexpr TwiddleValue twiddle_values[4096] = {
 };
 
 // ------------------------------------------------------------------------------------------------
-// PAD = false: the exchange layouts without their bank-conflict padding, so that a transform fits
-// into exactly N float2 of LDS (the reference's Stockham device functions get no more than that from
-// their callers, ST:319); slower, used only by the reference-shaped Stockham entry points.
-template <int N, bool PAD = true>
+template <int N>
 struct Geometry {
     static_assert(N >= 32 && N <= 4096 && (N & (N - 1)) == 0, "N must be a power of two in [32, 4096]");
     static constexpr int T = N / 16;                      // threads per FFT
@@ -57,10 +53,10 @@ struct Geometry {
     static constexpr int T1 = N / R1;                     // butterflies in pass 1
     static constexpr int B1 = 16 / R1;                    // pass-1 butterflies per thread
     static constexpr int BM = 16 / RM;                    // middle butterflies per thread
-    static constexpr int S1 = T1 + (PAD ? T1 / 16 : 0);   // row stride of exchange 1 (q1-major)
-    static constexpr int S2 = T + (PAD ? 1 : 0);          // row stride of the last layout (t-major)
-    static constexpr int S0 = PAD ? 17 : 16;              // row stride of the two-pass sizes' only layout
-    static constexpr int SF = PAD ? 17 * (N / 16) : N;    // LDS region of one FFT (float2)
+    static constexpr int S1 = T1 + T1 / 16;             // row stride of exchange 1 (q1-major)
+    static constexpr int S2 = T + 1;                      // row stride of the last layout (t-major)
+    static constexpr int S0 = 17;                          // row stride of the two-pass sizes' only layout
+    static constexpr int SF = 17 * (N / 16);               // LDS region of one FFT (float2)
     static constexpr bool kMultiWave = (T > 64);
     // N = 512 / 1024: exchange 1 is a transpose between the lane's row bits (lane >> 4) and the top
     // register-index bits, done in registers with v_permlane16_swap / v_permlane32_swap: no LDS.
@@ -359,10 +355,9 @@ struct Twiddles {
 // ------------------------------------------------------------------------------------------------
 // The engine.  One instance per thread; tid = threadIdx.x in a 256-thread workgroup.
 // ------------------------------------------------------------------------------------------------
-template <int N, int DIR, int REORDER, bool PAD = true>
+template <int N, int DIR, int REORDER>
 struct Engine {
-    using G = Geometry<N, PAD>;
-    static_assert(PAD || REORDER, "the unpadded engine exists for the natural-order (Stockham) entry points only");
+    using G = Geometry<N>;
     static constexpr int T = G::T, R1 = G::R1, RM = G::RM, T1 = G::T1, B1 = G::B1, BM = G::BM;
     static constexpr int S1 = G::S1, S2 = G::S2, S0 = G::S0, SF = G::SF;
     static constexpr int E_BITS = ilog2c(N), T_BITS = ilog2c(T), R1_BITS = ilog2c(R1), B1_BITS = ilog2c(B1);
@@ -718,9 +713,9 @@ struct Engine {
 // device functions in smfft_device_functions.hpp.  `stride` = float2 distance between the FFTs the
 // workgroup holds (Geometry::SF in the tiled kernels, N where FFTs are packed contiguously).
 // ------------------------------------------------------------------------------------------------
-template <int N, int DIR, int REORDER, bool PAD>
-__device__ __forceinline__ void fft_lds_inplace(float2* s, const Engine<N, DIR, REORDER, PAD>& eng, int stride = Geometry<N, PAD>::SF) {
-    using G = Geometry<N, PAD>;
+template <int N, int DIR, int REORDER>
+__device__ __forceinline__ void fft_lds_inplace(float2* s, const Engine<N, DIR, REORDER>& eng, int stride = Geometry<N>::SF) {
+    using G = Geometry<N>;
     float2* sf = s + eng.fft * stride;
     float2 r[16];
     eng.load_lds(r, sf);

@@ -51,7 +51,7 @@ __device__ __forceinline__ void addtid_store4(unsigned m0, float2 a, float2 b, f
 // Row placement.  A row holds TW dwords (one per thread of the workgroup); row j of an exchange starts at
 // TW * rank(j) + 4 * q[j] dwords, rank = the row's place in the order of the residues q (so rows never overlap and a plane
 // is at most 16 * TW + 60 dwords).  Only q[j] (the row's base / 4 mod 16) matters for bank conflicts; the residues per
-// length and exchange are the ones tools/soa_model.py found conflict free (N = 4096: 2-way on three of its reads, see there).
+// length and exchange are the ones tools/soa_model.py found conflict free.
 struct RowTable {
     int base[16];
     int span;
@@ -76,16 +76,16 @@ template <int N, int REORDER>
 constexpr int row_residue(RowKind kind, int j) {
     switch (kind) {
         case RowKind::image:    // read by the bit-reversed loads of the no-reorder variants (lane linear in the reorder variants)
-            return N == 32 ? 8 * bit_of(j, 3) : N == 64 ? 4 * (j >> 2) : N == 128 ? bit_of(j, 2) + 8 * bit_of(j, 3) : N == 256 ? j : N == 512 ? bit_of(j, 0) + 2 * bit_of(j, 2) + 8 * bit_of(j, 3) : N == 4096 ? 2 * bit_of(j, 3) : (j >> 2);
+            return N == 32 ? 8 * bit_of(j, 3) : N == 64 ? 4 * (j >> 2) : N == 128 ? bit_of(j, 2) + 8 * bit_of(j, 3) : N == 256 ? j : N == 512 ? bit_of(j, 0) + 2 * bit_of(j, 2) + 8 * bit_of(j, 3) : N == 4096 ? 4 * bit_of(j, 3) : (j >> 2);
         case RowKind::x1:       // after pass 1 (three-pass lengths)
-            return N == 2048 ? bit_of(j, 1) : N == 4096 ? bit_of(j, 0) : 0;      // (N = 512 exchanges in registers)
+            return N == 2048 ? bit_of(j, 1) : N == 4096 ? 2 * bit_of(j, 0) : 0;  // (N = 512 exchanges in registers)
         default:                // in front of the last pass
             if (N == 32) return 8 * bit_of(j, 0);
             if (N == 64) return 4 * (j & 3);
             if (N == 128) return bit_of(j, 0) + 8 * bit_of(j, 1);
             if (N == 256) return (j & 3) + 8 * bit_of(j, 3);
-            if (REORDER && N != 512) return (j & 3) + 8 * bit_of(j, 3);           // klow = pass-1 role
-            return N == 512 ? bit_of(j, 0) + 2 * bit_of(j, 1) + 8 * bit_of(j, 2) : N == 1024 ? (j >> 2) : N == 2048 ? bit_of(j, 0) + 2 * bit_of(j, 3) : bit_of(j, 0);
+            if ((REORDER && N != 512) || N == 4096) return (j & 3) + 8 * bit_of(j, 3);   // klow = pass-1 role
+            return N == 512 ? bit_of(j, 0) + 2 * bit_of(j, 1) + 8 * bit_of(j, 2) : N == 1024 ? (j >> 2) : bit_of(j, 0) + 2 * bit_of(j, 3);
     }
 }
 template <int N, int REORDER>
@@ -140,10 +140,19 @@ struct PlanarEngine {
     // N = 512 (RM = 2): exchange 1 moves data between two threads only -- sixteen v_permlane16_swap (Engine::exchange1_registers)
     // measured faster than a third trip through LDS (profiles/r03_ab_planar_all.txt); its roles are the register engine's (t1 = v)
     static constexpr bool kRegisterX1 = (RM == 2);
-    static constexpr bool kForward = REORDER;   // the last-pass thread computes klow = its own pass-1 role
-    // no reorder, RM >= 8: the RM threads that share t2 take r2 in bit-reversed order, so that the blocks of a row their
-    // bit-reversed loads touch are neighbours (conflict free for N = 2048, 2-way instead of 4-way for N = 4096)
-    static constexpr bool kReverseR2 = !REORDER && RM >= 8;
+    // N = 4096 (RM = 16: sixteen consecutive threads share t2, so eight lanes of a ds_read_b128 group would read blocks of ONE
+    // row -- 2-way conflicts no row shift can undo; round 3's first form had them on three reads, 384 of 1541 LDS cycles per FFT):
+    //  * exchange 1: a lane reads the four quads of its run in an order rotated by rot = t2 >> 3.  Its registers then hold the
+    //    radix-16 input cyclically shifted by 4*rot, i.e. the output times (-+i)^(q2*rot) -- folded into the middle twiddle at set-up;
+    //  * the last pass computes klow = the thread's pass-1 role in BOTH orderings (every lane of a read group then reads a
+    //    different row); the no-reorder image read, whose sixteen elements are then 16 dwords apart, is sixteen ds_read_b32 per
+    //    plane: conflict free at half the rate = what the conflicted ds_read_b128 cost.
+    static constexpr bool kRotatedX1 = (RM == 16);
+    static constexpr bool kRoleOutputs = REORDER || RM == 16;   // the last-pass thread computes klow = its own pass-1 role
+    static constexpr bool kForward = kRoleOutputs;
+    // no reorder, N = 2048: the RM threads that share t2 take r2 in bit-reversed order, so that the blocks of a row their
+    // bit-reversed loads touch are neighbours (conflict free)
+    static constexpr bool kReverseR2 = !REORDER && RM == 8;
     static constexpr int r2_of(int m) {
         if (!kReverseR2) return m;
         int r = 0;
@@ -182,15 +191,28 @@ struct PlanarEngine {
         t1 = pass1_role(v);
         t2 = v % 16;
         a = v / 16;
-        klow = (kThreePass && kForward) ? t1 : v;
+        klow = (kThreePass && kRoleOutputs) ? t1 : v;
         typedef __attribute__((address_space(3))) const float lds_float;
         m0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_float*)planes + 4u * (tid & ~63));
         tw.init(t1, t2);
+        if constexpr (kRotatedX1) {
+            const bool rot = (t2 >> 3) & 1;
+#pragma unroll
+            for (int q2 = 1; q2 < RM; ++q2) {
+                const float2 w = tw.wm[q2];
+                // w * (-+i)^q2   (forward: -i, inverse: +i)
+                const float2 r1 = DIR ? make_float2(-w.y, w.x) : make_float2(w.y, -w.x), r3 = make_float2(-r1.x, -r1.y);
+                const float2 turned = (q2 & 3) == 0 ? w : (q2 & 3) == 1 ? r1 : (q2 & 3) == 2 ? make_float2(-w.x, -w.y) : r3;
+                tw.wm[q2] = rot ? turned : w;
+            }
+        }
         const PlanarRows<N, REORDER>& rows = planar_rows<N, REORDER>;
         // bit-reversed load: the sixteen contiguous elements p = 16 * rho + i of the natural image, rho = rev_T(t1):
         // element p is dword fft * T + p % T of row p / T
         const int rho = (int)(__brev((unsigned)t1) >> (32 - T_BITS));
-        if constexpr (T >= 16) {
+        if constexpr (kRotatedX1) {
+            off_image[0] = rows.image.base[rho / 16] + fft * T + (rho % 16);   // element 16 * (rho % 16) + i sits at the dword of role ... + i: 16 * i + rho % 16
+        } else if constexpr (T >= 16) {
             off_image[0] = rows.image.base[rho / (T / 16)] + fft * T + 16 * (rho % (T / 16));
         } else {
 #pragma unroll
@@ -256,7 +278,11 @@ struct PlanarEngine {
     }
     __device__ __forceinline__ void image_load_bitrev(float2 (&r)[16], const float* planes) const {
         float2 e[16];
-        if constexpr (T >= 16) {
+        if constexpr (kRotatedX1) {
+            const float* p = planes + off_image[0];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) e[i] = make_float2(p[16 * i], p[P::kPlane + 16 * i]);
+        } else if constexpr (T >= 16) {
             load_run<16>(e, planes + off_image[0]);
         } else {
 #pragma unroll
@@ -295,6 +321,21 @@ struct PlanarEngine {
     // middle thread (t2, a): r[c*RM + r2] = element (t2 + 16*r2, q1 = a*BM + c) = row a*BM + c, dwords RM*t2 + m, r2 = r2_of(m)
     __device__ __forceinline__ void x1_load(float2 (&r)[16], const float* planes) const {
         const float* p = planes + off_x1;
+        if constexpr (kRotatedX1) {
+            // quad (k + rot) % 4 of the run at step k: p0 + 4k for k < 3, and for k = 3 the quad that is left
+            const int rot = (t2 >> 3) & 1;
+            const float* p0 = p + 4 * rot;
+            const float* p3 = p + (rot ? 0 : 12);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float* q = (k < 3) ? p0 + 4 * k : p3;
+                const f4v re = *reinterpret_cast<const f4v*>(q);
+                const f4v im = *reinterpret_cast<const f4v*>(q + P::kPlane);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) r[4 * k + m] = make_float2(re[m], im[m]);
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < BM; ++c) {
             float2 e[RM];

@@ -470,9 +470,6 @@ __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__
     }
 }
 
-#ifndef SMFFT_RC_MULTIPLE_FUSED
-#define SMFFT_RC_MULTIPLE_FUSED 1
-#endif
 #ifndef SMFFT_RC_MULTIPLE_PLANAR
 #define SMFFT_RC_MULTIPLE_PLANAR 1      // 0: the float2-image form below (A/B)
 #endif
@@ -481,17 +478,14 @@ __device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__
     using G = Geometry<L>;
     Engine<L, DIR, 1> eng;
     eng.init(threadIdx.x);
-#if SMFFT_RC_MULTIPLE_FUSED
     HermitianRegisters<L, DIR> herm;
     herm.init(threadIdx.x);
-#endif
     const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long first = (long)tile * G::kCompactFfts;
         fft_sync<G::kMultiWave>();
         tile_to_lds<L, false>(d_input + first * L, s, first, nSlots);
         fft_sync<G::kMultiWave>();
-#if SMFFT_RC_MULTIPLE_FUSED
         // The split (R2C, after the FFT) / merge (C2R, before it) of an application is fused into the LOAD of the transform
         // that follows it: the partner x[L - i] is read from the resident data next to x[i] and the pair is combined in
         // registers -- two LDS round trips per application instead of three (the LDS-resident pass reads and re-writes the
@@ -513,12 +507,6 @@ __device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__
             hermitian_pass<L, 0>(sf, u);
             fft_sync<G::kMultiWave>();
         }
-#else
-        for (int f = 0; f < nreuses; ++f) {
-            r2c_c2r_lds_inplace<L, DIR, true>(s, eng);
-            fft_sync<G::kMultiWave>();
-        }
-#endif
         lds_to_tile<L, false>(d_output + first * L, s, first, nSlots);
     }
 }
