@@ -28,7 +28,7 @@ B64_GROUPS = [list(range(0, 32)), list(range(32, 64))]
 def conflict_cycles(addrs, width):
     """addrs: dword address per lane (64 lanes, None = inactive) of one read instruction of `width` dwords per lane.
     Returns extra LDS cycles (0 = conflict free)."""
-    groups = B128_GROUPS if width == 4 else B64_GROUPS
+    groups = B128_GROUPS if width == 4 else B64_GROUPS     # ds_read_b64 / b32: two groups of 32 lanes
     nbanks = 64 if width >= 2 else 32
     extra = 0
     for g in groups:
@@ -211,7 +211,96 @@ def exchanges(N):
     return G, ex
 
 
+def bit(j, b):
+    return (j >> b) & 1
+
+
+# The residues include/smfft/smfft_planar.hpp uses (row_residue there, in closed form), per length and exchange, with the
+# pass-1 role map of that length: what tests/test_planar_layout_model.py checks to be conflict free in this model.
+# N = 512 exchanges 1 in registers (roles = positions); N = 2048 no reorder takes r2 bit-reversed; N = 4096 reads exchange 1
+# in a per-lane rotated order, computes klow = pass-1 role in both orderings and reads its bit-reversed image as dwords.
+HEADER_RESIDUES = {
+    64: {"image": [4 * (j >> 2) for j in range(16)], "last": [4 * (j & 3) for j in range(16)]},
+    128: {"image": [bit(j, 2) + 8 * bit(j, 3) for j in range(16)], "last": [bit(j, 0) + 8 * bit(j, 1) for j in range(16)]},
+    256: {"image": [j for j in range(16)], "last": [(j & 3) + 8 * bit(j, 3) for j in range(16)]},
+    512: {"image": [bit(j, 0) + 2 * bit(j, 2) + 8 * bit(j, 3) for j in range(16)], "x2": [bit(j, 0) + 2 * bit(j, 1) + 8 * bit(j, 2) for j in range(16)]},
+    1024: {"image": [j >> 2 for j in range(16)], "x1": [0] * 16, "x2": [j >> 2 for j in range(16)], "x2_reorder": [(j & 3) + 8 * bit(j, 3) for j in range(16)]},
+    2048: {"image": [j >> 2 for j in range(16)], "x1": [bit(j, 1) for j in range(16)], "x2": [bit(j, 0) + 2 * bit(j, 3) for j in range(16)],
+           "x2_reorder": [(j & 3) + 8 * bit(j, 3) for j in range(16)]},
+    4096: {"image": [4 * bit(j, 3) for j in range(16)], "x1": [2 * bit(j, 0) for j in range(16)], "x2_reorder": [(j & 3) + 8 * bit(j, 3) for j in range(16)]},
+}
+
+
+def header_conflicts(N):
+    """extra LDS cycles of every read set of length N with the header's residues and role maps: {name: cycles}"""
+    G = Geometry(N)
+    waves = G.TW // 64
+    res = HEADER_RESIDUES[N]
+    out = {}
+
+    def role_plain(v):
+        return (v // G.RM) + 16 * (v % G.RM) if G.RM > 1 else v
+
+    def role_noreorder(v):
+        if N == 512:
+            return v
+        if N == 2048:
+            return (v // G.RM) + 16 * rev(v % G.RM, ilog2(G.RM))
+        return role_plain(v)
+
+    def total(q, instrs):
+        bases = bases_from_residues(G.TW, q)
+        return sum(conflict_cycles(a, w) for a, w in instrs(bases))
+
+    global pass1_role
+    saved = pass1_role
+    try:
+        pass1_role = lambda G_, v: role_noreorder(v)       # noqa: E731  (the no-reorder kernels' map)
+        if N == 4096:
+            def image(bases):      # sixteen ds_read_b32 per plane: element 16 * (rho % 16) + i at dword 16 * i + rho % 16 of row rho / 16
+                ins = []
+                for w in range(waves):
+                    for i in range(16):
+                        addrs = []
+                        for lane in range(64):
+                            rho = rev(role_plain(64 * w + lane), 8)
+                            addrs.append(bases[rho // 16] + 16 * i + rho % 16)
+                        ins.append((addrs, 1))
+                return ins
+            out["image (dword reads)"] = total(res["image"], image)
+
+            def x1(bases):         # quad (k + rot) % 4 of the run at step k, rot = t2 >> 3
+                ins = []
+                for w in range(waves):
+                    for k in range(4):
+                        addrs = []
+                        for lane in range(64):
+                            v = 64 * w + lane
+                            t2, a = v % 16, v // 16
+                            addrs.append(bases[a] + 16 * t2 + 4 * ((k + (t2 >> 3)) & 3))
+                        ins.append((addrs, 4))
+                return ins
+            out["x1 (rotated)"] = total(res["x1"], x1)
+        else:
+            out["image"] = total(res["image"], lambda b: [i for w in range(waves) for i in image_bitrev_reads(G, b, wave=w)])
+            if "x1" in res:
+                out["x1"] = total(res["x1"], lambda b: [i for w in range(waves) for i in x1_reads(G, b, wave=w)])
+        if "last" in res:
+            out["last"] = total(res["last"], lambda b: [i for w in range(waves) for i in last_reads_two_pass(G, b, wave=w)])
+        if "x2" in res:
+            out["x2 (klow = position)"] = total(res["x2"], lambda b: [i for w in range(waves) for i in x2_reads(G, b, lambda v: v, wave=w)])
+        if "x2_reorder" in res:
+            out["x2 (klow = role)"] = total(res["x2_reorder"], lambda b: [i for w in range(waves) for i in x2_reads(G, b, role_plain, wave=w)])
+    finally:
+        pass1_role = saved
+    return out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--header":
+        for N in sorted(HEADER_RESIDUES):
+            print(N, header_conflicts(N))
+        return
     sizes = [int(a) for a in sys.argv[1:]] or [128, 256, 512, 1024, 2048, 4096]
     for N in sizes:
         G, ex = exchanges(N)
