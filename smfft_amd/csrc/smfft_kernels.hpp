@@ -5,8 +5,10 @@
 //   FFT_GPU_external/multiple<P>      ST/FFT-GPU-32bit-Stockham.cu:243-278
 //   FFT_GPU_R2C_C2R_external/multiple<P,D>  RC/FFT-GPU-32bit-Stockham.cu:349-384
 //
-// Every kernel uses 256-thread workgroups that own a tile of 4096 float2 (= 4096/N FFTs) and
-// P::fft_sm_required = 4352 float2 of LDS (34 KiB -> 4 workgroups = 16 waves per CU).  For
+// The EXTERNAL kernels use 256-thread workgroups that own a tile of 4096 float2 (= 4096/N FFTs) and
+// P::fft_sm_required = 4352 float2 of LDS (34 KiB -> 4 workgroups = 16 waves per CU), on the float2 engine
+// (smfft_engine.hpp).  The IN-LDS (`multiple`) kernels use compact workgroups (one wave per 1024 elements, one FFT per
+// workgroup above) on the planar engine (smfft_planar.hpp; N = 32: the float2 engine).  For
 // N >= 256 the external kernels do not stage through LDS on the way in or out: pass 1 loads
 // straight from global memory into registers (each wave instruction reads 512 contiguous bytes
 // for N >= 1024) and the last pass stores straight from registers, so the only LDS traffic is the
@@ -211,7 +213,8 @@ __device__ __forceinline__ void lds_to_tile(float2* __restrict__ g, const float2
     }
 }
 
-// C2C, multiple: the first nSlots FFTs are loaded once, transformed nreuses (= NREUSES = 100 in the
+// C2C, multiple, on the float2 engine (N = 32; every length with SMFFT_PLANAR=0 -- the A/B baseline of the planar engine):
+// the first nSlots FFTs are loaded once, transformed nreuses (= NREUSES = 100 in the
 // benchmark; a kernel argument so the tests can run 1, 2 and 4 applications) times in LDS, stored once.
 // Every application reads its input from LDS and writes its result to LDS (the device function's contract);
 // what the kernel chooses is the IMAGE the data are kept in between applications: natural order for the reorder
