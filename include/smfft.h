@@ -107,7 +107,11 @@ void* smfft_host_malloc(unsigned long long bytes); /* pinned host memory (hipHos
 int smfft_host_free(void* h_ptr);
 void smfft_host_pipeline_release(void);
 
-/* ---- tuning / introspection ------------------------------------------------------------------- */
+/* ---- tuning / introspection -------------------------------------------------------------------
+ * The setters act on the CALLING HOST THREAD (upstream: process globals and one thread, CT:15): device, grid cap,
+ * applications per slot and pacing belong to the thread, so that one thread per GPU can drive the unchanged prototypes
+ * concurrently; a value a thread has not set falls back to the process default (SMFFT_DEVICE, SMFFT_GRID_CAP, SMFFT_PACING,
+ * read once).  The lanes of smfft_host_transform inherit the state of the thread that called it. */
 void smfft_set_grid_cap(int max_workgroups); /* default 12288 (persistent, grid-strided); 0 = one workgroup per tile */
 int smfft_get_grid_cap(void);
 /* Applications of the transform per slot in the `multiple` kernels.  The benchmark value is
@@ -132,15 +136,16 @@ void* smfft_malloc(unsigned long long bytes);
  * in 8 MiB handles, 1 GiB at a time, and each GiB is classified by two write-only passes (mixed or not; same or other
  * class than the first ordinary GiB).  When mixed memory plus equal parts of two classes cover the output (and six GiB
  * further), the candidate outputs -- mixed memory first, interleaved classes only -- are each timed as the target of a
- * copy from the real input over the whole pair and the best is kept; while it is not good (copy within 2.22 x the input's
- * read time) eight more GiB are scanned and the candidates tried again, up to four times and inside the budgets -- a quarter
- * of the free memory (SMFFT_PAIR_BUDGET_FRAC), 2 s (SMFFT_PAIR_BUDGET_MS); whatever is missing then comes from ordinary
- * chunks.  Typically 10-25 GiB and 80-550 ms for a 4 GiB output (on the system runtime up to 1-2 s).  The
+ * copy from the real input over the whole pair and the best is kept; while it is not good (a pass into it beating the same
+ * pass into ordinary memory of the same scan by the margin mixed memory shows on this device) eight more GiB are scanned and the candidates tried again, up to four times and inside the budgets -- a quarter
+ * of the free memory (SMFFT_PAIR_BUDGET_FRAC; never more than what is free after the pair itself less 1 GiB), 2 s
+ * (SMFFT_PAIR_BUDGET_MS); whatever is missing then comes from ordinary chunks.  Typically 10-25 GiB and 80-550 ms for a 4 GiB output (on the system runtime up to 1-2 s).  The
  * chosen handles are blended evenly into one virtual range (an ordinary device pointer for the caller), the rest is
  * released at once.  Buffers are exactly `bytes` long (the output's range is rounded up to 8 MiB).
  * SMFFT_PAIR_POLICY=candidates: whole hipMalloc blocks timed as copy targets inside the same budgets
  * (also the fallback where the virtual-memory API is unavailable); =plain: two plain allocations.  Nothing is kept after
- * smfft_free_pair unless SMFFT_PAIR_CACHE=1.  Requests below 256 MiB are served plainly.
+ * smfft_free_pair unless SMFFT_PAIR_CACHE=1 (pairs taken through smfft_malloc_pair_for_wrapper are kept for the next such call).
+ * Every virtual address range the allocator has used stays reserved and unmapped afterwards (smfft_va_window).  Requests below 256 MiB are served plainly.
  * The L3 wrappers take their two buffers from this call; SMFFT_WRAPPER_PLACEMENT=0: two plain allocations as upstream (CT:850-853).
  * Release with smfft_free_pair(d_read) (an error for a pointer this call did not return). */
 int smfft_malloc_pair(unsigned long long bytes, void** d_read, void** d_written);
