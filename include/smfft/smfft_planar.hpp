@@ -34,6 +34,9 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 
 // ds_write_addtid_b32 x 8: four elements (re, im).  M0 holds the wave's base (plane 0 + 4 * 64 * wave); an SALU write of
 // M0 needs one wait state before an LDS "add-TID" instruction reads it (the assembler does not see into inline assembly).
+// M0 is written in EVERY block and not declared clobbered (LLVM treats it as reserved: a clobber would only draw a warning):
+// hipcc sets M0 itself right before each of its own uses of it, and a kernel built on this engine must not contain the few
+// constructs whose M0 set-up it may share between uses (LDS-DMA loads, GWS, indirect register indexing) -- none of ours does.
 template <int O0, int O1, int O2, int O3, int P>
 __device__ __forceinline__ void addtid_store4(unsigned m0, float2 a, float2 b, float2 c, float2 d) {
     asm volatile(
