@@ -11,9 +11,10 @@
 //   * addtid stores are lane linear (register j of thread tid -> row j, dword tid), so all freedom is in WHO READS WHAT:
 //     every exchange is arranged so that a reader's sixteen values are runs of contiguous dwords of few rows
 //     (ds_read_b128 / ds_read_b64: the full 256 B/clk) and the rows are shifted against each other so that those reads
-//     are bank-conflict free (tools/soa_model.py emulates the choreography and searches the shifts).
-//   * With exchanges this cheap, exchange 1 of N = 512 / 1024 goes through LDS as well: the 32 v_permlane*_swap of the
-//     register form were 124 ns of the 718 ns an N = 1024 application took per SIMD.
+//     are bank-conflict free (tools/soa_model.py states every read pattern, counts conflicts with the gfx950 lane-group
+//     rules and searched the shifts; tests/test_planar_layout_model.py ties this header's tables to it).
+//   * With exchanges this cheap, exchange 1 of N = 1024 goes through LDS as well: the 32 v_permlane*_swap of the
+//     register form were 124 ns of the 718 ns an N = 1024 application took per SIMD.  (N = 512 keeps its 16 swaps.)
 //
 // Thread positions and roles.  A compact workgroup has TW = max(64, T) threads, T = N / 16 per FFT; thread tid is at
 // position v = tid % T of FFT tid / T, and every store puts register j at dword tid of row j.
@@ -23,7 +24,9 @@
 //     last        output index klow = v (no reorder: the stored result is lane linear in klow, which the bit-reversed
 //                 read of the next application needs) or klow = pass-1 role of v (reorder: the registers a thread ends
 //                 with are the ones it starts the next application with -- forwarded, never re-loaded)
-//   two-pass sizes (N = 128, 256): pass-1 role t1 = v, last pass q1 = v.
+//     exceptions  N = 512: exchange 1 in registers, roles = positions; N = 2048 no reorder: r2 bit-reversed; N = 4096: rotated
+//                 exchange-1 reads and klow = role in both orderings (PlanarEngine below says why)
+//   two-pass sizes (N = 64, 128, 256): pass-1 role t1 = v, last pass q1 = v.
 #pragma once
 #include "smfft_engine.hpp"
 
