@@ -646,7 +646,9 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
     rec.b = out;
     rec.va_bytes = need * kHandleBytes;
     rec.searched = true;
-    rec.mixed = good;
+    // how the kernels pace their stores into it (pacing_for): by what the output CONSISTS of -- mixed or interleaved memory
+    // takes writes like mixed memory whether or not the scan could also call the result good
+    rec.mixed = 2 * (best.mixed_used + best.interleaved_used) >= need;
     info.candidates = (int)chunks.size();
     info.candidate_bytes = created;
     info.chosen = (int)((best.mixed_used * kHandleBytes + kChunkBytes - 1) / kChunkBytes);
