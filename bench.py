@@ -422,9 +422,14 @@ def main():
             vendor = {"library": "hipFFT (rocFFT) hipfftExecC2C, batched plan, same device buffers, 10 launches after 3 warm-ups",
                       "ms_on_pair": v_pair, "ms_on_plain": v_plain}
 
-    def median_ms(fn, reps=11, warm=3):
+    def median_ms(fn, reps=11, warm=3, settle_ms=0.0):
+        # settle_ms: the in-LDS kernels are compute-bound and the device's clocks follow the load -- right after memory-bound
+        # launches they run 6-7 % slower for the first ~25 ms (profiles/r03_warm_ramp.txt); their figures are the settled ones
         for _ in range(warm):
             fn(None)
+        spent = ctypes.c_double(0.0)
+        while spent.value < settle_ms:
+            fn(ctypes.byref(spent))
         ts = []
         for _ in range(reps):
             t = ctypes.c_double(0.0)
@@ -432,12 +437,13 @@ def main():
             ts.append(t.value)
         return sorted(ts)[len(ts) // 2]
 
+    SETTLE = 40.0                       # ms of untimed in-LDS launches before the timed ones (see median_ms)
     # in-LDS `multiple` path on the same buffers (config 3's N=1024 point) on every rank: whole-job figure
     mult = {}
     for reo in (0, 1):
-        mult[reo] = median_ms(lambda t, reo=reo: sm.lib.smfft_ct_multiple_benchmark(pa.value, pb.value, n, nffts, 0, reo, t))
+        mult[reo] = median_ms(lambda t, reo=reo: sm.lib.smfft_ct_multiple_benchmark(pa.value, pb.value, n, nffts, 0, reo, t), settle_ms=SETTLE)
     nr_max, re_max, _ = reduce_stats(dist, stats_dev, mult[0], mult[1])
-    mult = {k: {"ms": ms, "FFT/s": world * (nffts // 100) * 100 / (ms * 1e-3), "ms_is": "median of 11 launches, max over ranks", "n_gpus": world}
+    mult = {k: {"ms": ms, "FFT/s": world * (nffts // 100) * 100 / (ms * 1e-3), "ms_is": "median of 11 launches after 40 ms of untimed ones (settled clocks), max over ranks", "n_gpus": world}
             for k, ms in (("noreorder", nr_max), ("reorder", re_max))}
 
     # configs 3 and 4 of BASELINE.json (N = 1 only; FFT_*_benchmark calls = one event-timed launch each, median of 11)
@@ -452,10 +458,10 @@ def main():
             done = (bn // 400 * 400) if fn_n == 32 else (bn // 200 * 200) if fn_n == 64 else (bn // 100 * 100)
             row = {"nFFTs": bn}
             for name, reo in (("noreorder", 0), ("reorder", 1)):
-                ms = median_ms(lambda t, reo=reo: sm.lib.smfft_ct_multiple_benchmark(pa.value, pb.value, fn_n, bn, 0, reo, t))
+                ms = median_ms(lambda t, reo=reo: sm.lib.smfft_ct_multiple_benchmark(pa.value, pb.value, fn_n, bn, 0, reo, t), settle_ms=SETTLE)
                 tf = done * 5 * fn_n * math.log2(fn_n) / (ms * 1e-3) / 1e12
                 # the multiple path touches only the first nFFTs/100 slots, so a "batch" of SAT x nFFTs stays inside the buffers
-                ms_sat = median_ms(lambda t, reo=reo: sm.lib.smfft_ct_multiple_benchmark(pa.value, pb.value, fn_n, SAT * bn, 0, reo, t), reps=7)
+                ms_sat = median_ms(lambda t, reo=reo: sm.lib.smfft_ct_multiple_benchmark(pa.value, pb.value, fn_n, SAT * bn, 0, reo, t), reps=7, settle_ms=SETTLE)
                 row[name] = {"ms": ms, "FFT/s": done / (ms * 1e-3), "TFLOP/s": tf, "frac_fp32_peak": tf / FP32_PEAK_TFLOPS,
                              "saturating_batch": {"slots_x": SAT, "ms": ms_sat, "FFT/s": SAT * done / (ms_sat * 1e-3),
                                                   "frac_fp32_peak": SAT * done * 5 * fn_n * math.log2(fn_n) / (ms_sat * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}}
@@ -495,7 +501,7 @@ def main():
             bn = nffts * n // fn_n
             ms = median_ms(lambda t: sm.lib.smfft_st_external_benchmark(pa.value, pb.value, fn_n, bn, t), reps=7)
             gbps = 2 * fn_n * bn * 8 / (ms * 1e-3) / 1e9
-            msm = median_ms(lambda t: sm.lib.smfft_st_multiple_benchmark(pa.value, pb.value, fn_n, bn, t), reps=7)
+            msm = median_ms(lambda t: sm.lib.smfft_st_multiple_benchmark(pa.value, pb.value, fn_n, bn, t), reps=7, settle_ms=SETTLE)
             done = bn // 100 * 100
             cst[str(fn_n)] = {"nFFTs": bn, "external": {"ms": ms, "TB/s": gbps / 1e3, "frac": gbps / HBM_PEAK_GBPS},
                               "multiple": {"ms": msm, "FFT/s": done / (msm * 1e-3), "frac_fp32_peak": done * 5 * fn_n * math.log2(fn_n) / (msm * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}}
@@ -509,8 +515,8 @@ def main():
             ex.smfft_example_reference_shape_st.argtypes = [vp, vp, ci, ci, vp]
             ex.smfft_example_reference_shape_multiple_one.argtypes = [vp, vp, ci, ci, vp]
 
-            def event_ms(fn, reps=7, warm=2):
-                for _ in range(warm):
+            def event_ms(fn, reps=7, warm=2, settle_launches=0):
+                for _ in range(warm + settle_launches):
                     fn()
                 ts = []
                 for _ in range(reps):
@@ -532,11 +538,11 @@ def main():
             cref["stockham_external"] = {"ms": ms, "TB/s": gb / ms, "frac": gb / ms * 1e3 / HBM_PEAK_GBPS, "ratio_to_tiled": cst[str(n)]["external"]["ms"] / ms}
             for key, which, compact in (("ct_multiple_reorder", 0, c3[str(n)]["reorder"]["ms"]), ("ct_multiple_noreorder", 1, c3[str(n)]["noreorder"]["ms"]),
                                         ("stockham_multiple", 2, cst[str(n)]["multiple"]["ms"])):
-                ms = event_ms(lambda w=which: ex.smfft_example_reference_shape_multiple_one(pa.value, pb.value, slots, w, sh))
+                ms = event_ms(lambda w=which: ex.smfft_example_reference_shape_multiple_one(pa.value, pb.value, slots, w, sh), settle_launches=30)
                 cref[key] = {"ms": ms, "FFT/s": slots * 100 / (ms * 1e-3), "ratio_to_compact": compact / ms}
         except (OSError, AttributeError) as e:
             cref = {"error": repr(e)}
-        configs = {"timing": "median of 11 (7 where many cases) event-timed launches after 3 warm-ups, buffers of `roofline`",
+        configs = {"timing": "median of 11 (7 where many cases) event-timed launches after 3 warm-ups, buffers of `roofline`; the in-LDS (multiple) figures after a further 40 ms of untimed launches (clocks settled, profiles/r03_warm_ramp.txt)",
                    "config2_external_by_length": c2, "config3_multiple": c3, "config4_r2c_c2r_external": c4,
                    "stockham_program": cst, "reference_contract": cref}
 
