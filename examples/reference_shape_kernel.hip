@@ -99,3 +99,20 @@ extern "C" int smfft_example_reference_shape_multiple_one(void* d_in, void* d_ou
     }
     return (int)hipGetLastError();
 }
+
+// SMFFT_DIT_multiple<P> at any length in the reference's launch shape (CT:669-683: blocks of fft_length / 4 threads, each
+// holding fft_length / N transforms), forward; for timing the in-LDS contract path per length (tools/reference_contract.py)
+template <class P>
+static int launch_ct_multiple(float2* in, float2* out, int nBlocks, hipStream_t st) {
+    SMFFT_DIT_multiple<P><<<dim3(nBlocks), dim3(P::fft_length / 4), 0, st>>>(in, out);
+    return (int)hipGetLastError();
+}
+#define CTM_CASE(N) case N: return reorder ? launch_ct_multiple<FFT_##N##_forward>(in, out, nBlocks, st) : launch_ct_multiple<FFT_##N##_forward_noreorder>(in, out, nBlocks, st);
+extern "C" int smfft_example_reference_shape_ct_multiple(void* d_in, void* d_out, int FFT_size, int nBlocks, int reorder, void* stream) {
+    float2 *in = (float2*)d_in, *out = (float2*)d_out;
+    hipStream_t st = (hipStream_t)stream;
+    switch (FFT_size) {
+        CTM_CASE(32) CTM_CASE(64) CTM_CASE(128) CTM_CASE(256) CTM_CASE(512) CTM_CASE(1024) CTM_CASE(2048) CTM_CASE(4096)
+        default: return -1;
+    }
+}

@@ -18,11 +18,13 @@
 //     How it runs on a 64-lane wave: EVERY thread of the block works on four elements, as upstream -- the reference's own
 //     radix-2 decimation-in-time ladder with two stages fused per pass (quarter_fft_inplace below): in place, one
 //     synchronisation per pass (a compiler fence while the N/4 threads share a wave), the bit reversal of the
-//     natural-order variants folded into the first pass.  Measured against this library's tiled kernels on the same
-//     buffers (tools/reference_contract.py, profiles/r03_reference_contract_after.txt): external path 0.59-0.95 of their
-//     rate (round 2, one working wave per block: 0.14-0.55), in-LDS path 0.27-0.36 -- five LDS round trips of the
-//     whole FFT per transform (4 reads + 4 writes per thread and pass, 2-4-way bank conflicts in the first three passes
-//     because the data must stay contiguous) against two of the 16-elements-per-thread engine.  Kernels that want the
+//     natural-order variants folded into the first pass, and -- between the first reads and the last stores -- a swizzled
+//     image of the same LDS words that takes the bank conflicts out of the strided passes (quarter_swizzle below).
+//     Measured against this library's tiled / compact kernels on the same buffers (tools/reference_contract.py,
+//     profiles/r03_quarter_swizzle.txt): external path 0.65-0.96 of their rate (round 2, one working wave per block:
+//     0.14-0.55), in-LDS path 0.45-0.52 for N = 256 .. 2048 (0.24-0.39 for the half-wave blocks of N <= 128 and the
+//     16-wave blocks of N = 4096) -- five LDS round trips of the whole FFT per transform (4 reads + 4 writes per thread
+//     and pass) against two-and-a-half of the 16-elements-per-thread engine.  Kernels that want the
 //     engine's speed use form (2) or the Engine directly (examples/fft_convolution.hip).
 //
 // (2) THE ENGINE'S TILED CONTRACT (namespace smfft::tiled; what this library's own kernels are built on):
@@ -137,13 +139,39 @@ struct QuarterTwiddleRows {
 template <int N>
 static __device__ const QuarterTwiddleRows<N> quarter_twiddle_rows = QuarterTwiddleRows<N>();
 
-// BLOCK_THREADS: threads the caller's block has (what decides between a wave-level fence and a workgroup barrier)
+// Inside the function the data lives in a SWIZZLED image of the same LDS words: element i (index within the block's region:
+// the FFT's offset included, N <= 128 keeps 128 / N transforms per 32 threads) sits at
+//     i ^ ((i >> 8) & 31) ^ ((i >> 4) & 30) ^ ((i >> 2) & 24)
+// -- the five bank-selecting bits of a float2 index get the higher index bits mixed in (x = i >> 5: (x >> 3) ^ (x << 1) ^
+// (x << 3), GF(2)-linear, so a pass's four addresses are one swizzled base XOR three constants).  In the natural layout a
+// pass's stride-4P accesses hit 8 (P = 4) or 16 (P = 16) of the 32 float2 banks and the natural-order variants' scattered
+// store of pass 0 two of them; with the swizzle every read of every pass is conflict free and the stores at most 2-way
+// (tools/quarter_swizzle.py: LDS cycles per N = 1024 transform, both orderings together, 2912 -> 1344 of 1248 conflict free;
+// measured SQ_LDS_BANK_CONFLICT 0.44-0.57 -> 0.10-0.25 of the LDS cycles, in-LDS rate x 1.5-2.0).  The
+// price: the first pass must have read everything before anything is stored, and the last pass reads everything before it
+// stores in natural order -- one more synchronisation at either end (the natural-order first pass had one already).
+#ifndef SMFFT_QUARTER_SWIZZLE
+#define SMFFT_QUARTER_SWIZZLE 1
+#endif
+__host__ __device__ constexpr int quarter_swizzle(int i) {
+#if SMFFT_QUARTER_SWIZZLE
+    return i ^ ((i >> 8) & 31) ^ ((i >> 4) & 30) ^ ((i >> 2) & 24);
+#else
+    return i;
+#endif
+}
+
+// BLOCK_THREADS: threads the caller's block has (what decides between a wave-level fence and a workgroup barrier);
+// s: the block's LDS region, region_offset: where this thread's transform starts in it (f * N)
 template <int N, int DIR, int REORDER, int BLOCK_THREADS>
-__device__ __forceinline__ void quarter_fft_inplace(float2* sf, int t) {
+__device__ __forceinline__ void quarter_fft_inplace(float2* s, int t, int region_offset = 0) {
     using R = QuarterTwiddleRows<N>;
     constexpr int Q = N / 4;
     constexpr bool kBarrier = BLOCK_THREADS > 64;
+    constexpr bool kSwizzled = SMFFT_QUARTER_SWIZZLE != 0;
     constexpr int T_BITS = ilog2c(Q);
+    constexpr int kLastQuad = R::kOdd ? -1 : R::kPasses - 1;    // the pass whose results leave in natural order (none: the radix-2 pass is last)
+    float2* sf = s + region_offset;
     float2 e[4];
     // ---- pass 0 (P = 1): twiddles 1, 1, -+i -----------------------------------------------------------------------
     int a;
@@ -156,14 +184,17 @@ __device__ __forceinline__ void quarter_fft_inplace(float2* sf, int t) {
         a = 4 * t;
 #pragma unroll
         for (int i = 0; i < 4; ++i) e[i] = sf[a + i];
+        if constexpr (kSwizzled && kLastQuad != 0) fft_sync<kBarrier>();                // ... and the swizzled ones
     }
     {
         const float2 s0 = cadd(e[0], e[1]), d0 = csub(e[0], e[1]), s1 = cadd(e[2], e[3]), d1 = csub(e[2], e[3]);
         const float2 jd1 = DIR ? make_float2(-d1.y, d1.x) : make_float2(d1.y, -d1.x);   // -+i * d1
-        sf[a + 0] = cadd(s0, s1);
-        sf[a + 2] = csub(s0, s1);
-        sf[a + 1] = cadd(d0, jd1);
-        sf[a + 3] = csub(d0, jd1);
+        if constexpr (kLastQuad == 0) {
+            sf[a + 0] = cadd(s0, s1), sf[a + 2] = csub(s0, s1), sf[a + 1] = cadd(d0, jd1), sf[a + 3] = csub(d0, jd1);
+        } else {
+            const int a0 = quarter_swizzle(region_offset + a);                          // a0 ^ m: the same aligned group of four
+            s[a0] = cadd(s0, s1), s[a0 ^ 2] = csub(s0, s1), s[a0 ^ 1] = cadd(d0, jd1), s[a0 ^ 3] = csub(d0, jd1);
+        }
     }
     // ---- passes 1 .. (P = 4, 16, ...) -----------------------------------------------------------------------------
     if constexpr (R::kPasses > 1) {
@@ -176,15 +207,19 @@ __device__ __forceinline__ void quarter_fft_inplace(float2* sf, int t) {
             const TwiddleValue tv = quarter_twiddle_rows<N>.w[R::row_start(p) + k];
             const float2 w2 = make_float2(tv.x, DIR ? -tv.y : tv.y);
             const float2 w1 = make_float2(w2.x * w2.x - w2.y * w2.y, 2.f * w2.x * w2.y);
-            float2 x0 = sf[base], x1 = sf[base + P], x2 = sf[base + 2 * P], x3 = sf[base + 3 * P];
+            const int a0 = quarter_swizzle(region_offset + base);
+            const int a1 = a0 ^ quarter_swizzle(P), a2 = a0 ^ quarter_swizzle(2 * P), a3 = a0 ^ quarter_swizzle(3 * P);
+            float2 x0 = s[a0], x1 = s[a1], x2 = s[a2], x3 = s[a3];
             const float2 t1 = cmul(x1, w1), t3 = cmul(x3, w1);
             const float2 y0 = cadd(x0, t1), y1 = csub(x0, t1), y2 = cadd(x2, t3), y3 = csub(x2, t3);
             const float2 u2 = cmul(y2, w2), v3 = cmul(y3, w2);
             const float2 u3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);  // y3 * w2 * (-+i)
-            sf[base] = cadd(y0, u2);
-            sf[base + 2 * P] = csub(y0, u2);
-            sf[base + P] = cadd(y1, u3);
-            sf[base + 3 * P] = csub(y1, u3);
+            if (p == kLastQuad) {
+                if constexpr (kSwizzled) fft_sync<kBarrier>();                           // every swizzled load precedes the natural stores
+                sf[base] = cadd(y0, u2), sf[base + 2 * P] = csub(y0, u2), sf[base + P] = cadd(y1, u3), sf[base + 3 * P] = csub(y1, u3);
+            } else {
+                s[a0] = cadd(y0, u2), s[a2] = csub(y0, u2), s[a1] = cadd(y1, u3), s[a3] = csub(y1, u3);
+            }
         }
     }
     // ---- odd log2 N: the last radix-2 stage (span N/2), two butterflies per thread ----------------------------------
@@ -192,9 +227,11 @@ __device__ __forceinline__ void quarter_fft_inplace(float2* sf, int t) {
         fft_sync<kBarrier>();
         const TwiddleValue tv = quarter_twiddle_rows<N>.w[R::row_start(R::kPasses) + t];
         const float2 w = make_float2(tv.x, DIR ? -tv.y : tv.y);
-        const float2 x0 = sf[t], x1 = sf[t + N / 2], x2 = sf[t + Q], x3 = sf[t + 3 * Q];
+        const int a0 = quarter_swizzle(region_offset + t);
+        const float2 x0 = s[a0], x1 = s[a0 ^ quarter_swizzle(N / 2)], x2 = s[a0 ^ quarter_swizzle(Q)], x3 = s[a0 ^ quarter_swizzle(3 * Q)];
         const float2 t1 = cmul(x1, w), v3 = cmul(x3, w);
         const float2 t3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);
+        if constexpr (kSwizzled) fft_sync<kBarrier>();
         sf[t] = cadd(x0, t1);
         sf[t + N / 2] = csub(x0, t1);
         sf[t + Q] = cadd(x2, t3);
@@ -276,7 +313,7 @@ __device__ void do_SMFFT_CT_DIT(float2* s_input) {
     constexpr int N = const_params::fft_size;
     constexpr int kBlock = const_params::fft_length / 4;                 // 32 threads hold 128 / N transforms for N <= 128 (CT:586-595)
     const int f = threadIdx.x / (N / 4), t = threadIdx.x % (N / 4);
-    smfft::quarter_fft_inplace<N, const_params::fft_direction, const_params::fft_reorder, kBlock>(s_input + f * N, t);
+    smfft::quarter_fft_inplace<N, const_params::fft_direction, const_params::fft_reorder, kBlock>(s_input, t, f * N);
 }
 
 template <class const_params>

@@ -1,0 +1,53 @@
+"""The four-elements-per-thread engine's LDS swizzle (quarter_swizzle, include/smfft/smfft_device_functions.hpp): the header
+computes what tools/quarter_swizzle.py models, the function is a GF(2)-linear permutation of every aligned group of 32
+elements (so it stays inside the caller's N float2 and a pass's four addresses are one swizzled base XOR three constants),
+and in the model (gfx950 lane groups and banks, MI355X_MICROARCH.md) it removes the bank conflicts of the natural layout.
+CPU only: the header's constexpr function is evaluated by a host-side hipcc compile (no GPU code is run)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import quarter_swizzle as qs  # noqa: E402
+
+
+def test_swizzle_is_a_linear_permutation_of_aligned_groups():
+    f = qs.product_swizzle
+    for block in range(0, 4096, 32):
+        assert sorted(f(i) for i in range(block, block + 32)) == list(range(block, block + 32))
+    for a in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 37, 1234, 4095):
+        for b in (3, 5, 48, 1000, 2048, 4094):
+            assert f(a ^ b) == f(a) ^ f(b)
+    assert all(f(m) == m for m in range(4))      # a thread's four pass-0 results stay one aligned group of four
+
+
+@pytest.mark.parametrize("n", [32, 64, 128, 256, 512, 1024, 2048, 4096])
+def test_swizzle_removes_the_conflicts_in_the_model(n):
+    natural, swizzled, ideal = qs.lds_cycles(n, lambda i: i), qs.lds_cycles(n, qs.product_swizzle), qs.ideal_cycles(n)
+    assert swizzled <= 1.13 * ideal, (n, swizzled, ideal)      # what is left: 2-way stores (8 instead of 6 cycles) in one pass
+    assert swizzled < natural
+    if n >= 256:
+        assert natural >= 2 * swizzled - 150, (n, natural, swizzled)
+
+
+def test_header_computes_the_models_function(tmp_path):
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = tmp_path / "swz.hip"
+    src.write_text(r'''
+#include <cstdio>
+#include "smfft_device.hpp"
+int main() {
+    for (int i = 0; i < 4096; ++i) printf("%d\n", smfft::quarter_swizzle(i));
+    return 0;
+}
+''')
+    exe = tmp_path / "swz"
+    subprocess.check_call([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                          stderr=subprocess.DEVNULL)
+    got = [int(v) for v in subprocess.check_output([str(exe)], text=True).split()]
+    assert got == [qs.product_swizzle(i) for i in range(4096)]

@@ -16,13 +16,16 @@ import smfft_amd as sm  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--sizes", default="1024")
 ap.add_argument("--plain", action="store_true")
+ap.add_argument("--examples", default=os.path.join(os.path.dirname(sm.LIB_PATH), "libsmfft_examples.so"), help="another build of examples/ to time")
+ap.add_argument("--in-lds-only", action="store_true")
 args = ap.parse_args()
-ex = ctypes.CDLL(os.path.join(os.path.dirname(sm.LIB_PATH), "libsmfft_examples.so"))
+ex = ctypes.CDLL(os.path.abspath(args.examples))
 vp, i = ctypes.c_void_p, ctypes.c_int
 ex.smfft_example_reference_shape_ct.argtypes = [vp, vp, i, i, i, i, i, vp]
 ex.smfft_example_reference_shape_st.argtypes = [vp, vp, i, i, vp]
 ex.smfft_example_reference_shape_rc.argtypes = [vp, vp, i, i, i, vp]
 ex.smfft_example_reference_shape_multiple_one.argtypes = [vp, vp, i, i, vp]
+ex.smfft_example_reference_shape_ct_multiple.argtypes = [vp, vp, i, i, i, vp]
 
 TOTAL = 1 << 29
 nbytes = TOTAL * 8
@@ -68,6 +71,18 @@ def lib_ms(call):
 for n in [int(v) for v in args.sizes.split(",")]:
     nffts = TOTAL // n
     gb = 2 * nbytes / 1e9
+    for reo in (1, 0):
+        # in-LDS path: SMFFT_DIT_multiple<P> in the reference's shape next to the compact kernel, README batch
+        per_block = max(n, 128) // n if n <= 128 else 1
+        if n <= 128:
+            per_block = 128 // n
+        blocks = (nffts // 100) // per_block
+        ref = timed(lambda: ex.smfft_example_reference_shape_ct_multiple(a, b, n, blocks, reo, None), reps=15, warm=25)
+        lib = lib_ms(lambda t: sm.lib.smfft_ct_multiple_benchmark(a, b, n, nffts, 0, reo, t))
+        done = blocks * per_block * 100
+        print(f"in-LDS N={n} reorder={reo}: reference contract {ref:.3f} ms {done / ref * 1e3:.3e} FFT/s | compact {lib:.3f} ms | ratio {lib / ref:.2f}", flush=True)
+    if args.in_lds_only:
+        continue
     for reo in (1, 0):
         ref = timed(lambda: ex.smfft_example_reference_shape_ct(a, b, n, nffts, 0, reo, 1, None))
         lib = lib_ms(lambda t: sm.lib.smfft_ct_external_benchmark(a, b, n, nffts, 0, reo, t))
