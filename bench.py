@@ -456,7 +456,7 @@ def main():
         for fn_n in (32, 64, 128, 256, 512, 1024, 2048, 4096):
             bn = min(total // fn_n, nffts * n // fn_n)
             done = (bn // 400 * 400) if fn_n == 32 else (bn // 200 * 200) if fn_n == 64 else (bn // 100 * 100)
-            row = {"nFFTs": bn}
+            row = {"nFFTs": bn, "FFTs_executed": done}
             for name, reo in (("noreorder", 0), ("reorder", 1)):
                 ms = median_ms(lambda t, reo=reo: sm.lib.smfft_ct_multiple_benchmark(pa.value, pb.value, fn_n, bn, 0, reo, t), settle_ms=SETTLE)
                 tf = done * 5 * fn_n * math.log2(fn_n) / (ms * 1e-3) / 1e12
@@ -540,6 +540,23 @@ def main():
                                         ("stockham_multiple", 2, cst[str(n)]["multiple"]["ms"])):
                 ms = event_ms(lambda w=which: ex.smfft_example_reference_shape_multiple_one(pa.value, pb.value, slots, w, sh), settle_launches=30)
                 cref[key] = {"ms": ms, "FFT/s": slots * 100 / (ms * 1e-3), "ratio_to_compact": compact / ms}
+            # every length: the CT kernels in the reference's shape, external (reorder / no reorder) and in-LDS (README batch)
+            ex.smfft_example_reference_shape_ct_multiple.argtypes = [vp, vp, ci, ci, ci, vp]
+            by_len = {}
+            for fn_n in (32, 64, 128, 256, 512, 1024, 2048, 4096):
+                bn = min(total // fn_n, nffts * n // fn_n)
+                per_block = max(1, 128 // fn_n)
+                blocks = (bn // 100) // per_block
+                row = {}
+                for name, reo in (("reorder", 1), ("noreorder", 0)):
+                    ms = event_ms(lambda r=reo, fn_n=fn_n, bn=bn: ex.smfft_example_reference_shape_ct(pa.value, pb.value, fn_n, bn, 0, r, 1, sh), reps=5)
+                    tiled = c2[str(fn_n)]["forward" if reo else "forward_noreorder"]["ms"]
+                    msm = event_ms(lambda r=reo, fn_n=fn_n, blocks=blocks: ex.smfft_example_reference_shape_ct_multiple(pa.value, pb.value, fn_n, blocks, r, sh), reps=5, settle_launches=20)
+                    compact = c3[str(fn_n)][name]["ms"] * (blocks * per_block * 100) / c3[str(fn_n)]["FFTs_executed"]
+                    row[name] = {"external_ms": ms, "external_ratio_to_tiled": tiled / ms, "in_lds_ms": msm,
+                                 "in_lds_FFT/s": blocks * per_block * 100 / (msm * 1e-3), "in_lds_ratio_to_compact": compact / msm}
+                by_len[str(fn_n)] = row
+            cref["by_length"] = by_len
         except (OSError, AttributeError) as e:
             cref = {"error": repr(e)}
         configs = {"timing": "median of 11 (7 where many cases) event-timed launches after 3 warm-ups, buffers of `roofline`; the in-LDS (multiple) figures after a further 40 ms of untimed launches (clocks settled, profiles/r03_warm_ramp.txt)",
