@@ -168,6 +168,15 @@ __device__ __forceinline__ void quarter_fft_inplace(float2* s, int t, int region
     using R = QuarterTwiddleRows<N>;
     constexpr int Q = N / 4;
     constexpr bool kBarrier = BLOCK_THREADS > 64;
+    // A workgroup barrier is needed only where data crosses waves.  Thread t's elements of a pass with P <= 64 lie in the
+    // aligned block of 256 elements number t >> 6 -- its wave's -- and so do their swizzled places (the swizzle permutes
+    // aligned groups of 32) and the elements of the first (no-reorder) and of the last pass (t + m N/4: thread and element
+    // share their offset inside a group of 32): between those a wave-level fence orders everything.  What does cross waves:
+    // the natural-order first pass (loads t + m N/4, stores 4 rev(t) + m), the passes with P >= 256 and the radix-2 pass.
+#ifndef SMFFT_QUARTER_WAVE_SYNC
+#define SMFFT_QUARTER_WAVE_SYNC 1
+#endif
+    constexpr bool kWaveLocal = SMFFT_QUARTER_WAVE_SYNC != 0;
     constexpr bool kSwizzled = SMFFT_QUARTER_SWIZZLE != 0;
     constexpr int T_BITS = ilog2c(Q);
     constexpr int kLastQuad = R::kOdd ? -1 : R::kPasses - 1;    // the pass whose results leave in natural order (none: the radix-2 pass is last)
@@ -184,7 +193,7 @@ __device__ __forceinline__ void quarter_fft_inplace(float2* s, int t, int region
         a = 4 * t;
 #pragma unroll
         for (int i = 0; i < 4; ++i) e[i] = sf[a + i];
-        if constexpr (kSwizzled && kLastQuad != 0) fft_sync<kBarrier>();                // ... and the swizzled ones
+        if constexpr (kSwizzled && kLastQuad != 0) fft_sync<kBarrier && !kWaveLocal>();  // ... and the swizzled ones (same wave's)
     }
     {
         const float2 s0 = cadd(e[0], e[1]), d0 = csub(e[0], e[1]), s1 = cadd(e[2], e[3]), d1 = csub(e[2], e[3]);
@@ -201,7 +210,8 @@ __device__ __forceinline__ void quarter_fft_inplace(float2* s, int t, int region
         int P = 4;
 #pragma unroll
         for (int p = 1; p < R::kPasses; ++p, P *= 4) {
-            fft_sync<kBarrier>();
+            if (P > 64 || (REORDER && p == 1) || !kWaveLocal) fft_sync<kBarrier>();
+            else fft_sync<false>();
             const int k = t & (P - 1);
             const int base = ((t - k) << 2) + k;
             const TwiddleValue tv = quarter_twiddle_rows<N>.w[R::row_start(p) + k];
@@ -215,7 +225,7 @@ __device__ __forceinline__ void quarter_fft_inplace(float2* s, int t, int region
             const float2 u2 = cmul(y2, w2), v3 = cmul(y3, w2);
             const float2 u3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);  // y3 * w2 * (-+i)
             if (p == kLastQuad) {
-                if constexpr (kSwizzled) fft_sync<kBarrier>();                           // every swizzled load precedes the natural stores
+                if constexpr (kSwizzled) fft_sync<kBarrier && !kWaveLocal>();            // every swizzled load precedes the natural stores (same wave's)
                 sf[base] = cadd(y0, u2), sf[base + 2 * P] = csub(y0, u2), sf[base + P] = cadd(y1, u3), sf[base + 3 * P] = csub(y1, u3);
             } else {
                 s[a0] = cadd(y0, u2), s[a2] = csub(y0, u2), s[a1] = cadd(y1, u3), s[a3] = csub(y1, u3);
@@ -231,7 +241,7 @@ __device__ __forceinline__ void quarter_fft_inplace(float2* s, int t, int region
         const float2 x0 = s[a0], x1 = s[a0 ^ quarter_swizzle(N / 2)], x2 = s[a0 ^ quarter_swizzle(Q)], x3 = s[a0 ^ quarter_swizzle(3 * Q)];
         const float2 t1 = cmul(x1, w), v3 = cmul(x3, w);
         const float2 t3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);
-        if constexpr (kSwizzled) fft_sync<kBarrier>();
+        if constexpr (kSwizzled) fft_sync<kBarrier && !kWaveLocal>();
         sf[t] = cadd(x0, t1);
         sf[t + N / 2] = csub(x0, t1);
         sf[t + Q] = cadd(x2, t3);
