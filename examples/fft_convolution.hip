@@ -59,9 +59,11 @@ __global__ void __launch_bounds__(256) convolve_kernel_registers(const float2* _
     float2* sf = s + fwd.fft * G::SF;
     float2 h[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) h[q] = H[fwd.u + G::T * q];
+    for (int q = 0; q < 16; ++q) {   // 1 / N folded into the filter: the inverse transform's result is stored as it is
+        const float2 t = H[fwd.u + G::T * q];
+        h[q] = make_float2(t.x * (1.0f / N), t.y * (1.0f / N));
+    }
     const int ntiles = (nSeries + G::kFftsPerBlock - 1) / G::kFftsPerBlock;
-    const float scale = 1.0f / N;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long f = (long)tile * G::kFftsPerBlock + fwd.fft;
         const bool active = f < nSeries;
@@ -73,8 +75,6 @@ __global__ void __launch_bounds__(256) convolve_kernel_registers(const float2* _
         for (int q = 0; q < 16; ++q) r[q] = smfft::cmul(r[q], h[q]);
         smfft::fft_sync<G::kMultiWave>();          // the forward transform's last LDS reads are done
         inv.transform(r, sf);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) r[q] = make_float2(r[q].x * scale, r[q].y * scale);
         inv.store_global(r, y + f * N, active);
     }
 }

@@ -116,3 +116,34 @@ extern "C" int smfft_example_reference_shape_ct_multiple(void* d_in, void* d_out
         default: return -1;
     }
 }
+
+// The library use case in the reference's shape: a batched circular convolution y = IFFT(FFT(x) .* H) / N written by a user
+// who knows nothing but the reference's contract -- one block per series, blockDim.x = N / 4, do_SMFFT_CT_DIT<forward>,
+// a pointwise product in shared memory, do_SMFFT_CT_DIT<inverse> (README.md:10-16).  examples/fft_convolution.hip has the
+// same pipeline on the engine's tiled contract and on its register-level interface.
+template <class Fwd, class Inv>
+__global__ void user_convolution_kernel(const float2* d_x, const float2* d_H, float2* d_y) {
+    __shared__ float2 s_data[Fwd::fft_sm_required];
+    constexpr int N = Fwd::fft_length, Q = Fwd::fft_length_quarter;
+    const int offset = blockIdx.x * N;
+    for (int k = 0; k < 4; k++) s_data[threadIdx.x + k * Q] = d_x[offset + threadIdx.x + k * Q];
+    __syncthreads();
+    do_SMFFT_CT_DIT<Fwd>(s_data);
+    __syncthreads();
+    for (int k = 0; k < 4; k++) {
+        const float2 a = s_data[threadIdx.x + k * Q], h = d_H[threadIdx.x + k * Q];
+        s_data[threadIdx.x + k * Q] = make_float2(a.x * h.x - a.y * h.y, a.x * h.y + a.y * h.x);
+    }
+    __syncthreads();
+    do_SMFFT_CT_DIT<Inv>(s_data);
+    __syncthreads();
+    for (int k = 0; k < 4; k++) {
+        const float2 v = s_data[threadIdx.x + k * Q];
+        d_y[offset + threadIdx.x + k * Q] = make_float2(v.x * (1.0f / N), v.y * (1.0f / N));
+    }
+}
+extern "C" int smfft_example_reference_shape_convolve_1024(const void* d_x, const void* d_H, void* d_y, int nSeries, void* stream) {
+    if (nSeries <= 0) return 0;
+    user_convolution_kernel<FFT_1024_forward, FFT_1024_inverse><<<dim3(nSeries), dim3(256), 0, (hipStream_t)stream>>>((const float2*)d_x, (const float2*)d_H, (float2*)d_y);
+    return (int)hipGetLastError();
+}

@@ -261,7 +261,8 @@ def test_harness_programs(sm, prog, args, expect):
 
 # ------------------------------------------- device functions called from a user kernel (examples/)
 @pytest.mark.parametrize("n,sym", [(1024, "smfft_example_convolve_1024"), (256, "smfft_example_convolve_256"),
-                                   (1024, "smfft_example_convolve_1024_registers")])
+                                   (1024, "smfft_example_convolve_1024_registers"),
+                                   (1024, "smfft_example_reference_shape_convolve_1024")])
 def test_example_convolution_kernel(sm, n, sym):
     """examples/fft_convolution.hip: a user kernel chaining do_SMFFT_CT_DIT<forward> -> .* H ->
     do_SMFFT_CT_DIT<inverse> in LDS (the library use case, reference README.md:10-16)."""
