@@ -147,3 +147,33 @@ extern "C" int smfft_example_reference_shape_convolve_1024(const void* d_x, cons
     user_convolution_kernel<FFT_1024_forward, FFT_1024_inverse><<<dim3(nSeries), dim3(256), 0, (hipStream_t)stream>>>((const float2*)d_x, (const float2*)d_H, (float2*)d_y);
     return (int)hipGetLastError();
 }
+
+// SMFFT_DIT_multiple<P>'s call pattern with two applications instead of NREUSES (whose 100 un-normalised transforms overflow
+// fp32 by design, CT:563-565): load, (do_SMFFT_CT_DIT<P>, barrier) x 2, store -- so that the back-to-back calls can be
+// checked: forward twice in natural order is N * x[(-n) mod N].
+template <class const_params>
+__global__ void user_fft_twice_kernel(float2* d_input, float2* d_output) {
+    __shared__ float2 s_data[const_params::fft_sm_required];
+    const int offset = blockIdx.x * const_params::fft_length;
+    for (int k = 0; k < 4; k++) s_data[threadIdx.x + k * const_params::fft_length_quarter] = d_input[offset + threadIdx.x + k * const_params::fft_length_quarter];
+    __syncthreads();
+    for (int f = 0; f < 2; f++) {
+        do_SMFFT_CT_DIT<const_params>(s_data);
+        __syncthreads();
+    }
+    for (int k = 0; k < 4; k++) d_output[offset + threadIdx.x + k * const_params::fft_length_quarter] = s_data[threadIdx.x + k * const_params::fft_length_quarter];
+}
+template <class P>
+static int launch_ct_twice(float2* in, float2* out, int nFFTs, hipStream_t st) {
+    user_fft_twice_kernel<P><<<dim3(nFFTs / (P::fft_length / P::fft_size)), dim3(P::fft_length / 4), 0, st>>>(in, out);
+    return (int)hipGetLastError();
+}
+#define CT2_CASE(N) case N: return reorder ? launch_ct_twice<FFT_##N##_forward>(in, out, nFFTs, st) : launch_ct_twice<FFT_##N##_forward_noreorder>(in, out, nFFTs, st);
+extern "C" int smfft_example_reference_shape_ct_twice(void* d_in, void* d_out, int FFT_size, int nFFTs, int reorder, void* stream) {
+    float2 *in = (float2*)d_in, *out = (float2*)d_out;
+    hipStream_t st = (hipStream_t)stream;
+    switch (FFT_size) {
+        CT2_CASE(32) CT2_CASE(64) CT2_CASE(128) CT2_CASE(256) CT2_CASE(512) CT2_CASE(1024) CT2_CASE(2048) CT2_CASE(4096)
+        default: return -1;
+    }
+}

@@ -324,6 +324,56 @@ def test_reference_shaped_kernel_matches_oracle(sm, oracle_lib, n, inv, reo, whi
     ref.assert_close_fp32(got, sm.c2c(x, inverse=bool(inv), reorder=bool(reo)).astype(np.complex128), "reference-shaped vs tiled kernel")
 
 
+@pytest.mark.parametrize("n", C2C_SIZES)
+@pytest.mark.parametrize("reo", [1, 0])
+def test_reference_shaped_kernel_full_occupancy(sm, n, reo):
+    """The same kernels on 2^22 elements (every CU full of their blocks, several rounds): the engine's wave-level fences and
+    its swizzled LDS image hold under contention -- every FFT of the batch agrees with the library's tiled kernel within
+    the fp32 tolerance, and a second launch gives the same bits."""
+    import ctypes
+    ex = _examples(sm)
+    fn = ex.smfft_example_reference_shape_ct
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    nffts = (1 << 22) // n
+    rng = np.random.default_rng(77 * n + reo)
+    x = (rng.random((nffts, n), dtype=np.float32) - 0.5 + 1j * (rng.random((nffts, n), dtype=np.float32) - 0.5)).astype(np.complex64)
+    dx, dy = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
+    assert fn(dx.ptr, dy.ptr, n, nffts, 0, reo, 1, None) == 0
+    assert sm.lib.smfft_synchronize() == 0
+    got = dy.to_host(np.complex64, x.shape)
+    want = sm.c2c(x, inverse=False, reorder=bool(reo)).astype(np.complex128)
+    l2, mx = ref.fft_errors(got, want)
+    assert l2 < 5e-7 and mx < 1e-6, (n, reo, l2, mx)
+    sm.lib.smfft_memset(dy.ptr, 0xFF, x.nbytes)
+    assert fn(dx.ptr, dy.ptr, n, nffts, 0, reo, 1, None) == 0
+    assert sm.lib.smfft_synchronize() == 0
+    assert np.array_equal(dy.to_host(np.complex64, x.shape).view(np.uint32), got.view(np.uint32))
+
+
+@pytest.mark.parametrize("n", C2C_SIZES)
+@pytest.mark.parametrize("reo", [1, 0])
+def test_reference_shaped_back_to_back_calls(sm, n, reo):
+    """The call pattern of SMFFT_DIT_multiple<P> (CT:553-572) with two applications, every CU full: do_SMFFT_CT_DIT<P>, barrier,
+    do_SMFFT_CT_DIT<P>.  Natural order: F(F(x))[n] = N x[(-n) mod N]; no reorder: the library's own transform applied twice."""
+    import ctypes
+    ex = _examples(sm)
+    fn = ex.smfft_example_reference_shape_ct_twice
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+    nffts = (1 << 21) // n
+    rng = np.random.default_rng(5 * n + reo)
+    x = (rng.random((nffts, n), dtype=np.float32) - 0.5 + 1j * (rng.random((nffts, n), dtype=np.float32) - 0.5)).astype(np.complex64)
+    dx, dy = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
+    assert fn(dx.ptr, dy.ptr, n, nffts, reo, None) == 0
+    assert sm.lib.smfft_synchronize() == 0
+    got = dy.to_host(np.complex64, x.shape)
+    if reo:
+        want = n * np.roll(x[:, ::-1], 1, axis=1).astype(np.complex128)
+    else:
+        want = sm.c2c(sm.c2c(x, reorder=False), reorder=False).astype(np.complex128)
+    l2, mx = ref.fft_errors(got, want)
+    assert l2 < 5e-7 and mx < 1.5e-6, (n, reo, l2, mx)
+
+
 @pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096])
 def test_reference_shaped_stockham_kernel(sm, oracle_lib, n):
     """FFT_GPU_external<FFT_N><<<nFFTs, N/4, N*8>>>(in, out) calling do_FFT_Stockham_mk6 on exactly N float2 of dynamic
