@@ -530,8 +530,11 @@ def main():
             slots = (nffts // 100)
             gb = 2 * n * nffts * 8 / 1e9
             cref = {"kernels": "SMFFT_DIT_external<P>(in, out) <<<nFFTs, N/4>>> etc. of include/smfft/smfft_device_functions.hpp", "N": n}
-            for key, which_reo in (("ct_external_reorder", 1), ("ct_external_noreorder", 0)):
-                ms = event_ms(lambda r=which_reo: ex.smfft_example_reference_shape_ct(pa.value, pb.value, n, nffts, 0, r, 1, sh))
+            # ct_external_*: the library's two-argument kernel (N >= 256: the block's transform on registers, do_SMFFT_CT_DIT_registers);
+            # user_kernel_external_*: a user's kernel around do_SMFFT_CT_DIT (fill LDS, call, drain), examples/reference_shape_kernel.hip
+            for key, which_reo, which_kernel in (("ct_external_reorder", 1, 1), ("ct_external_noreorder", 0, 1),
+                                                 ("user_kernel_external_reorder", 1, 0), ("user_kernel_external_noreorder", 0, 0)):
+                ms = event_ms(lambda r=which_reo, w=which_kernel: ex.smfft_example_reference_shape_ct(pa.value, pb.value, n, nffts, 0, r, w, sh))
                 tiled = c2[str(n)]["forward" if which_reo else "forward_noreorder"]["ms"]
                 cref[key] = {"ms": ms, "TB/s": gb / ms, "frac": gb / ms * 1e3 / HBM_PEAK_GBPS, "ratio_to_tiled": tiled / ms}
             ms = event_ms(lambda: ex.smfft_example_reference_shape_st(pa.value, pb.value, n, nffts, sh))
@@ -550,10 +553,12 @@ def main():
                 row = {}
                 for name, reo in (("reorder", 1), ("noreorder", 0)):
                     ms = event_ms(lambda r=reo, fn_n=fn_n, bn=bn: ex.smfft_example_reference_shape_ct(pa.value, pb.value, fn_n, bn, 0, r, 1, sh), reps=5)
+                    ms_user = event_ms(lambda r=reo, fn_n=fn_n, bn=bn: ex.smfft_example_reference_shape_ct(pa.value, pb.value, fn_n, bn, 0, r, 0, sh), reps=5)
                     tiled = c2[str(fn_n)]["forward" if reo else "forward_noreorder"]["ms"]
                     msm = event_ms(lambda r=reo, fn_n=fn_n, blocks=blocks: ex.smfft_example_reference_shape_ct_multiple(pa.value, pb.value, fn_n, blocks, r, sh), reps=5, settle_launches=20)
                     compact = c3[str(fn_n)][name]["ms"] * (blocks * per_block * 100) / c3[str(fn_n)]["FFTs_executed"]
-                    row[name] = {"external_ms": ms, "external_ratio_to_tiled": tiled / ms, "in_lds_ms": msm,
+                    row[name] = {"external_ms": ms, "external_ratio_to_tiled": tiled / ms, "user_kernel_external_ms": ms_user,
+                                 "user_kernel_external_ratio_to_tiled": tiled / ms_user, "in_lds_ms": msm,
                                  "in_lds_FFT/s": blocks * per_block * 100 / (msm * 1e-3), "in_lds_ratio_to_compact": compact / msm}
                 by_len[str(fn_n)] = row
             cref["by_length"] = by_len

@@ -142,9 +142,33 @@ __global__ void user_convolution_kernel(const float2* d_x, const float2* d_H, fl
         d_y[offset + threadIdx.x + k * Q] = make_float2(v.x * (1.0f / N), v.y * (1.0f / N));
     }
 }
+// ... and with the register form of the same functions (do_SMFFT_CT_DIT_registers: a thread's four elements
+// threadIdx.x + m N/4 in and out, the shared array as scratch): the series never lies in shared memory in natural order.
+template <class Fwd, class Inv>
+__global__ void user_convolution_kernel_registers(const float2* d_x, const float2* d_H, float2* d_y) {
+    __shared__ float2 s_scratch[Fwd::fft_sm_required];
+    constexpr int N = Fwd::fft_length, Q = Fwd::fft_length_quarter;
+    const int offset = blockIdx.x * N;
+    float2 x[4];
+    for (int k = 0; k < 4; k++) x[k] = d_x[offset + threadIdx.x + k * Q];
+    do_SMFFT_CT_DIT_registers<Fwd>(x, s_scratch);
+    for (int k = 0; k < 4; k++) {
+        const float2 a = x[k], h = d_H[threadIdx.x + k * Q];
+        x[k] = make_float2((a.x * h.x - a.y * h.y) * (1.0f / N), (a.x * h.y + a.y * h.x) * (1.0f / N));
+    }
+    __syncthreads();   // the forward transform's last reads of s_scratch are done before the inverse one writes it
+    do_SMFFT_CT_DIT_registers<Inv>(x, s_scratch);
+    for (int k = 0; k < 4; k++) d_y[offset + threadIdx.x + k * Q] = x[k];
+}
+// which = 0: shared-memory form, 1: register form
 extern "C" int smfft_example_reference_shape_convolve_1024(const void* d_x, const void* d_H, void* d_y, int nSeries, void* stream) {
     if (nSeries <= 0) return 0;
     user_convolution_kernel<FFT_1024_forward, FFT_1024_inverse><<<dim3(nSeries), dim3(256), 0, (hipStream_t)stream>>>((const float2*)d_x, (const float2*)d_H, (float2*)d_y);
+    return (int)hipGetLastError();
+}
+extern "C" int smfft_example_reference_shape_convolve_1024_registers(const void* d_x, const void* d_H, void* d_y, int nSeries, void* stream) {
+    if (nSeries <= 0) return 0;
+    user_convolution_kernel_registers<FFT_1024_forward, FFT_1024_inverse><<<dim3(nSeries), dim3(256), 0, (hipStream_t)stream>>>((const float2*)d_x, (const float2*)d_H, (float2*)d_y);
     return (int)hipGetLastError();
 }
 

@@ -21,8 +21,9 @@
 //     natural-order variants folded into the first pass, and -- between the first reads and the last stores -- a swizzled
 //     image of the same LDS words that takes the bank conflicts out of the strided passes (quarter_swizzle below).
 //     Measured against this library's tiled / compact kernels on the same buffers (tools/reference_contract.py,
-//     profiles/r03_quarter_swizzle.txt): external path 0.65-0.96 of their rate (round 2, one working wave per block:
-//     0.14-0.55), in-LDS path 0.45-0.52 for N = 256 .. 2048 (0.24-0.39 for the half-wave blocks of N <= 128 and the
+//     profiles/r03_quarter_swizzle.txt, r03_contract_registers.txt): a user's fill / call / drain kernel 0.65-0.94 of their
+//     rate (round 2, one working wave per block: 0.14-0.55), the two-argument kernels below -- which for N >= 256 hand the
+//     block's registers to do_SMFFT_CT_DIT_registers -- 0.72-0.97; in-LDS path 0.45-0.52 for N = 256 .. 2048 (0.24-0.39 for the half-wave blocks of N <= 128 and the
 //     16-wave blocks of N = 4096) -- five LDS round trips of the whole FFT per transform (4 reads + 4 writes per thread
 //     and pass) against two-and-a-half of the 16-elements-per-thread engine.  Kernels that want the
 //     engine's speed use form (2) or the Engine directly (examples/fft_convolution.hip).
@@ -162,9 +163,14 @@ __host__ __device__ constexpr int quarter_swizzle(int i) {
 }
 
 // BLOCK_THREADS: threads the caller's block has (what decides between a wave-level fence and a workgroup barrier);
-// s: the block's LDS region, region_offset: where this thread's transform starts in it (f * N)
-template <int N, int DIR, int REORDER, int BLOCK_THREADS>
-__device__ __forceinline__ void quarter_fft_inplace(float2* s, int t, int region_offset = 0) {
+// s: the block's LDS region, region_offset: where this thread's transform starts in it (f * N).
+// IN_REGS: the first pass takes its four inputs from x[] instead of loading them from s -- x[m] = element t + m N/4 (natural
+// order) or 4 t + m (no reorder) of the transform: exactly what the pass would load -- and s only has to be FREE at the
+// call; OUT_REGS: the last pass leaves its four results, elements t + m N/4, in x[] instead of storing them.  Both:
+// the transform of a thread block's registers with s as scratch -- one LDS round trip and one synchronisation less at
+// either end (the kernels in the reference's launch shape below use it for N >= 256).
+template <int N, int DIR, int REORDER, int BLOCK_THREADS, bool IN_REGS = false, bool OUT_REGS = false>
+__device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, int region_offset = 0) {
     using R = QuarterTwiddleRows<N>;
     constexpr int Q = N / 4;
     constexpr bool kBarrier = BLOCK_THREADS > 64;
@@ -186,14 +192,14 @@ __device__ __forceinline__ void quarter_fft_inplace(float2* s, int t, int region
     int a;
     if constexpr (REORDER) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) e[((m & 1) << 1) | (m >> 1)] = sf[t + m * Q];      // e[i] = x[bitrev(4j + i)], i = rev2(m)
+        for (int m = 0; m < 4; ++m) e[((m & 1) << 1) | (m >> 1)] = IN_REGS ? x[m] : sf[t + m * Q];   // e[i] = x[bitrev(4j + i)], i = rev2(m)
         a = 4 * (int)(T_BITS ? __brev((unsigned)t) >> (32 - (T_BITS ? T_BITS : 1)) : 0);
-        fft_sync<kBarrier>();                                                           // every load precedes the scattered stores
+        if constexpr (!IN_REGS) fft_sync<kBarrier>();                                   // every load precedes the scattered stores
     } else {
         a = 4 * t;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) e[i] = sf[a + i];
-        if constexpr (kSwizzled && kLastQuad != 0) fft_sync<kBarrier && !kWaveLocal>();  // ... and the swizzled ones (same wave's)
+        for (int i = 0; i < 4; ++i) e[i] = IN_REGS ? x[i] : sf[a + i];
+        if constexpr (!IN_REGS && kSwizzled && kLastQuad != 0) fft_sync<kBarrier && !kWaveLocal>();  // ... and the swizzled ones (same wave's)
     }
     {
         const float2 s0 = cadd(e[0], e[1]), d0 = csub(e[0], e[1]), s1 = cadd(e[2], e[3]), d1 = csub(e[2], e[3]);
@@ -225,8 +231,12 @@ __device__ __forceinline__ void quarter_fft_inplace(float2* s, int t, int region
             const float2 u2 = cmul(y2, w2), v3 = cmul(y3, w2);
             const float2 u3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);  // y3 * w2 * (-+i)
             if (p == kLastQuad) {
-                if constexpr (kSwizzled) fft_sync<kBarrier && !kWaveLocal>();            // every swizzled load precedes the natural stores (same wave's)
-                sf[base] = cadd(y0, u2), sf[base + 2 * P] = csub(y0, u2), sf[base + P] = cadd(y1, u3), sf[base + 3 * P] = csub(y1, u3);
+                if constexpr (OUT_REGS) {                                                // base = t, P = N / 4
+                    x[0] = cadd(y0, u2), x[2] = csub(y0, u2), x[1] = cadd(y1, u3), x[3] = csub(y1, u3);
+                } else {
+                    if constexpr (kSwizzled) fft_sync<kBarrier && !kWaveLocal>();        // every swizzled load precedes the natural stores (same wave's)
+                    sf[base] = cadd(y0, u2), sf[base + 2 * P] = csub(y0, u2), sf[base + P] = cadd(y1, u3), sf[base + 3 * P] = csub(y1, u3);
+                }
             } else {
                 s[a0] = cadd(y0, u2), s[a2] = csub(y0, u2), s[a1] = cadd(y1, u3), s[a3] = csub(y1, u3);
             }
@@ -241,12 +251,22 @@ __device__ __forceinline__ void quarter_fft_inplace(float2* s, int t, int region
         const float2 x0 = s[a0], x1 = s[a0 ^ quarter_swizzle(N / 2)], x2 = s[a0 ^ quarter_swizzle(Q)], x3 = s[a0 ^ quarter_swizzle(3 * Q)];
         const float2 t1 = cmul(x1, w), v3 = cmul(x3, w);
         const float2 t3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);
-        if constexpr (kSwizzled) fft_sync<kBarrier && !kWaveLocal>();
-        sf[t] = cadd(x0, t1);
-        sf[t + N / 2] = csub(x0, t1);
-        sf[t + Q] = cadd(x2, t3);
-        sf[t + 3 * Q] = csub(x2, t3);
+        if constexpr (OUT_REGS) {
+            x[0] = cadd(x0, t1), x[2] = csub(x0, t1), x[1] = cadd(x2, t3), x[3] = csub(x2, t3);
+        } else {
+            if constexpr (kSwizzled) fft_sync<kBarrier && !kWaveLocal>();
+            sf[t] = cadd(x0, t1);
+            sf[t + N / 2] = csub(x0, t1);
+            sf[t + Q] = cadd(x2, t3);
+            sf[t + 3 * Q] = csub(x2, t3);
+        }
     }
+}
+// in place on the LDS region (the reference's contract)
+template <int N, int DIR, int REORDER, int BLOCK_THREADS>
+__device__ __forceinline__ void quarter_fft_inplace(float2* s, int t, int region_offset = 0) {
+    float2 unused[4];
+    quarter_fft<N, DIR, REORDER, BLOCK_THREADS, false, false>(unused, s, t, region_offset);
 }
 
 // Hermitian split / merge on the reference's thread shape (L/4 threads, two pairs each: i = t + 1 and t + 1 + L/4, RC:289-328)
@@ -326,6 +346,23 @@ __device__ void do_SMFFT_CT_DIT(float2* s_input) {
     smfft::quarter_fft_inplace<N, const_params::fft_direction, const_params::fft_reorder, kBlock>(s_input, t, f * N);
 }
 
+// The same transform on the block's REGISTERS, in the reference's thread shape (an extension; N >= 256, blockDim.x = N / 4):
+// x[m] = element threadIdx.x + m N/4 of the block's transform going in (no-reorder classes: element 4 threadIdx.x + m --
+// what the first pass consumes) and element threadIdx.x + m N/4 of the result coming out; s_scratch = P::fft_sm_required
+// float2 of LDS that nobody is still reading.  For kernels that load from and store to global memory anyway: one LDS round
+// trip and one synchronisation less at either end than do_SMFFT_CT_DIT between a fill and a drain of s.
+template <class const_params>
+__device__ void do_SMFFT_CT_DIT_registers(float2 (&x)[4], float2* s_scratch) {
+    constexpr int N = const_params::fft_size;
+    static_assert(N >= 256 && const_params::fft_length == N, "one transform per block of N / 4 threads");
+    smfft::quarter_fft<N, const_params::fft_direction, const_params::fft_reorder, N / 4, true, true>(x, s_scratch, threadIdx.x);
+}
+template <class const_params, class const_direction>
+__device__ void do_FFT_Stockham_C2C_registers(float2 (&x)[4], float2* s_scratch) {
+    constexpr int N = const_params::fft_length;
+    smfft::quarter_fft<N, const_direction::fft_direction, 1, N / 4, true, true>(x, s_scratch, threadIdx.x);
+}
+
 template <class const_params>
 __device__ void do_FFT_Stockham_mk6(float2* s_input) {
     constexpr int N = const_params::fft_length;
@@ -356,10 +393,27 @@ __device__ void do_FFT_Stockham_R2C_C2R(float2* s_input) {
     __syncthreads();   // as upstream: the forward branch ends behind a barrier (RC:330), the inverse one in do_FFT_Stockham_C2C
 }
 
-// ---- kernels in the reference's launch shape (own text; same loads, stores and barriers as CT:534-572) ----
+// ---- kernels in the reference's launch shape (own text; CT:534-572) ----
+// (N >= 256: the block's transform on registers -- the four loads of a thread are what the first pass consumes and the last
+//  pass's results are what it stores; SMFFT_CONTRACT_FUSED_IO=0 keeps the fill / call / drain form of CT:534-551, which is also
+//  what a user's kernel around do_SMFFT_CT_DIT looks like: examples/reference_shape_kernel.hip)
+#ifndef SMFFT_CONTRACT_FUSED_IO
+#define SMFFT_CONTRACT_FUSED_IO 1
+#endif
 template <class const_params>
 __global__ void SMFFT_DIT_external(float2* d_input, float2* d_output) {
     __shared__ float2 s_input[const_params::fft_sm_required];
+    if constexpr (SMFFT_CONTRACT_FUSED_IO && const_params::fft_size >= 256) {
+        const int block = blockIdx.x * const_params::fft_length;
+        float2 x[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            x[m] = const_params::fft_reorder ? d_input[block + threadIdx.x + m * const_params::fft_length_quarter] : d_input[block + 4 * threadIdx.x + m];
+        do_SMFFT_CT_DIT_registers<const_params>(x, s_input);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) d_output[block + threadIdx.x + m * const_params::fft_length_quarter] = x[m];
+        return;
+    }
     const int base = threadIdx.x + blockIdx.x * const_params::fft_length;
     s_input[threadIdx.x] = d_input[base];
     s_input[threadIdx.x + const_params::fft_length_quarter] = d_input[base + const_params::fft_length_quarter];
@@ -399,6 +453,15 @@ __global__ void FFT_GPU_external(float2* d_input, float2* d_output) {
     extern __shared__ float2 s_input_dynamic[];
     float2* s_input = s_input_dynamic;
     const int base = threadIdx.x + blockIdx.x * const_params::fft_length;
+    if constexpr (SMFFT_CONTRACT_FUSED_IO) {
+        float2 x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = d_input[base + k * const_params::fft_quarter];
+        do_FFT_Stockham_C2C_registers<const_params, FFT_inverse>(x, s_input);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d_output[base + k * const_params::fft_quarter] = x[k];
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) s_input[threadIdx.x + k * const_params::fft_quarter] = d_input[base + k * const_params::fft_quarter];
     __syncthreads();

@@ -262,7 +262,8 @@ def test_harness_programs(sm, prog, args, expect):
 # ------------------------------------------- device functions called from a user kernel (examples/)
 @pytest.mark.parametrize("n,sym", [(1024, "smfft_example_convolve_1024"), (256, "smfft_example_convolve_256"),
                                    (1024, "smfft_example_convolve_1024_registers"),
-                                   (1024, "smfft_example_reference_shape_convolve_1024")])
+                                   (1024, "smfft_example_reference_shape_convolve_1024"),
+                                   (1024, "smfft_example_reference_shape_convolve_1024_registers")])
 def test_example_convolution_kernel(sm, n, sym):
     """examples/fft_convolution.hip: a user kernel chaining do_SMFFT_CT_DIT<forward> -> .* H ->
     do_SMFFT_CT_DIT<inverse> in LDS (the library use case, reference README.md:10-16)."""
@@ -326,8 +327,10 @@ def test_reference_shaped_kernel_matches_oracle(sm, oracle_lib, n, inv, reo, whi
 
 @pytest.mark.parametrize("n", C2C_SIZES)
 @pytest.mark.parametrize("reo", [1, 0])
-def test_reference_shaped_kernel_full_occupancy(sm, n, reo):
-    """The same kernels on 2^22 elements (every CU full of their blocks, several rounds): the engine's wave-level fences and
+@pytest.mark.parametrize("which", [0, 1])
+def test_reference_shaped_kernel_full_occupancy(sm, n, reo, which):
+    """The same kernels (0: the user-written fill / do_SMFFT_CT_DIT / drain kernel, 1: the library's two-argument kernel, which
+    for N >= 256 transforms the block's registers with do_SMFFT_CT_DIT_registers) on 2^22 elements (every CU full of their blocks, several rounds): the engine's wave-level fences and
     its swizzled LDS image hold under contention -- every FFT of the batch agrees with the library's tiled kernel within
     the fp32 tolerance, and a second launch gives the same bits."""
     import ctypes
@@ -338,14 +341,14 @@ def test_reference_shaped_kernel_full_occupancy(sm, n, reo):
     rng = np.random.default_rng(77 * n + reo)
     x = (rng.random((nffts, n), dtype=np.float32) - 0.5 + 1j * (rng.random((nffts, n), dtype=np.float32) - 0.5)).astype(np.complex64)
     dx, dy = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
-    assert fn(dx.ptr, dy.ptr, n, nffts, 0, reo, 1, None) == 0
+    assert fn(dx.ptr, dy.ptr, n, nffts, 0, reo, which, None) == 0
     assert sm.lib.smfft_synchronize() == 0
     got = dy.to_host(np.complex64, x.shape)
     want = sm.c2c(x, inverse=False, reorder=bool(reo)).astype(np.complex128)
     l2, mx = ref.fft_errors(got, want)
     assert l2 < 5e-7 and mx < 1e-6, (n, reo, l2, mx)
     sm.lib.smfft_memset(dy.ptr, 0xFF, x.nbytes)
-    assert fn(dx.ptr, dy.ptr, n, nffts, 0, reo, 1, None) == 0
+    assert fn(dx.ptr, dy.ptr, n, nffts, 0, reo, which, None) == 0
     assert sm.lib.smfft_synchronize() == 0
     assert np.array_equal(dy.to_host(np.complex64, x.shape).view(np.uint32), got.view(np.uint32))
 

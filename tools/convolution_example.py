@@ -44,6 +44,7 @@ def timed(fn, reps=11, warm=3):
 
 gb = 2 * NS * N * 8 / 1e9
 for name, sym in (("reference contract (blockDim = N/4)", "smfft_example_reference_shape_convolve_1024"),
+                  ("reference thread shape, register form", "smfft_example_reference_shape_convolve_1024_registers"),
                   ("tiled device functions", "smfft_example_convolve_1024"),
                   ("register-level engine", "smfft_example_convolve_1024_registers")):
     fn = getattr(ex, sym)

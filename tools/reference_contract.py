@@ -85,8 +85,9 @@ for n in [int(v) for v in args.sizes.split(",")]:
         continue
     for reo in (1, 0):
         ref = timed(lambda: ex.smfft_example_reference_shape_ct(a, b, n, nffts, 0, reo, 1, None))
+        usr = timed(lambda: ex.smfft_example_reference_shape_ct(a, b, n, nffts, 0, reo, 0, None))
         lib = lib_ms(lambda t: sm.lib.smfft_ct_external_benchmark(a, b, n, nffts, 0, reo, t))
-        print(f"external N={n} reorder={reo}: reference contract {ref:.3f} ms {gb / ref:.2f} TB/s | tiled {lib:.3f} ms {gb / lib:.2f} TB/s | ratio {lib / ref:.2f}", flush=True)
+        print(f"external N={n} reorder={reo}: two-argument kernel {ref:.3f} ms {gb / ref:.2f} TB/s | user kernel (fill / call / drain) {usr:.3f} ms | tiled {lib:.3f} ms {gb / lib:.2f} TB/s | ratios {lib / ref:.2f} {lib / usr:.2f}", flush=True)
     if n >= 256:
         ref = timed(lambda: ex.smfft_example_reference_shape_st(a, b, n, nffts, None))
         lib = lib_ms(lambda t: sm.lib.smfft_st_external_benchmark(a, b, n, nffts, t))
