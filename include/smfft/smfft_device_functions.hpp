@@ -489,6 +489,32 @@ template <class const_params, class const_direction>
 __global__ void FFT_GPU_R2C_C2R_external(float2* d_input, float2* d_output) {
     __shared__ float2 s_input[const_params::fft_length + 1];
     const int base = threadIdx.x + blockIdx.x * const_params::fft_length;
+    if constexpr (SMFFT_CONTRACT_FUSED_IO) {
+        // the complex transform takes its inputs from (R2C) / leaves its results in (C2R) the thread's registers; the split /
+        // merge works on the natural layout in LDS as upstream (RC:269-344)
+        constexpr int L = const_params::fft_length;
+        float2 x[4];
+        if constexpr (const_direction::fft_direction == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = d_input[base + k * const_params::fft_quarter];
+            smfft::quarter_fft<L, 0, 1, L / 4, true, false>(x, s_input, threadIdx.x);
+            __syncthreads();
+            smfft::hermitian_pass_quarter<L, 0>(s_input, threadIdx.x);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d_output[base + k * const_params::fft_quarter] = s_input[threadIdx.x + k * const_params::fft_quarter];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_input[threadIdx.x + k * const_params::fft_quarter] = d_input[base + k * const_params::fft_quarter];
+            __syncthreads();
+            smfft::hermitian_pass_quarter<L, 1>(s_input, threadIdx.x);
+            __syncthreads();
+            smfft::quarter_fft<L, 1, 1, L / 4, false, true>(x, s_input, threadIdx.x);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d_output[base + k * const_params::fft_quarter] = x[k];
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) s_input[threadIdx.x + k * const_params::fft_quarter] = d_input[base + k * const_params::fft_quarter];
     __syncthreads();

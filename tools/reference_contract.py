@@ -92,6 +92,14 @@ for n in [int(v) for v in args.sizes.split(",")]:
         ref = timed(lambda: ex.smfft_example_reference_shape_st(a, b, n, nffts, None))
         lib = lib_ms(lambda t: sm.lib.smfft_st_external_benchmark(a, b, n, nffts, t))
         print(f"Stockham external N={n}: reference contract {ref:.3f} ms {gb / ref:.2f} TB/s | tiled {lib:.3f} ms {gb / lib:.2f} TB/s | ratio {lib / ref:.2f}", flush=True)
+    if n >= 512:
+        # R2C / C2R program, real length n: FFT_GPU_R2C_C2R_external<FFT_{n/2}, D><<<nFFTs, n/8>>> against the tiled kernels (2 GiB in + 2 GiB out)
+        rnffts = TOTAL // n
+        rgb = 2 * rnffts * n * 4 / 1e9
+        for inv in (0, 1):
+            ref = timed(lambda: ex.smfft_example_reference_shape_rc(a, b, n, rnffts, inv, None))
+            lib = lib_ms(lambda t: sm.lib.smfft_rc_external_benchmark(a, b, n, rnffts, inv, t))
+            print(f"{'C2R' if inv else 'R2C'} external real N={n}: two-argument kernel {ref:.3f} ms {rgb / ref:.2f} TB/s | tiled {lib:.3f} ms {rgb / lib:.2f} TB/s | ratio {lib / ref:.2f}", flush=True)
     if n == 1024:
         slots = nffts // 100
         for which, name, call in ((0, "CT multiple reorder", lambda t: sm.lib.smfft_ct_multiple_benchmark(a, b, n, nffts, 0, 1, t)),
