@@ -647,8 +647,15 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
     rec.va_bytes = need * kHandleBytes;
     rec.searched = true;
     // how the kernels pace their stores into it (pacing_for): by what the output CONSISTS of -- mixed or interleaved memory
-    // takes writes like mixed memory whether or not the scan could also call the result good
-    rec.mixed = 2 * (best.mixed_used + best.interleaved_used) >= need;
+    // takes writes like mixed memory whether or not the scan could also call the result good -- unless the timed pass says
+    // that this blend is no better than ordinary memory (a box whose scanned memory is all ONE class: what the interleave
+    // probes' noise called another class is not; the count for ordinary memory is then worth its 2-8 %)
+    bool helps = true;
+    if (in && info.first_ordinary_copy_ms > 0.f && best_ms < 1e29f) {
+        const double whole = (double)(need * kHandleBytes), window = (double)(bytes < kChunkBytes ? bytes : kChunkBytes);
+        helps = (double)best_ms / whole < 0.97 * (double)info.first_ordinary_copy_ms / window;
+    }
+    rec.mixed = helps && 2 * (best.mixed_used + best.interleaved_used) >= need;
     info.candidates = (int)chunks.size();
     info.candidate_bytes = created;
     info.chosen = (int)((best.mixed_used * kHandleBytes + kChunkBytes - 1) / kChunkBytes);
