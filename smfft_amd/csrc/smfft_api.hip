@@ -416,10 +416,12 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
         arena_give_back(slot, kChunkBytes);
         if (!ok) (void)hipGetLastError();
         if (getenv("SMFFT_PAIR_DEBUG")) printf("smfft_malloc_pair: interleave probe %.3f ms (own passes %.3f, %.3f)\n", ms, x.write_ms, y.write_ms);
-        // two classes interleaved write like mixed memory: below the split's threshold, or (no split yet) 7 % under the two own passes
+        // two classes interleaved write like mixed memory (0.80-0.83 of the chunks' own passes): below the split's threshold, or
+        // (no split yet) 12 % under the two own passes -- 7 % was within the noise of the 1 GiB passes: on a box whose first
+        // 93 GiB were ONE class it called six of them another one, and the blend built from those was half as good as it should be
         const WriteSplit w = split();
         const float own = 0.5f * (x.write_ms + y.write_ms);
-        return ms < (w.accepted ? std::min(w.mixed_below, 0.96f * own) : 0.93f * own);
+        return ms < (w.accepted ? std::min(w.mixed_below, 0.96f * own) : 0.88f * own);
     };
     // Scans until the output is covered (mixed memory plus equal parts of two classes) and `lookahead` chunks further -- so
     // that either recipe alone, all mixed or all interleaved, may become complete and spare mixed chunks let the output take
