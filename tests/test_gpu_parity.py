@@ -701,7 +701,7 @@ def test_malloc_pair_bounded_search(sm, monkeypatch):
     use(a, b)
     assert info["bytes"] == nbytes and info["candidates"] >= 1 and 0 <= info["chosen"] <= info["candidates"]
     assert info["candidate_bytes"] <= 0.25 * free0 + (1 << 30)              # the byte budget (a quarter of the free memory) + one chunk
-    assert info["search_ms"] <= 2000 + 2500 and took < 8.0, (info, took)   # the time budget (+ the last chunks and the timed candidates)
+    assert info["search_ms"] <= 2 * 2000 + 2500 and took < 10.0, (info, took)   # the time budget (+ the last chunks and the timed candidates; twice on a device whose free memory starts with one class: the scan is repeated once)
     assert info["copy_ms"] <= info["first_copy_ms"] * 1.05                  # never worse than the first chunk seen (a box of ONE memory class: equal within the probes' noise)
     assert _settled_usage(sm, free0, 2 * nbytes + (256 << 20)) <= 2 * nbytes + (256 << 20)   # only the pair (+ page tables) is still allocated
     print("smfft_malloc_pair:", info)
