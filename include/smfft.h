@@ -172,12 +172,12 @@ typedef struct SmfftPairInfo {
     unsigned long long candidate_bytes;  /* physical memory the scan held at its end (<= max(byte budget + 1 GiB, bytes)) */
     int candidates;                      /* mixed policy: GiB chunks scanned (+1 if a remainder was created unprobed); candidates policy: blocks probed; 0: plain */
     int chosen;                          /* mixed policy: GiB of mixed memory in the output; candidates policy: index of the block kept */
-    int good_enough;                     /* 1: a pass into the output beats the same pass into ordinary memory measured in the same scan by the margin mixed memory shows on this device */
+    int good_enough;                     /* 1: the whole-pair copy from the input into the output takes at most 2.31 x the pure read pass over the input (good outputs: 2.18-2.29 x, ordinary memory of the input's class: 2.49-2.61 x); without an input: a write pass into it beats the scan's ordinary chunks by the margin its mixed chunks show */
     float read_ms, copy_ms, first_copy_ms;   /* over min(bytes, 1 GiB): pure read of the input; copy into the output; copy into the first chunk / block seen */
     double search_ms;
     unsigned long long mixed_bytes;        /* mixed policy: bytes of the output that are mixed memory ... */
     unsigned long long interleaved_bytes;  /* ... and bytes that are ordinary memory of two classes interleaved in 8 MiB handles */
-    float first_ordinary_copy_ms;        /* over min(bytes, 1 GiB): copy into the first clearly ordinary chunk of the scan (the yardstick of good_enough) */
+    float first_ordinary_copy_ms;        /* over min(bytes, 1 GiB): copy into the first clearly ordinary chunk of the scan (reported; good_enough is judged against the input's read pass) */
     int classification;                  /* 1: the scan's write times split into a fast (mixed) and a slow (ordinary) cluster; 0: inconclusive -- nothing was called mixed */
 } SmfftPairInfo;
 int smfft_last_pair_info(SmfftPairInfo* out);

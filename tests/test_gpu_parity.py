@@ -701,9 +701,7 @@ def test_malloc_pair_bounded_search(sm, monkeypatch):
     use(a, b)
     assert info["bytes"] == nbytes and info["candidates"] >= 1 and 0 <= info["chosen"] <= info["candidates"]
     assert info["candidate_bytes"] <= 0.25 * free0 + (1 << 30)              # the byte budget (a quarter of the free memory) + one chunk
-    # the time budget (2 s + the last chunks and the timed candidates), twice where the scan is repeated (a device whose free memory
-    # starts with one class)
-    assert info["search_ms"] <= 2 * (2000 + 2500) and took < 12.0, (info, took)
+    assert info["search_ms"] <= 2000 + 2500 and took < 8.0, (info, took)   # the time budget (+ the last chunks and the timed candidates)
     # not worse than the first chunk seen (on a device of ONE class the fallback output measured up to 6 % slower than the
     # 1 GiB window into a single chunk)
     assert info["copy_ms"] <= info["first_copy_ms"] * 1.10, info
@@ -742,7 +740,8 @@ def test_malloc_pair_bounded_search(sm, monkeypatch):
     assert sm.lib.smfft_malloc_pair(2 * nbytes, ctypes.byref(a), ctypes.byref(b)) == 0
     info = sm.last_pair_info()
     print("interleave only:", info)
-    assert info["mixed_bytes"] == 0 and info["interleaved_bytes"] <= 2 * nbytes and (not info["good_enough"] or info["interleaved_bytes"] == 2 * nbytes)
+    # (a good output is either fully interleaved or whole chunks of a single class that pairs well with the input's)
+    assert info["mixed_bytes"] == 0 and info["interleaved_bytes"] <= 2 * nbytes and (not info["good_enough"] or info["interleaved_bytes"] in (0, 2 * nbytes))
     handle = 8 << 20
     pats = [np.full(1024, k + 1, dtype=np.uint32) for k in range(2 * nbytes // handle)]
     for k, pat in enumerate(pats):
@@ -786,7 +785,7 @@ def _settled_usage(sm, free0, limit):
     """bytes in use relative to free0 once the driver has caught up (released VRAM is returned asynchronously)"""
     import time
     used = free0 - _free_bytes(sm)
-    for _ in range(100):     # up to 10 s: a repeated scan (a device whose free memory starts with one class) releases 2 x 70 GiB
+    for _ in range(50):      # up to 5 s: a scan that ran to its budget releases 70 GiB
         if used <= limit:
             break
         time.sleep(0.1)

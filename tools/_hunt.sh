@@ -1,11 +1,14 @@
 #!/bin/bash
-SMFFT_PAIR_NO_RESCAN=1 timeout 200 python tools/uniform_box_probe.py > gpurun_out/probe0.txt 2>&1
-if grep -q "UNIFORM" gpurun_out/probe0.txt; then
-  echo "RESULT uniform"
-  grep -E "default budget|UNIFORM" gpurun_out/probe0.txt | cut -c1-420 | sed 's/^/NO_RESCAN /'
-  timeout 200 python tools/uniform_box_probe.py 2>&1 | grep -E "default budget|UNIFORM|ordinary" | cut -c1-420 | sed 's/^/RESCAN /'
-  timeout 200 python tools/uniform_box_probe.py 2>&1 | grep -E "default budget|UNIFORM|ordinary" | cut -c1-420 | sed 's/^/RESCAN2 /'
-  timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "malloc or pacing or allocator or retired or written" 2>&1 | grep -E "passed|failed"
-else
-  echo "RESULT ordinary"
+timeout 200 python tools/_detect.py > gpurun_out/detect.txt 2>&1
+cat gpurun_out/detect.txt | grep DETECT
+if grep -q "DETECT uniform" gpurun_out/detect.txt; then
+  timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|assert|^E " | head -30
+  timeout 400 python bench.py --no-configs --no-cpu-baseline 2>/dev/null > gpurun_out/bench_uniform.json
+  python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/bench_uniform.json").read().strip().splitlines()[-1])
+print("BENCH", d["roofline"]["frac"], d["roofline"]["frac_of_copy"], d["pair_alloc_s"],
+      [(a["candidates"], a["good_enough"], a["interleaved_bytes"] >> 30, round(a["search_ms"])) for a in d["pair_attempts"]],
+      d["roofline_plain"]["frac"], d["roofline_own_input"]["frac"])
+PY
 fi
