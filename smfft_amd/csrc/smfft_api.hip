@@ -595,6 +595,7 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
     };
     bool tried_single[2] = {false, false};
     bool confirmed = false;
+    float round_start_best = 1e30f;
     const bool compare = getenv("SMFFT_PAIR_NO_COMPARE") == nullptr;
     const size_t max_rounds = budget.ms > 5000.0 ? 16 : 4;      // a caller that grants a long scan (smfft_malloc_pair_budget) gets more tries
     for (size_t lookahead = 6, round = 0; round < max_rounds && api_ok; lookahead += 8, ++round) {
@@ -632,10 +633,12 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
         if (getenv("SMFFT_PAIR_DEBUG"))
             printf("smfft_malloc_pair: after %zu chunks: mixed first %.4f ms%s as the target of a %s pass over the whole buffer (input read %.4f ms; whole chunks of one class: %.4f / %.4f ms; best %.4f): %s\n", chunks.size(), ms[0],
                    ncand > 1 ? (std::string(", interleaved only ") + std::to_string(ms[1]) + " ms").c_str() : "", in ? "copy" : "write", read_whole_ms, single_ms[0], single_ms[1], best_ms, good ? "good" : "not good");
-        // one more round after the first good candidate: eight more chunks give the recipes more to choose from (the same box
-        // gave 0.793 after 10 chunks and 0.807 after 35), the best seen is kept
-        if (!more || (good && confirmed)) break;
+        // more rounds after the first good candidate while they still pay: eight more chunks give the recipes more to choose
+        // from (the same box gave 0.793 after 10 chunks and 0.807 after 35); the scan ends with the first round that does not
+        // improve the best candidate by 1 %
+        if (!more || (good && confirmed && best_ms > 0.99f * round_start_best)) break;
         if (good) confirmed = true;
+        round_start_best = best_ms;
     }
     if (getenv("SMFFT_PAIR_DEBUG")) {
         printf("smfft_malloc_pair scan: %zu chunks, write ms per GiB (class):", chunks.size());
