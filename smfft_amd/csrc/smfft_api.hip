@@ -585,7 +585,8 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
     // 2.34 x into a blend half made of mis-called chunks, 2.49-2.61 x into ordinary memory of the input's class.  With an input,
     // good = at most kGoodCopyOverRead x the read pass; without one (smfft_malloc_written: write passes only) the split of the
     // chunks' write times decides as before.  The single-class outputs are candidates like the two blends.
-    constexpr float kGoodCopyOverRead = 2.31f, kLightPacingCopyOverRead = 2.38f;
+    // (the scan itself only ends early on kStopCopyOverRead: a candidate between the two is acceptable, but more rounds are tried)
+    constexpr float kGoodCopyOverRead = 2.31f, kStopCopyOverRead = 2.25f, kLightPacingCopyOverRead = 2.38f;
     auto single_class = [&](Kind kind) {
         Built b;
         for (auto& c : chunks)
@@ -636,8 +637,9 @@ bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int devi
         // more rounds after the first good candidate while they still pay: eight more chunks give the recipes more to choose
         // from (the same box gave 0.793 after 10 chunks and 0.807 after 35); the scan ends with the first round that does not
         // improve the best candidate by 1 %
-        if (!more || (good && confirmed && best_ms > 0.99f * round_start_best)) break;
-        if (good) confirmed = true;
+        const bool excellent = (in && read_whole_ms > 0.f) ? best_ms <= kStopCopyOverRead * read_whole_ms : good;
+        if (!more || (excellent && confirmed && best_ms > 0.99f * round_start_best)) break;
+        if (excellent) confirmed = true;
         round_start_best = best_ms;
     }
     if (getenv("SMFFT_PAIR_DEBUG")) {
