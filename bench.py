@@ -211,6 +211,109 @@ def device_info(torch, dev):
     return info
 
 
+def _sig(x, digits=6):
+    """floats to `digits` significant digits (the compact line is bounded), NaN / inf -> None (strict JSON)"""
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"%.{digits}g" % x)
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _get(d, *path, default=None):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+def _minmax(values):
+    vals = [v for v in values if isinstance(v, (int, float)) and v == v]
+    return [min(vals), max(vals)] if vals else None
+
+
+COMPACT_LIMIT = 4096      # bytes: the driver's parser lost round 3's 22.6 KB line
+REQUIRED_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline", "cpu_baseline", "pair_search", "comm_backend", "ranks_seen", "spot_check_relL2")
+
+
+def compact_line(detail):
+    """The ONE line of the driver contract, built from the full record (`detail`, written to bench_detail.json): the contract's
+    keys, `roofline` and `cpu_baseline`, the outcome of every allocation attempt, the per-rank list, and a dozen scalars that
+    summarise configs 3 / 4 and the reference-contract path.  Strict JSON (no NaN), under COMPACT_LIMIT bytes."""
+    roof = dict(detail["roofline"])
+    src = roof.get("traffic_source")
+    if isinstance(src, dict):
+        roof["traffic_source"] = f"{src.get('file')}@{src.get('commit')} (separate --pmc passes of this command)"
+    plain, own = detail.get("roofline_plain"), detail.get("roofline_own_input")
+    cpu = detail.get("cpu_baseline")
+    if cpu:
+        cpu = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "sample", "GB/s")}
+        cpu["sample"] = (cpu["sample"] or "")[:120]
+        cpu["impl"] = (detail["cpu_baseline"].get("impl") or "")[:60]
+    attempts = []
+    for a in detail.get("pair_attempts") or []:
+        attempts.append({"budget": (a.get("budget") or "")[:7], "good_enough": a.get("good_enough"), "classification": a.get("classification"),
+                         "copy_ms": a.get("copy_ms"), "read_ms": a.get("read_ms"), "chunks": a.get("candidates"),
+                         "seconds": (a.get("search_ms") or 0.0) / 1e3, "kept": bool(a.get("kept"))})
+    cfg = detail.get("configs") or {}
+    c3, c4, c2 = cfg.get("config3_multiple") or {}, cfg.get("config4_r2c_c2r_external") or {}, cfg.get("config2_external_by_length") or {}
+    cref = cfg.get("reference_contract") or {}
+    by_len = cref.get("by_length") or {}
+    summary = {
+        # the in-LDS path at N = 1024, FFT/s: what ONE call of the device function costs (contract path; the compact kernel
+        # without cross-application fusion) next to the fused compact kernel (DESIGN.md section 5.2)
+        "in_lds_1024_contract_FFTps": _minmax([_get(cref, "ct_multiple_reorder", "FFT/s"), _get(cref, "ct_multiple_noreorder", "FFT/s")]),
+        "in_lds_1024_unfused_FFTps": _get(cfg, "in_lds_1024_unfused", "FFT/s"),
+        "in_lds_1024_fused_FFTps": _minmax([_get(c3, "1024", "reorder", "FFT/s"), _get(c3, "1024", "noreorder", "FFT/s")]),
+        "config3_frac_fp32_peak": _minmax([_get(c3, k, o, "frac_fp32_peak") for k in c3 for o in ("reorder", "noreorder")]),
+        "config3_saturating_frac": _minmax([_get(c3, k, o, "saturating_batch", "frac_fp32_peak") for k in c3 for o in ("reorder", "noreorder")]),
+        "config3_frac_2048_4096": [_get(c3, k, o, "frac_fp32_peak") for k in ("2048", "4096") for o in ("reorder", "noreorder")],
+        "config2_by_length_frac": _minmax([_get(c2, k, o, "frac") for k in c2 for o in ("forward", "inverse", "forward_noreorder", "inverse_noreorder")]),
+        "config4_r2c_frac": _get(c4, "r2c", "frac"), "config4_c2r_frac": _get(c4, "c2r", "frac"),
+        "contract_external_ratio_to_tiled": _minmax([_get(by_len, k, o, "external_ratio_to_tiled") for k in by_len for o in ("reorder", "noreorder")]),
+        "contract_in_lds_ratio_to_compact": _minmax([_get(by_len, k, o, "in_lds_ratio_to_compact") for k in by_len for o in ("reorder", "noreorder")]),
+        "contract_small_N_external_ratio": [_get(by_len, k, "reorder", "external_ratio_to_tiled") for k in ("32", "64", "128")],
+        "contract_small_N_in_lds_ratio": [_get(by_len, k, "reorder", "in_lds_ratio_to_compact") for k in ("32", "64", "128")],
+        "hipfft_ms_on_pair": _get(detail, "vendor_hipfft", "ms_on_pair"),
+    }
+    line = {k: detail.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                       "vs_baseline", "dtype", "data")}
+    conf = dict(detail["config"])
+    conf["buffers"] = (conf.get("buffers") or "")[:60]
+    line.update({
+        "config": conf,
+        "hbm_GBps_per_gpu": detail.get("hbm_GBps_per_gpu"),
+        "roofline": roof,
+        "roofline_plain": {k: plain.get(k) for k in ("frac", "kernel_ms", "frac_of_copy")} if plain else None,
+        "roofline_own_input": {k: own.get(k) for k in ("frac", "kernel_ms")} if own else None,
+        "cpu_baseline": cpu,
+        "pair_search": attempts,
+        "per_rank": detail.get("per_rank"),
+        "value_sum_of_rates": detail.get("value_sum_of_rates"),
+        "multiple_path_FFTps": {k: _get(detail, "multiple_path", k, "FFT/s") for k in ("noreorder", "reorder")},
+        "summary": summary if cfg else None,
+        "comm_backend": detail.get("comm_backend"),
+        "ranks_seen": detail.get("ranks_seen"),
+        "spot_check_relL2": detail.get("spot_check_relL2"),
+        "detail": detail.get("detail_file"),
+    })
+    line = _sig(line)
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) >= COMPACT_LIMIT:          # never again an unparseable line: drop the optional parts, largest first
+        for k in ("summary", "per_rank", "roofline_own_input", "multiple_path_FFTps"):
+            line[k] = None
+            text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+            if len(text) < COMPACT_LIMIT:
+                break
+    return text
+
+
 def spawn_ranks(args):
     """--gpus N without a launcher: one child process per rank.  This parent has not initialised HIP (and never
     will): it imports neither torch.cuda state nor the library, so nothing is re-executed from a GPU process."""
@@ -329,6 +432,7 @@ def main():
         else:
             sm.lib.smfft_free_pair(pa2.value)
             pair_info["budget"] += " (kept: the patient attempt's output measured no better)"
+    pair_info["kept"] = True             # `value` / `roofline` are measured on this one
     vram["after_smfft_malloc_pair"] = vram_used_bytes(torch, dev)
     p_in = p_out = None
     if not args.no_plain:
@@ -378,7 +482,7 @@ def main():
         return time.perf_counter() - t0, ev0.elapsed_time(ev1) / args.steps
 
     # the plain pair first (so that the contract's timed region is the last thing before the reductions)
-    plain_wall, plain_kernel_ms = run_timed(p_in.ptr, p_out.ptr, False) if p_in else (float("nan"), float("nan"))
+    plain_wall, plain_kernel_ms = run_timed(p_in.ptr, p_out.ptr, False) if p_in else (0.0, 0.0)
     wall, kernel_ms = run_timed(pa.value, pb.value, True)
 
     # sanity on the timed output (cheap, outside the timed region): spot-check 4 FFTs of BOTH outputs against torch fp64
@@ -391,7 +495,7 @@ def main():
         err = max(err, (torch.linalg.vector_norm(ys - want) / torch.linalg.vector_norm(want)).item())
     assert err < 5e-7, f"timed output failed the spot check: relL2={err}"
 
-    from smfft_amd.sharding import reduce_stats
+    from smfft_amd.sharding import gather_stats, reduce_stats
     wall_max, kernel_ms_max, ranks_seen = reduce_stats(dist, stats_dev, wall, kernel_ms, 1)
     plain_wall_max, plain_kernel_ms_max, _ = reduce_stats(dist, stats_dev, plain_wall, plain_kernel_ms)
 
@@ -407,7 +511,13 @@ def main():
         torch.cuda.synchronize(dev)
         return c0.elapsed_time(c1) / 20
     pair_copy_ms = copy_ms(pa.value, pb.value)
-    plain_copy_ms = copy_ms(p_in.ptr, p_out.ptr) if p_in else float("nan")
+    # every rank's own outcome, so that a straggler (a rank whose allocator scan found no good output) shows in the line:
+    # `value` = world * nffts / max_g(t_g) is hostage to the slowest rank, sum_g(nffts / t_g) is what the ranks did separately
+    rows = gather_stats(dist, stats_dev, [wall, kernel_ms, float(pair_info["good_enough"]), pair_copy_ms, float(len(pair_attempts))])
+    per_rank = {"wall_ms_per_step": [r[0] / args.steps * 1e3 for r in rows], "kernel_ms": [r[1] for r in rows],
+                "good_enough": [int(r[2]) for r in rows], "copy_ms": [r[3] for r in rows], "attempts": [int(r[4]) for r in rows]}
+    value_sum_of_rates = sum(nffts / (r[0] / args.steps) for r in rows)
+    plain_copy_ms = copy_ms(p_in.ptr, p_out.ptr) if p_in else None
 
     # a caller's own plain input with only the OUTPUT taken from the library (smfft_malloc_written_for): the one-line change
     # for code that allocates its own buffers (N = 1 only; outside the contract's timed region, same pre-warm and step count)
@@ -618,6 +728,8 @@ def main():
             "pair_alloc_s": alloc_s,
             "pair_search": pair_info,
             "pair_attempts": pair_attempts,
+            "per_rank": per_rank,
+            "value_sum_of_rates": value_sum_of_rates,
             "vram_used_bytes": vram,
             "vendor_hipfft": vendor,
             "multiple_path": mult,
@@ -631,7 +743,21 @@ def main():
             out["cpu_baseline"] = cpu_baseline(host_in, os.cpu_count() or 1)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        # the full record goes to a file; stdout ends with ONE compact strict-JSON line (< 4 KB)
+        detail_path = os.environ.get("SMFFT_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+        out["detail_file"] = os.path.relpath(detail_path, ROOT) if detail_path.startswith(ROOT) else detail_path
+        out = _sig(out, 9)
+        try:
+            with open(detail_path, "w") as f:
+                json.dump(out, f, allow_nan=False, indent=1)
+            side = os.path.join(ROOT, "gpurun_out")
+            if os.path.isdir(side):
+                with open(os.path.join(side, "bench_detail.json"), "w") as f:
+                    json.dump(out, f, allow_nan=False, indent=1)
+        except OSError as e:
+            print(f"[bench] could not write {detail_path}: {e}", file=sys.stderr)
+            out["detail_file"] = None
+        print(compact_line(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -35,3 +35,16 @@ def reduce_stats(dist, device, wall_s: float, kernel_ms: float, errors: int = 0)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(e, op=dist.ReduceOp.SUM)
     return t[0].item(), t[1].item(), int(e.item())
+
+
+def gather_stats(dist, device, values):
+    """Every rank's list of floats, in rank order: [[rank 0's values], [rank 1's values], ...] on every rank (one
+    all_gather of a small tensor; a single process returns [values])."""
+    import torch
+
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if dist is None:
+        return [t.tolist()]
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [p.tolist() for p in parts]

@@ -1,0 +1,67 @@
+"""The driver contract's ONE line (bench.py compact_line): bounded, strict JSON, carrying the required objects.
+Round 3's line grew to 22.6 KB and the driver could not parse it."""
+import json
+import math
+import os
+
+import pytest
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RECORDED = [os.path.join(ROOT, "profiles", f) for f in ("r03_bench.json", "r03_bench_slow_box.json", "r02_bench.json")]
+
+
+def _strict(text):
+    def no_constants(name):
+        raise ValueError(f"non-strict JSON constant {name}")
+    return json.loads(text, parse_constant=no_constants)
+
+
+@pytest.mark.parametrize("path", [p for p in RECORDED if os.path.exists(p)])
+def test_compact_line_from_recorded_detail(path):
+    detail = json.load(open(path))
+    detail.setdefault("pair_attempts", [detail.get("pair_search") or {}])
+    text = bench.compact_line(detail)
+    assert "\n" not in text
+    assert len(text) < bench.COMPACT_LIMIT, len(text)
+    line = _strict(text)
+    for key in bench.REQUIRED_KEYS:
+        assert key in line, key
+    assert line["roofline"]["bound"] == "hbm"
+    for key in ("achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_launch", "copy_ceiling", "frac_of_copy"):
+        assert key in line["roofline"], key
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-4
+    assert line["config"]["workload"].startswith("config 2")
+    assert "model" not in line["config"]
+    assert isinstance(line["pair_search"], list) and line["pair_search"]
+    for a in line["pair_search"]:
+        for key in ("good_enough", "classification", "copy_ms", "chunks", "seconds"):
+            assert key in a
+    if line["cpu_baseline"]:
+        for key in ("value", "unit", "cores", "kind", "sample"):
+            assert key in line["cpu_baseline"]
+
+
+def test_compact_line_worst_case_is_bounded_and_strict():
+    """a detail record with NaN / inf in it, eight ranks, and overlong strings still gives a strict, bounded line"""
+    detail = json.load(open(RECORDED[0]))
+    detail["n_gpus"] = 8
+    detail["per_rank"] = {"wall_ms_per_step": [1.3071234567] * 8, "kernel_ms": [1.3064439392089844] * 8, "good_enough": [1] * 8,
+                          "copy_ms": [0.3633233308792114] * 8, "attempts": [2] * 8}
+    detail["value_sum_of_rates"] = float("inf")
+    detail["roofline_plain"] = dict(detail["roofline"], frac=float("nan"))
+    detail["pair_attempts"] = [dict(detail["pair_search"], budget="default: " + "x" * 500), dict(detail["pair_search"], budget="patient: " + "y" * 500, kept=True)]
+    detail["config"]["buffers"] = "z" * 2000
+    detail["cpu_baseline"]["sample"] = "s" * 2000
+    text = bench.compact_line(detail)
+    assert len(text) < bench.COMPACT_LIMIT, len(text)
+    line = _strict(text)
+    assert line["value_sum_of_rates"] is None and line["roofline_plain"]["frac"] is None
+    assert len(line["per_rank"]["kernel_ms"]) == 8
+    assert [a["kept"] for a in line["pair_search"]] == [False, True]
+
+
+def test_sig_rounds_and_removes_non_finite():
+    assert bench._sig(1.23456789012) == 1.23457
+    assert bench._sig({"a": [float("nan"), math.inf, 2]}) == {"a": [None, None, 2]}
