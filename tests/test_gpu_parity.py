@@ -1020,6 +1020,14 @@ def test_bench_two_ranks_on_one_device(sm):
     doc = json.loads(lines[0])
     assert doc["n_gpus"] == 2 and doc["ranks_seen"] == 2 and doc["comm_backend"] == "gloo"
     assert doc["value"] > 0 and doc["roofline"]["frac"] > 0 and doc["roofline_plain"]["frac"] > 0
+    # the line is the compact one (the driver's parser lost round 3's 22.6 KB line) and shows every rank's own outcome
+    assert len(lines[0]) < 4096
+    per_rank = doc["per_rank"]
+    for key in ("wall_ms_per_step", "kernel_ms", "good_enough", "copy_ms", "attempts"):
+        assert len(per_rank[key]) == 2, (key, per_rank)
+    assert max(per_rank["kernel_ms"]) == pytest.approx(doc["roofline"]["kernel_ms"], rel=1e-4)
+    assert doc["value_sum_of_rates"] >= doc["value"] * 0.999
+    assert len(doc["pair_search"]) >= 1 and sum(a["kept"] for a in doc["pair_search"]) == 1
 
 
 # ------------------------------------------------------------ analytic known-answer tests through the HIP path (8(c) item 3)
