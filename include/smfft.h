@@ -186,6 +186,9 @@ int smfft_last_pair_info(SmfftPairInfo* out);
 int smfft_va_window(unsigned long long* first, unsigned long long* next);
 /* K >= 0: the external kernels of THIS host thread run their rate limiter with K loads whatever the output buffer; < 0: automatic */
 void smfft_set_pacing(int k);
+/* the K an external launch of `family` (0 CT, 1 Stockham, 2 R2C/C2R: FFT_size = the real length) and length FFT_size would run
+   with for this output buffer right now (introspection for the tests: what pacing_for chooses per launch) */
+int smfft_pacing_for_output(const void* d_output, int family, int FFT_size);
 int smfft_free(void* d_ptr);
 int smfft_memcpy_h2d(void* d_dst, const void* h_src, unsigned long long bytes);
 int smfft_memcpy_d2h(void* h_dst, const void* d_src, unsigned long long bytes);

@@ -35,20 +35,25 @@ namespace smfft {
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 
-// ds_write_addtid_b32 x 8: four elements (re, im).  M0 holds the wave's base (plane 0 + 4 * 64 * wave); an SALU write of
-// M0 needs one wait state before an LDS "add-TID" instruction reads it (the assembler does not see into inline assembly).
-// M0 is written in EVERY block and not declared clobbered (LLVM treats it as reserved: a clobber would only draw a warning):
-// hipcc sets M0 itself right before each of its own uses of it, and a kernel built on this engine must not contain the few
-// constructs whose M0 set-up it may share between uses (LDS-DMA loads, GWS, indirect register indexing) -- none of ours does.
+// ds_write_addtid_b32 x 8: four elements (re, im).  M0 holds the wave's base (plane 0 + 4 * 64 * wave) for the duration of the
+// block; an SALU write of M0 needs one wait state before an LDS "add-TID" instruction reads it (the assembler does not see into
+// inline assembly).  LLVM treats M0 as reserved (a clobber would only draw a warning) and may share ONE M0 set-up between several
+// of its own uses (LDS-DMA loads, GWS, s_movrel register indexing, s_sendmsg), so the block SAVES M0 and RESTORES it: a user
+// kernel may combine this engine with any of those (tests/test_gpu_parity.py::test_planar_stores_preserve_m0 runs LDS-DMA loads
+// around planar stores).  The DS instructions read M0 when they issue, in order, so the restore may follow them directly.
+// What remains the caller's business in a MULTI-WAVE kernel: the compiler does not count these stores, so consumers in other
+// waves must be ordered by planar_sync (s_waitcnt lgkmcnt(0) + barrier), never by a bare __syncthreads().
 template <int O0, int O1, int O2, int O3, int P>
 __device__ __forceinline__ void addtid_store4(unsigned m0, float2 a, float2 b, float2 c, float2 d) {
+    unsigned saved;
     asm volatile(
-        "s_mov_b32 m0, %8\n\ts_nop 0\n\t"
-        "ds_write_addtid_b32 %0 offset:%9\n\tds_write_addtid_b32 %1 offset:%10\n\t"
-        "ds_write_addtid_b32 %2 offset:%11\n\tds_write_addtid_b32 %3 offset:%12\n\t"
-        "ds_write_addtid_b32 %4 offset:%13\n\tds_write_addtid_b32 %5 offset:%14\n\t"
-        "ds_write_addtid_b32 %6 offset:%15\n\tds_write_addtid_b32 %7 offset:%16"
-        :
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %9\n\ts_nop 0\n\t"
+        "ds_write_addtid_b32 %1 offset:%10\n\tds_write_addtid_b32 %2 offset:%11\n\t"
+        "ds_write_addtid_b32 %3 offset:%12\n\tds_write_addtid_b32 %4 offset:%13\n\t"
+        "ds_write_addtid_b32 %5 offset:%14\n\tds_write_addtid_b32 %6 offset:%15\n\t"
+        "ds_write_addtid_b32 %7 offset:%16\n\tds_write_addtid_b32 %8 offset:%17\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(saved)
         : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y), "v"(c.x), "v"(c.y), "v"(d.x), "v"(d.y), "s"(m0),
           "n"(4 * O0), "n"(4 * (O0 + P)), "n"(4 * O1), "n"(4 * (O1 + P)), "n"(4 * O2), "n"(4 * (O2 + P)), "n"(4 * O3), "n"(4 * (O3 + P))
         : "memory");

@@ -48,6 +48,7 @@ _SIGS = {
     "smfft_get_grid_cap": (_i, []),
     "smfft_set_nreuses": (None, [_i]),
     "smfft_set_pacing": (None, [_i]),
+    "smfft_pacing_for_output": (_i, [_vp, _i, _i]),
     "smfft_va_window": (_i, [ctypes.POINTER(_ull), ctypes.POINTER(_ull)]),
     "smfft_get_nreuses": (_i, []),
     "smfft_device_count": (_i, []),

@@ -7,21 +7,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <algorithm>
-#include <chrono>
-#include <atomic>
 #include <climits>
-#include <map>
-#include <memory>
 #include <mutex>
-#include <set>
-#include <string>
-#include <vector>
 
 #include "../../include/smfft.h"
 #include "../../include/smfft_reference_api.h"
 #include "smfft_host_util.hpp"
 #include "smfft_launch.hpp"
+#include "smfft_pairs.hpp"
 #include "smfft_state.hpp"
 
 namespace {
@@ -58,7 +51,7 @@ int ct_multiple_slots(int FFT_size, int nFFTs) {
 }
 
 // K > 0: the external kernels run their rate limiter with K loads for this output buffer: k_ordinary when it is ordinary
-// memory, k_mixed when it is one of the mixed outputs smfft_malloc_pair built (defined below, next to the pair table)
+// memory, k_mixed when it is one of the mixed outputs smfft_malloc_pair built (smfft_pairs.hip)
 int pacing_for(const void* d_output, int k_ordinary, int k_mixed);
 // serialised LDS loads between a wave's loads and stores, by transform length (sweeps on the same buffers:
 // tools/pacing_sweep.py, profiles/r02_pacing_sweep_plain.txt / _pair.txt)
@@ -125,732 +118,29 @@ int timed(F&& launch, double* FFT_time) {
     return 0;
 }
 
-// ---- paired allocation ----------------------------------------------------------------------------
-// What round 2 measured on MI355X (round 2's tools/microbench/placement_study.hip (git history); profiles/r02_placement_map.txt,
-// profiles/r02_placement_pmc.json, profiles/r02_vmm_mixed_assembly.txt, profiles/r02_vmm_interleave.txt):
-//  * Physical memory comes in CLASSES (three were told apart).  A plain allocation of a few GiB lies inside one class;
-//    pure reads from it run at 7.2 TB/s, pure writes at 5.6 TB/s.
-//  * About one physical GiB in seven is MIXED: pure writes 20 % FASTER (6.9 TB/s), pure reads 7 % slower.
-//  * A kernel that reads buffer A and writes buffer B moves the 4 GiB + 4 GiB batch in 1.55-1.60 ms when A and B are
-//    ordinary and in the same class -- what two hipMalloc calls in a row give -- in 1.48-1.53 ms in different classes, and
-//    in 1.30-1.31 ms (0.82 of the HBM peak) when B consists of mixed memory; reading FROM mixed memory is the slowest case.
-//    Same request counts in every case (TCC_EA0_RDREQ / WRREQ = the algorithmic bytes): what differs is DRAM service time.
-//  * Mixed memory can be MADE: a range whose 8 MiB handles alternate between ordinary memory of two different classes
-//    takes writes like mixed memory (copy into it 1.32 ms); alternating within one class, or in 128 MiB stripes, does not.
-//  * None of it shows in virtual addresses, but write passes tell: a physical GiB is mixed if its own pass is fast, and two
-//    ordinary GiB are of different classes if the pass over their interleaved halves is.
-// smfft_malloc_pair ("mixed" policy, the default) therefore takes the input from hipMalloc and BUILDS the output with
-// the virtual-memory API: physical memory is created in 8 MiB handles, 1 GiB at a time; each GiB is mapped at a slot of its
-// own and classified by those two passes (0.2 ms each).  Once mixed memory plus equal amounts of two classes cover the
-// output (and six chunks further), candidate outputs are assembled -- mixed memory first / interleaved classes only -- and
-// each is TIMED as the target of a copy from the real input over the whole pair; the best is kept, and while it is not
-// good eight more chunks are scanned and the candidates tried again (build_mixed_output below).  Typically 10-25 GiB and
-// 80-550 ms for a 4 GiB output, where hunting for mixed memory alone needed up to the whole byte budget and found none on
-// some boxes; bounded by the byte budget (default: a quarter of the free memory) and the time budget (default 2 s),
-// whatever is missing then coming from the last ordinary chunks scanned.  The chosen handles are blended evenly into one
-// virtual range -- the caller sees an ordinary device pointer -- and everything else is released.
-//   SMFFT_PAIR_POLICY=mixed|candidates|plain   candidates: round-1 style, whole hipMalloc blocks timed as
-//                                              copy targets inside the same budgets; plain: two plain allocations
-//   SMFFT_PAIR_BUDGET_FRAC=0.25                byte budget of the scan as a fraction of the free memory
-//   SMFFT_PAIR_BUDGET_MS=2000                  time budget
-//   SMFFT_PAIR_CACHE=1                         keep the last released pair for the next request of the same size
-//   SMFFT_PAIR_NO_MIXED=1 / SMFFT_PAIR_NO_INTERLEAVE=1 / SMFFT_PAIR_NO_COMPARE=1   A/B and test switches: only interleaving /
-//                                              only mixed chunks count / the first recipe is taken unmeasured
-struct PairRec {
-    void* a = nullptr;
-    void* b = nullptr;
-    int device = -1;
-    size_t bytes = 0;
-    bool searched = false;
-    std::vector<hipMemGenericAllocationHandle_t> handles;   // b is a virtual range backed by these (mixed policy)
-    size_t va_bytes = 0;
-    bool mixed = false;       // at least half of b is mixed memory
-    bool from_wrapper = false;   // taken by an L3 wrapper / the harness's comparator: kept for the next one when released
-};
-std::map<void*, PairRec> g_pairs;      // keyed by the read buffer; grows as needed
-PairRec g_pair_cache;                  // the last searched pair that was released: the wrappers' pairs, everybody's with SMFFT_PAIR_CACHE=1
-std::mutex g_pairs_mutex;              // shared by the per-GPU host threads of a multi-GPU driver
-SmfftPairInfo g_last_pair_info = {};
+// The paired-buffer allocator (smfft_malloc_pair and friends; what the L3 wrappers take their buffers from) is a translation
+// unit of its own: smfft_pairs.hip / smfft_pairs.hpp.
+using smfft::pairs::alloc_pair;
+using smfft::pairs::alloc_pair_for_wrapper;
+using smfft::pairs::free_pair;
+int pacing_for(const void* d_output, int k_ordinary, int k_mixed) { return smfft::pairs::pacing_for(d_output, k_ordinary, k_mixed, cur_pacing()); }
 
-// Pacing per launch (smfft_kernels.hpp, vmem_throttle): K serialised loads between a wave's loads and its stores.  Into
-// ordinary memory the paced kernels are 2-8 % faster, most when input and output lie in different memory classes (K = 12 for N <= 1024, 8 above; R2C / C2R of real N = 1024 / 2048:
-// 6 / 8), into the mixed outputs smfft_malloc_pair builds a light K = 4 is worth 0.3-1.6 % and more costs
-// (profiles/r02_pacing_sweep_*.txt).
-// The lookup runs at every launch: it reads an immutable snapshot of the built outputs' address ranges (sorted by start;
-// republished under g_pairs_mutex whenever a pair is built or freed) and takes no lock (nFFTs = 4 launch latency before /
-// after: profiles/r03_launch_latency.txt).  smfft_set_pacing(K) / SMFFT_PACING=K (read once) force K loads for every length.
-struct OutRange { uintptr_t lo, hi; bool mixed; };
-std::shared_ptr<const std::vector<OutRange>> g_out_ranges = std::make_shared<const std::vector<OutRange>>();
-void publish_out_ranges_locked() {          // caller holds g_pairs_mutex
-    auto v = std::make_shared<std::vector<OutRange>>();
-    for (auto& kv : g_pairs)
-        if (kv.second.va_bytes) v->push_back({(uintptr_t)kv.second.b, (uintptr_t)kv.second.b + kv.second.va_bytes, kv.second.mixed});
-    std::sort(v->begin(), v->end(), [](const OutRange& x, const OutRange& y) { return x.lo < y.lo; });
-    std::atomic_store(&g_out_ranges, std::shared_ptr<const std::vector<OutRange>>(v));
-}
-int pacing_for(const void* d_output, int k_ordinary, int k_mixed) {
-    const int forced = cur_pacing();
-    if (forced >= 0) return forced;
-    const auto ranges = std::atomic_load(&g_out_ranges);
-    const uintptr_t p = (uintptr_t)d_output;
-    auto it = std::upper_bound(ranges->begin(), ranges->end(), p, [](uintptr_t v, const OutRange& r) { return v < r.lo; });
-    if (it != ranges->begin() && p < (it - 1)->hi) return (it - 1)->mixed ? k_mixed : k_ordinary;
-    return k_ordinary;
-}
-
-// What counts as "mixed", "clearly ordinary" and "a good write target" is read off the scan's OWN measurements (round 2 had
-// three constants tuned on this pool: 0.91, 0.96, 2.22):
-//  * the write times of the scanned chunks are split into a fast and a slow cluster at the widest gap of their sorted
-//    values (split_write_times); the split is accepted when that gap is at least 4 % of the slow cluster's median and at
-//    least three times the slow cluster's own spread -- ordinary chunks scatter by +-1.5 %, mixed ones sit 12-20 % lower.
-//    A chunk is mixed below the gap, clearly ordinary inside the slow cluster's spread, and in between neither;
-//  * without an accepted split (too few chunks, or no mixed memory in what was scanned) nothing is called mixed, and a
-//    chunk is clearly ordinary within +-3 % of the median; SmfftPairInfo.classification says which case it was;
-//  * a candidate output is good when a pass into it beats the same pass into ORDINARY memory measured in this scan (the
-//    first clearly ordinary chunk) by the margin mixed memory shows against ordinary memory on this device -- half-way
-//    between the two cluster medians -- or, without a split, by 7 %.
-struct WriteSplit { bool accepted = false; float mixed_below = 0.f, ordinary_above = 0.f, fast_median = 0.f, slow_median = 0.f; };
-WriteSplit split_write_times(std::vector<float> t) {
-    WriteSplit w;
-    std::sort(t.begin(), t.end());
-    if (t.empty()) return w;
-    w.slow_median = t[t.size() / 2];
-    w.ordinary_above = 0.97f * w.slow_median;
-    if (t.size() < 4) return w;
-    size_t cut = 0;
-    float gap = 0.f;
-    for (size_t i = 1; i < t.size(); ++i)
-        if (t[i] - t[i - 1] > gap) { gap = t[i] - t[i - 1]; cut = i; }
-    if (cut == 0) return w;
-    const float slow_med = t[cut + (t.size() - cut) / 2], fast_med = t[cut / 2];
-    const float slow_spread = t.back() - t[cut];
-    // the slow cluster must be the majority (six chunks in seven are ordinary) for its median to mean "ordinary"
-    if (t.size() - cut < cut || gap < 0.04f * slow_med || gap < 3.f * slow_spread / std::max<size_t>(1, t.size() - cut - 1) * 1.0f) {
-        w.slow_median = t[t.size() / 2];
-        return w;
-    }
-    w.accepted = true;
-    w.slow_median = slow_med;
-    w.fast_median = fast_med;
-    w.mixed_below = t[cut - 1] + 0.5f * gap;
-    w.ordinary_above = t[cut] - 0.25f * gap;
-    return w;
-}
-#ifndef SMFFT_PAIR_HANDLE_MIB
-#define SMFFT_PAIR_HANDLE_MIB 8
-#endif
-constexpr size_t kHandleBytes = (size_t)SMFFT_PAIR_HANDLE_MIB << 20, kChunkBytes = 1ull << 30;
-
-// mean ms of `launches` passes in the external kernels' access shape over the first `bytes`: copy (in, out), pure read
-// (in, nullptr) or pure write (nullptr, out)
-float probe_ms(const void* in, void* out, size_t bytes, int launches) {
-    const long n = (long)(bytes / 8 / 4096 * 4096);
-    if (n <= 0) return 0.f;
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 0.f;
-    auto launch = [&] {
-        if (in && out) return smfft::launch_stream_copy((const float2*)in, (float2*)out, n, 12288, 0, 0);
-        if (in) return smfft::launch_stream_read((const float2*)in, n, 12288, 0);
-        return smfft::launch_stream_write((float2*)out, n, 12288, 0);
-    };
-    launch();
-    (void)hipEventRecord(e0, 0);
-    for (int i = 0; i < launches; ++i) launch();
-    (void)hipEventRecord(e1, 0);
-    (void)hipEventSynchronize(e1);
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return ms / launches;
-}
-
-double env_double(const char* name, double dflt) {
-    const char* e = getenv(name);
-    return e ? atof(e) : dflt;
-}
-
-// Virtual ranges for the VMM-backed buffers: every range is a reservation of its own at an address that has NEVER been used
-// before in this process, and it is given back (hipMemAddressFree) as soon as its mapping is gone.  Two things measured on
-// ROCm 7.2 / MI355X force that shape (round 2's tools/microbench/placement_study.hip (git history) vmm7, profiles/r02_vmm_remap_check.txt,
-// r02_vmm_release_check.txt):
-//  * after hipMemUnmap -- and even after hipMemAddressFree and a new hipMemAddressReserve of the same address -- a hipMemMap
-//    of ANOTHER handle at that virtual address leaves the GPU translating to the OLD physical memory (the second fill of the
-//    test lands in the first handle): a virtual address is usable for one mapping only, ever;
-//  * the physical memory of handles that are unmapped and released is returned to the system only when the virtual range
-//    they were mapped at is freed: ranges kept for later (an arena) pin every byte ever mapped into them.
-// Addresses are handed out upwards from a base far below the runtime's own region (hints are honoured); a reservation that
-// comes back below the high-water mark is refused.  Every 4 GiB pair consumes 50-100 GiB of address space for good, so a
-// process can build one to two thousand of them; after that the allocator falls back to plain allocations.
-// A retired range must never be handed to anybody else either (a hint-less reservation of another component -- PyTorch's
-// expandable segments, RCCL -- that landed in it would map new memory at an address the GPU still translates to old pages):
-// right after the range has been freed (which is what returns the physical memory) the SAME address range is reserved again
-// and never mapped -- a tombstone.  It costs address space only, which was spent anyway.
-std::mutex g_va_mutex;
-constexpr uintptr_t kVaBase = 0x100000000000ull;    // 16 TiB
-uintptr_t g_va_next = kVaBase;                      // next address to ask for
-size_t g_tombstones = 0, g_tombstones_missed = 0;
-constexpr uintptr_t kVaLimit = 0x700000000000ull;   // 112 TiB: stay below the region the runtime itself allocates from
-char* arena_take(size_t bytes) {
-    const size_t align = 1ull << 30;
-    bytes = (bytes + align - 1) / align * align;
-    std::lock_guard<std::mutex> lock(g_va_mutex);
-    for (int attempt = 0; attempt < 4 && g_va_next + bytes < kVaLimit; ++attempt) {
-        void* p = nullptr;
-        if (hipMemAddressReserve(&p, bytes, align, (void*)g_va_next, 0) != hipSuccess) { (void)hipGetLastError(); g_va_next += 64 * align; continue; }
-        if ((uintptr_t)p >= g_va_next && (uintptr_t)p + bytes < kVaLimit) { g_va_next = (uintptr_t)p + bytes; return (char*)p; }
-        (void)hipMemAddressFree(p, bytes);         // not where it was asked for, possibly an address used before: refuse it
-        g_va_next += 64 * align;
-    }
-    return nullptr;
-}
-void arena_give_back(char* p, size_t bytes) {
-    const size_t align = 1ull << 30;
-    if (!p) return;
-    bytes = (bytes + align - 1) / align * align;
-    std::lock_guard<std::mutex> lock(g_va_mutex);
-    (void)hipMemAddressFree(p, bytes);
-    void* q = nullptr;
-    if (hipMemAddressReserve(&q, bytes, align, p, 0) == hipSuccess && q == (void*)p) { ++g_tombstones; return; }
-    (void)hipGetLastError();
-    if (q) (void)hipMemAddressFree(q, bytes);
-    ++g_tombstones_missed;
-    static bool warned = false;
-    if (!warned) { warned = true; fprintf(stderr, "smfft: could not re-reserve a retired address range at %p (%zu bytes); it is left unprotected\n", (void*)p, bytes); }
-}
-
-void release_output(PairRec& rec) {
-    if (!rec.b) return;
-    if (rec.va_bytes) {
-        (void)hipMemUnmap(rec.b, rec.va_bytes);
-        for (auto h : rec.handles) (void)hipMemRelease(h);
-        rec.handles.clear();
-        arena_give_back((char*)rec.b, rec.va_bytes);   // the address is retired with the mapping (see arena_take)
-        rec.va_bytes = 0;
-    } else {
-        (void)hipFree(rec.b);
-    }
-    rec.b = nullptr;
-}
-
-struct Budget {
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    size_t bytes = 0;
-    double ms = 0;
-    double elapsed_ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
-};
-
-// "mixed" policy: the output as a virtual range over scanned physical chunks (see the comment above).  false: the VMM
-// API is not usable here (nothing is left allocated), the caller falls back to the candidates policy.
-//
-// Two kinds of memory make a fast write target (round 2's tools/microbench/placement_study.hip (git history) vmm / vmm_il,
-// profiles/r02_vmm_mixed_assembly.txt, r02_vmm_interleave.txt): MIXED chunks (pure writes 20 % faster; copy into them 1.30 ms
-// per 4 GiB + 4 GiB), and ORDINARY chunks of two different memory classes INTERLEAVED handle by handle (8 MiB): 1.32 ms,
-// against 1.55 ms into ordinary memory of one class -- what mixed memory is, made by hand.  Interleaving chunks of the SAME
-// class gains nothing, nor does interleaving in stripes of 128 MiB.  So every scanned chunk is classified twice: mixed or not
-// by its own write pass, and -- if not -- same or other class than the first ordinary chunk by the write pass over a test
-// range in which their handles alternate.  The scan ends as soon as mixed + 2 * min(same, other) covers the output.
-// in_is_fresh: `in` is the pair's own new (still empty) input buffer and may be written by a probe; a caller's buffer is only read
-bool build_mixed_output(size_t bytes, const void* in, bool in_is_fresh, int device, const Budget& budget, PairRec& rec, SmfftPairInfo& info) {
-    hipMemAllocationProp prop = {};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = device;
-    size_t gran = 0;
-    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0 || kHandleBytes % gran) { (void)hipGetLastError(); return false; }
-    hipMemAccessDesc acc = {};
-    acc.location = prop.location;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    const size_t need = (bytes + kHandleBytes - 1) / kHandleBytes, per_chunk = kChunkBytes / kHandleBytes;
-    enum Kind { kUnknown, kSameClass, kOtherClass };
-    struct Chunk { std::vector<hipMemGenericAllocationHandle_t> hs; float write_ms; Kind kind; };
-    std::vector<Chunk> chunks;
-    size_t created = 0, first_covered = 0;
-    int reference = -1;            // the first ordinary chunk: the class the others are compared with
-    bool api_ok = true;
-    const bool interleave = getenv("SMFFT_PAIR_NO_INTERLEAVE") == nullptr;   // A/B and test switches: only mixed chunks count /
-    const bool use_mixed = getenv("SMFFT_PAIR_NO_MIXED") == nullptr;         // only interleaving counts
-    // the reference a chunk's write pass is judged against: the median chunk (six chunks in seven are ordinary), but not
-    // less than the write pass over the input buffer itself (an ordinary hipMalloc block), so that a run of mixed chunks
-    // at the start of the scan is recognised as such
-    // (no input buffer -- smfft_malloc_written: the median alone)
-    const float in_write_ms = !(in && in_is_fresh) ? 0.f : probe_ms(nullptr, const_cast<void*>(in), bytes < kChunkBytes ? bytes : kChunkBytes, 3) * (float)((double)kChunkBytes / (double)(bytes < kChunkBytes ? bytes : kChunkBytes));
-    auto split = [&] {
-        std::vector<float> t;
-        for (auto& c : chunks) if (c.write_ms < 1e29f) t.push_back(c.write_ms);
-        WriteSplit w = split_write_times(t);
-        // a run of mixed chunks at the start of the scan: the pair's own (ordinary, hipMalloc) input buffer is the yardstick
-        if (!w.accepted && in_write_ms > 0.f && !t.empty() && w.slow_median < 0.92f * in_write_ms) {
-            w.accepted = true;
-            w.fast_median = w.slow_median;
-            w.slow_median = in_write_ms;
-            w.mixed_below = 0.94f * in_write_ms;
-            w.ordinary_above = 0.97f * in_write_ms;
-        }
-        return w;
-    };
-    auto is_mixed = [&](const Chunk& c, const WriteSplit& w) { return use_mixed && w.accepted && c.write_ms < w.mixed_below; };
-    struct Tally { size_t mixed, same, other; };
-    auto tally = [&] {
-        const WriteSplit typ = split();
-        Tally t = {0, 0, 0};
-        for (auto& c : chunks) {
-            if (is_mixed(c, typ)) t.mixed += c.hs.size();
-            else if (c.kind == kSameClass) t.same += c.hs.size();
-            else if (c.kind == kOtherClass) t.other += c.hs.size();
-        }
-        return t;
-    };
-    // write pass over a test range in which the first halves of two chunks alternate handle by handle: clearly faster than
-    // the chunks' own passes if they belong to different classes
-    auto other_class = [&](const Chunk& x, const Chunk& y) {
-        char* slot = arena_take(kChunkBytes);
-        if (!slot) return false;
-        bool ok = true;
-        for (size_t k = 0; k < per_chunk / 2 && ok; ++k)
-            ok = hipMemMap(slot + (2 * k) * kHandleBytes, kHandleBytes, 0, x.hs[k], 0) == hipSuccess &&
-                 hipMemMap(slot + (2 * k + 1) * kHandleBytes, kHandleBytes, 0, y.hs[k], 0) == hipSuccess;
-        ok = ok && hipMemSetAccess(slot, kChunkBytes, &acc, 1) == hipSuccess;
-        const float ms = ok ? probe_ms(nullptr, slot, kChunkBytes, 3) : 1e30f;
-        (void)hipMemUnmap(slot, kChunkBytes);
-        arena_give_back(slot, kChunkBytes);
-        if (!ok) (void)hipGetLastError();
-        if (getenv("SMFFT_PAIR_DEBUG")) printf("smfft_malloc_pair: interleave probe %.3f ms (own passes %.3f, %.3f)\n", ms, x.write_ms, y.write_ms);
-        // two classes interleaved write like mixed memory (0.80-0.83 of the chunks' own passes): below the split's threshold, or
-        // (no split yet) 12 % under the two own passes -- 7 % was within the noise of the 1 GiB passes: on a box whose first
-        // 93 GiB were ONE class it called six of them another one, and the blend built from those was half as good as it should be
-        const WriteSplit w = split();
-        const float own = 0.5f * (x.write_ms + y.write_ms);
-        return ms < (w.accepted ? std::min(w.mixed_below, 0.96f * own) : 0.88f * own);
-    };
-    // Scans until the output is covered (mixed memory plus equal parts of two classes) and `lookahead` chunks further -- so
-    // that either recipe alone, all mixed or all interleaved, may become complete and spare mixed chunks let the output take
-    // the fastest ones -- or to the budgets.  false: nothing more can be scanned.
-    bool budget_hit = false;
-    auto scan = [&](size_t lookahead) {
-        while (true) {
-            const Tally have = chunks.empty() ? Tally{0, 0, 0} : tally();
-            const bool covered = have.mixed + 2 * std::min(have.same, have.other) >= need;
-            if (covered && first_covered == 0) first_covered = chunks.size();
-            if (covered && chunks.size() >= first_covered + lookahead) return true;
-            if (!chunks.empty() && (created + kChunkBytes > budget.bytes || budget.elapsed_ms() > budget.ms)) { budget_hit = true; return false; }
-            Chunk c;
-            c.kind = kUnknown;
-            for (size_t h = 0; h < per_chunk; ++h) {
-                hipMemGenericAllocationHandle_t handle;
-                if (hipMemCreate(&handle, kHandleBytes, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
-                c.hs.push_back(handle);
-            }
-            if (c.hs.size() < per_chunk) {      // out of memory (or no VMM): give the partial chunk back and stop scanning
-                for (auto h : c.hs) (void)hipMemRelease(h);
-                api_ok = !chunks.empty();
-                budget_hit = true;
-                return false;
-            }
-            created += kChunkBytes;
-            char* scratch = arena_take(kChunkBytes);      // a slot of its own: virtual addresses are never re-used (see arena_take)
-            bool ok = scratch != nullptr;
-            for (size_t h = 0; h < per_chunk && ok; ++h) ok = hipMemMap(scratch + h * kHandleBytes, kHandleBytes, 0, c.hs[h], 0) == hipSuccess;
-            ok = ok && hipMemSetAccess(scratch, kChunkBytes, &acc, 1) == hipSuccess;
-            if (!ok) {
-                (void)hipGetLastError();
-                if (scratch) { (void)hipMemUnmap(scratch, kChunkBytes); arena_give_back(scratch, kChunkBytes); }
-                for (auto h : c.hs) (void)hipMemRelease(h);
-                api_ok = !chunks.empty();
-                budget_hit = true;
-                return false;
-            }
-            c.write_ms = probe_ms(nullptr, scratch, kChunkBytes, 3);
-            if (chunks.empty() && in) info.first_copy_ms = probe_ms(in, scratch, bytes < kChunkBytes ? bytes : kChunkBytes, 3);   // copy into the first (almost surely ordinary) chunk
-            (void)hipMemUnmap(scratch, kChunkBytes);
-            arena_give_back(scratch, kChunkBytes);
-            chunks.push_back(std::move(c));
-            Chunk& last = chunks.back();
-            // only CLEARLY ordinary chunks are classified (and only such a chunk is the reference): one whose own pass lies
-            // between the two kinds is partly mixed, its probes against other chunks come out between the two answers
-            if (interleave && last.write_ms > split().ordinary_above) {
-                if (info.first_ordinary_copy_ms == 0.f && in) {       // the yardstick of "good": a pass into clearly ordinary memory
-                    char* again = arena_take(kChunkBytes);
-                    bool ok2 = again != nullptr;
-                    for (size_t h = 0; h < per_chunk && ok2; ++h) ok2 = hipMemMap(again + h * kHandleBytes, kHandleBytes, 0, last.hs[h], 0) == hipSuccess;
-                    ok2 = ok2 && hipMemSetAccess(again, kChunkBytes, &acc, 1) == hipSuccess;
-                    if (ok2) info.first_ordinary_copy_ms = probe_ms(in, again, bytes < kChunkBytes ? bytes : kChunkBytes, 3);
-                    else (void)hipGetLastError();
-                    if (again) { (void)hipMemUnmap(again, kChunkBytes); arena_give_back(again, kChunkBytes); }
-                }
-                if (reference < 0) { reference = (int)chunks.size() - 1; last.kind = kSameClass; }
-                else last.kind = other_class(chunks[reference], last) ? kOtherClass : kSameClass;
-            }
-        }
-    };
-
-    // One candidate output = a list of handles.  Three pools: mixed memory (fastest chunks first, their handles taken
-    // round-robin across the chunks), ordinary memory of the reference's class, ordinary memory of another class; the last two
-    // contribute equal numbers.  The pools are spread EVENLY over the range (largest-remainder round-robin), so that every part
-    // of the buffer is the same blend -- a caller that uses half of it gets the same rate as one that uses all of it -- and
-    // neighbouring handles alternate between the classes.  What the pools cannot cover comes from the remaining memory, at the end.
-    struct Built { std::vector<hipMemGenericAllocationHandle_t> hs; size_t mixed_used = 0, interleaved_used = 0; };
-    auto build = [&](size_t m_limit) {                        // m_limit: how much of the output mixed memory may provide
-        const WriteSplit typ = split();
-        std::vector<size_t> m_chunks, s_chunks, o_chunks;
-        for (size_t i = 0; i < chunks.size(); ++i) {
-            if (is_mixed(chunks[i], typ)) m_chunks.push_back(i);
-            else if (chunks[i].kind == kSameClass) s_chunks.push_back(i);
-            else if (chunks[i].kind == kOtherClass) o_chunks.push_back(i);
-        }
-        std::sort(m_chunks.begin(), m_chunks.end(), [&](size_t x, size_t y) { return chunks[x].write_ms < chunks[y].write_ms; });
-        size_t m_total = 0, s_total = 0, o_total = 0;
-        for (size_t i : m_chunks) m_total += chunks[i].hs.size();
-        for (size_t i : s_chunks) s_total += chunks[i].hs.size();
-        for (size_t i : o_chunks) o_total += chunks[i].hs.size();
-        auto take = [&](std::vector<size_t> order, size_t limit) {       // handles of these chunks, round-robin across them
-            std::vector<hipMemGenericAllocationHandle_t> pool;
-            std::vector<size_t> pos(order.size(), 0);
-            for (bool any = true; any && pool.size() < limit;) {
-                any = false;
-                for (size_t k = 0; k < order.size(); ++k) {
-                    const auto& hs = chunks[order[k]].hs;
-                    if (pos[k] < hs.size() && pool.size() < limit) { pool.push_back(hs[pos[k]++]); any = true; }
-                }
-            }
-            return pool;
-        };
-        // as many whole mixed chunks as allowed (the fastest), the rest in equal parts from the two classes
-        const size_t m_take = std::min(std::min(m_total, m_limit), need);
-        const size_t each = std::min((need - m_take + 1) / 2, std::min(s_total, o_total));
-        if (m_take < m_total) m_chunks.resize((m_take + per_chunk - 1) / per_chunk);
-        std::vector<hipMemGenericAllocationHandle_t> pool[3];
-        pool[0] = take(m_chunks, m_take);
-        pool[1] = take(s_chunks, each);
-        pool[2] = take(o_chunks, std::min(each, need - m_take - pool[1].size()));
-        const size_t count[3] = {pool[0].size(), pool[1].size(), pool[2].size()};
-        const size_t blended = count[0] + count[1] + count[2];
-        size_t next[3] = {0, 0, 0};
-        double acc_rr[3] = {0.0, 0.0, 0.0};
-        Built b;
-        for (size_t k = 0; k < blended; ++k) {
-            int best = -1;
-            for (int q = 0; q < 3; ++q) {
-                if (next[q] == count[q]) continue;
-                acc_rr[q] += (double)count[q];
-                if (best < 0 || acc_rr[q] > acc_rr[best]) best = q;
-            }
-            acc_rr[best] -= (double)blended;
-            b.hs.push_back(pool[best][next[best]++]);
-        }
-        b.mixed_used = count[0];
-        b.interleaved_used = count[1] + count[2];
-        if (b.hs.size() < need) {                                        // the rest: whatever memory is left, last scanned first
-            std::set<hipMemGenericAllocationHandle_t> used(b.hs.begin(), b.hs.end());
-            for (size_t i = chunks.size(); i-- > 0 && b.hs.size() < need;)
-                for (size_t k = chunks[i].hs.size(); k-- > 0 && b.hs.size() < need;)
-                    if (!used.count(chunks[i].hs[k])) b.hs.push_back(chunks[i].hs[k]);
-        }
-        return b;
-    };
-    auto map_at = [&](char* va, const std::vector<hipMemGenericAllocationHandle_t>& hs) {
-        size_t mapped = 0;
-        bool ok = true;
-        for (; mapped < hs.size() && ok; ++mapped) ok = hipMemMap(va + mapped * kHandleBytes, kHandleBytes, 0, hs[mapped], 0) == hipSuccess;
-        ok = ok && hipMemSetAccess(va, hs.size() * kHandleBytes, &acc, 1) == hipSuccess;
-        if (!ok) { (void)hipGetLastError(); if (mapped) (void)hipMemUnmap(va, mapped * kHandleBytes); }
-        return ok;
-    };
-    // The measure of a candidate: the time of a pass over the WHOLE pair in the kernels' access shape -- a copy from the real
-    // input (no input: a write pass) -- with the candidate mapped at a range of its own.  Which blend is best depends on the
-    // class of the input, which cannot be probed (a hipMalloc block has no handles): an output that shares no class with it is
-    // 1.4 % better than one that does, and what a mixed chunk consists of is not known either (profiles/r02_vmm_classes.txt).
-    // So the recipes -- mixed memory first, interleaved classes only -- are TIMED and the best candidate seen is kept; while
-    // it is not good (see split_write_times above) and the budgets allow, eight more chunks are
-    // scanned and the recipes tried again with what they add.
-    auto measure = [&](const Built& b) {
-        char* va = arena_take(need * kHandleBytes);
-        if (!va || b.hs.size() != need || !map_at(va, b.hs)) { arena_give_back(va, need * kHandleBytes); return 1e30f; }
-        const float ms = in ? probe_ms(in, va, bytes, 3) : probe_ms(nullptr, va, bytes, 3);
-        (void)hipMemUnmap(va, need * kHandleBytes);
-        arena_give_back(va, need * kHandleBytes);
-        return ms;
-    };
-    const float read_whole_ms = in ? probe_ms(in, nullptr, bytes, 3) : 0.f;
-    Built best;
-    float best_ms = 1e30f;
-    bool good = false;
-    // What "good" is measured against.  Judging a candidate against ordinary memory seen in the same scan failed twice in
-    // round 3: a 1 GiB window into the first ordinary chunk is per byte faster than a whole-pair pass and that chunk may itself
-    // be a good target; and the same whole-pair pass into whole chunks of ONE class took anything between 1.32 ms (as fast as the
-    // best blends: a class that pairs well with the input's) and 1.55 ms (the input's own class) -- "ordinary memory" is not one
-    // thing, it depends on the class of the input, which cannot be probed.  What IS one thing per device is the pure read pass
-    // over the input (0.59-0.61 ms per 4 GiB on every box met), and against it the outcomes separate: the whole-pair copy takes
-    // 2.18-2.29 x that pass into every good output measured on ~30 boxes (mixed, interleaved, a well-paired single class),
-    // 2.34 x into a blend half made of mis-called chunks, 2.49-2.61 x into ordinary memory of the input's class.  With an input,
-    // good = at most kGoodCopyOverRead x the read pass; without one (smfft_malloc_written: write passes only) the split of the
-    // chunks' write times decides as before.  The single-class outputs are candidates like the two blends.
-    // (the scan itself only ends early on kStopCopyOverRead: a candidate between the two is acceptable, but more rounds are tried)
-    constexpr float kGoodCopyOverRead = 2.31f, kStopCopyOverRead = 2.25f, kLightPacingCopyOverRead = 2.38f;
-    auto single_class = [&](Kind kind) {
-        Built b;
-        for (auto& c : chunks)
-            if (c.kind == kind)
-                for (auto h : c.hs) if (b.hs.size() < need) b.hs.push_back(h);
-        return b;
-    };
-    bool tried_single[2] = {false, false};
-    bool confirmed = false;
-    float round_start_best = 1e30f;
-    const bool compare = getenv("SMFFT_PAIR_NO_COMPARE") == nullptr;
-    const size_t max_rounds = budget.ms > 5000.0 ? 16 : 4;      // a caller that grants a long scan (smfft_malloc_pair_budget) gets more tries
-    for (size_t lookahead = 6, round = 0; round < max_rounds && api_ok; lookahead += 8, ++round) {
-        const bool more = scan(lookahead);
-        size_t total = 0;
-        for (auto& c : chunks) total += c.hs.size();
-        if (!api_ok || total < need) break;
-        const Built cand[2] = {build(need), build(0)};
-        const int ncand = (compare && cand[0].mixed_used > 0 && cand[1].mixed_used + cand[1].interleaved_used == need) ? 2 : 1;
-        float ms[2] = {1e30f, 1e30f};
-        for (int k = 0; k < ncand; ++k) {
-            ms[k] = measure(cand[k]);
-            if (ms[k] < best_ms) { best_ms = ms[k]; best = cand[k]; }
-        }
-        float single_ms[2] = {0.f, 0.f};
-        if (in && compare && interleave)
-            for (int k = 0; k < 2; ++k) {                     // whole chunks of the reference's class / of the other chunks, once each
-                if (tried_single[k]) continue;
-                Built b = single_class(k == 0 ? kSameClass : kOtherClass);
-                if (b.hs.size() != need) continue;
-                tried_single[k] = true;
-                single_ms[k] = measure(b);
-                if (single_ms[k] < best_ms) { best_ms = single_ms[k]; best = b; }
-            }
-        const WriteSplit w = split();
-        if (in && read_whole_ms > 0.f) {
-            good = best_ms <= kGoodCopyOverRead * read_whole_ms;
-        } else {
-            // no input: a write pass into the candidate against the write passes of the scan's ordinary chunks, by half the
-            // distance this device shows between its ordinary and its mixed chunks (no split: by 7 %)
-            const float margin = w.accepted ? 0.5f * (1.f + w.fast_median / w.slow_median) : 0.93f;
-            good = best_ms < margin * w.slow_median * (float)((double)(need * kHandleBytes) / (double)kChunkBytes);
-        }
-        info.classification = w.accepted ? 1 : 0;
-        if (getenv("SMFFT_PAIR_DEBUG"))
-            printf("smfft_malloc_pair: after %zu chunks: mixed first %.4f ms%s as the target of a %s pass over the whole buffer (input read %.4f ms; whole chunks of one class: %.4f / %.4f ms; best %.4f): %s\n", chunks.size(), ms[0],
-                   ncand > 1 ? (std::string(", interleaved only ") + std::to_string(ms[1]) + " ms").c_str() : "", in ? "copy" : "write", read_whole_ms, single_ms[0], single_ms[1], best_ms, good ? "good" : "not good");
-        // more rounds after the first good candidate while they still pay: eight more chunks give the recipes more to choose
-        // from (the same box gave 0.793 after 10 chunks and 0.807 after 35); the scan ends with the first round that does not
-        // improve the best candidate by 1 %
-        const bool excellent = (in && read_whole_ms > 0.f) ? best_ms <= kStopCopyOverRead * read_whole_ms : good;
-        if (!more || (excellent && confirmed && best_ms > 0.99f * round_start_best)) break;
-        if (excellent) confirmed = true;
-        round_start_best = best_ms;
-    }
-    if (getenv("SMFFT_PAIR_DEBUG")) {
-        printf("smfft_malloc_pair scan: %zu chunks, write ms per GiB (class):", chunks.size());
-        for (auto& c : chunks) printf(" %.3f(%c)", c.write_ms, c.kind == kOtherClass ? 'o' : c.kind == kSameClass ? 's' : '-');
-        printf("\n");
-    }
-    if (!api_ok || chunks.empty()) {
-        for (auto& c : chunks) for (auto h : c.hs) (void)hipMemRelease(h);
-        return false;
-    }
-    if (best.hs.size() != need) {
-        // a scan that ended on its budget before it held the output's size: the rest is created unprobed
-        size_t total = 0;
-        for (auto& c : chunks) total += c.hs.size();
-        if (total < need) {
-            Chunk c;
-            c.write_ms = 1e30f;
-            c.kind = kUnknown;
-            for (size_t h = total; h < need; ++h) {
-                hipMemGenericAllocationHandle_t handle;
-                if (hipMemCreate(&handle, kHandleBytes, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
-                c.hs.push_back(handle);
-            }
-            created += c.hs.size() * kHandleBytes;
-            chunks.push_back(std::move(c));
-        }
-        best = build(need);
-        good = false;
-    }
-    {
-        std::set<hipMemGenericAllocationHandle_t> used(best.hs.begin(), best.hs.end());
-        for (auto& c : chunks) for (auto h : c.hs) if (!used.count(h)) (void)hipMemRelease(h);      // everything that was not used
-    }
-    char* out = best.hs.size() == need ? arena_take(need * kHandleBytes) : nullptr;
-    if (!out || !map_at(out, best.hs)) {
-        for (auto h : best.hs) (void)hipMemRelease(h);
-        arena_give_back(out, need * kHandleBytes);
-        return false;
-    }
-    rec.handles = best.hs;
-    rec.b = out;
-    rec.va_bytes = need * kHandleBytes;
-    rec.searched = true;
-    // how the kernels pace their stores into it (pacing_for): by what the output CONSISTS of -- mixed or interleaved memory
-    // takes writes like mixed memory whether or not the scan could also call the result good
-    // ... with an input, by how the timed pass came out: what takes the copy like a good output gets the light count whatever it
-    // consists of (a well-paired single class included), what does not -- a blend of mis-called chunks -- the count for
-    // ordinary memory
-    if (in && read_whole_ms > 0.f && best_ms < 1e29f) rec.mixed = best_ms <= kLightPacingCopyOverRead * read_whole_ms;
-    info.candidates = (int)chunks.size();
-    info.candidate_bytes = created;
-    info.chosen = (int)((best.mixed_used * kHandleBytes + kChunkBytes - 1) / kChunkBytes);
-    info.good_enough = good ? 1 : 0;
-    info.mixed_bytes = best.mixed_used * kHandleBytes;
-    info.interleaved_bytes = best.interleaved_used * kHandleBytes;
-    return true;
-}
-
-// "candidates" policy (the fallback where the virtual-memory API is not usable): whole hipMalloc blocks one after the other,
-// each timed as a copy target; ends at the first candidate that beats the SLOWEST one seen by 10 % (two blocks of one memory
-// class against a mixed or other-class one: 1.55-1.60 against 1.30-1.34 ms per 4 GiB + 4 GiB), or at the budgets.
-bool pick_candidate_output(size_t bytes, const void* in, const Budget& budget, float read_ms, PairRec& rec, SmfftPairInfo& info) {
-    const size_t window = bytes < kChunkBytes ? bytes : kChunkBytes;
-    struct Cand { void* p; float ms; };
-    std::vector<Cand> cands;
-    size_t used = 0;
-    int best = -1;
-    bool good = false;
-    while (!good) {
-        if (!cands.empty() && (used + bytes > budget.bytes || budget.elapsed_ms() > budget.ms)) break;
-        void* p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-        used += bytes;
-        const float ms = probe_ms(in, p, window, 3);
-        cands.push_back({p, ms > 0.f ? ms : 1e30f});
-        if (best < 0 || cands.back().ms < cands[best].ms) best = (int)cands.size() - 1;
-        float worst = 0.f;
-        for (auto& c : cands) if (c.ms < 1e29f && c.ms > worst) worst = c.ms;
-        good = cands.size() >= 2 && cands[best].ms <= 0.90f * worst;
-    }
-    info.candidates = (int)cands.size();
-    info.candidate_bytes = used;
-    if (best < 0) return false;
-    for (int i = 0; i < (int)cands.size(); ++i)
-        if (i != best) (void)hipFree(cands[i].p);
-    rec.b = cands[best].p;
-    rec.searched = true;
-    info.first_copy_ms = cands[0].ms;
-    info.chosen = best;
-    info.good_enough = good ? 1 : 0;
-    return true;
-}
-
-// with_input = false (smfft_malloc_written): only the written buffer, for a caller whose input exists already; the record is
-// kept under the written buffer's address
-// caller_input (with_input = false only): the caller's own input buffer of at least `bytes`, read (never written) by the
-// timed copies that judge the candidate outputs
-int alloc_pair(size_t bytes, void** d_a, void** d_b, bool allow_search, double budget_frac = -1.0, double budget_ms = -1.0, bool with_input = true,
-               const void* caller_input = nullptr, bool for_wrapper = false) {
-    if (d_a) *d_a = nullptr;
-    *d_b = nullptr;
-    int device = -1;
+// The wrappers' memory test (CT:844-847: "2 * bytes > free_mem").  What the device must hold is the pair; what the wrapper MAY
+// hold while it allocates is more -- the placement search scans chunks on top of the pair, bounded by its byte budget and by what
+// is free after the pair less 1 GiB (smfft_pairs.hpp, wrapper_peak_bytes), and it shrinks to fit, so it never turns a request
+// that fits into one that fails.  A pair the previous wrapper call left in the cache is either re-used (same size: nothing is
+// allocated, the test is skipped) or released before the new pair is allocated, so its bytes count as available.
+// false: "not enough memory" (the caller prints the reference's line and returns 1).
+bool wrapper_memory_ok(size_t pair_bytes_each, size_t needed, size_t free_mem) {
+    int device = 0;
     (void)hipGetDevice(&device);
-    const char* pol = getenv("SMFFT_PAIR_POLICY");
-    const bool plain = !allow_search || (pol && strcmp(pol, "plain") == 0) || bytes < (256ull << 20);
-    const bool candidates_only = pol && strcmp(pol, "candidates") == 0;
-    SmfftPairInfo info = {};
-    info.bytes = bytes;
-    if (!plain && with_input && (for_wrapper || getenv("SMFFT_PAIR_CACHE"))) {
-        std::lock_guard<std::mutex> lock(g_pairs_mutex);
-        if (g_pair_cache.a && g_pair_cache.device == device && g_pair_cache.bytes == bytes) {
-            PairRec rec = g_pair_cache;
-            g_pair_cache = PairRec();
-            rec.from_wrapper = for_wrapper;
-            g_pairs[rec.a] = rec;
-            publish_out_ranges_locked();
-            *d_a = rec.a;
-            *d_b = rec.b;
-            return 0;
-        }
-    }
-    void* in = nullptr;
-    if (with_input && hipMalloc(&in, bytes) != hipSuccess) { (void)hipGetLastError(); return 1; }
-    PairRec rec;
-    rec.a = in; rec.device = device; rec.bytes = bytes; rec.from_wrapper = for_wrapper;
-    if (!plain) {
-        Budget budget;
-        size_t free_mem = 0, total_mem = 0;
-        (void)hipMemGetInfo(&free_mem, &total_mem);
-        budget.bytes = (size_t)((budget_frac >= 0.0 ? budget_frac : env_double("SMFFT_PAIR_BUDGET_FRAC", 0.25)) * (double)free_mem);
-        // the scan holds its chunks ON TOP of the pair's two buffers: never more than what is free after them, less 1 GiB of
-        // head room for whoever else uses the device; a scan that could not even hold the output's size is not started
-        const size_t after_pair = free_mem > bytes + (1ull << 30) ? free_mem - bytes - (1ull << 30) : 0;
-        if (budget.bytes > after_pair) budget.bytes = after_pair;
-        budget.ms = budget_ms >= 0.0 ? budget_ms : env_double("SMFFT_PAIR_BUDGET_MS", 2000.0);
-        const size_t window = bytes < kChunkBytes ? bytes : kChunkBytes;
-        const void* probe_in = in ? in : caller_input;
-        if (probe_in) info.read_ms = probe_ms(probe_in, nullptr, window, 3);
-        bool done = !candidates_only && budget.bytes >= bytes + kChunkBytes && build_mixed_output(bytes, probe_in, in != nullptr, device, budget, rec, info);
-        // (A scan that met ONE memory class and nothing else -- a device whose free memory starts with a long run of one class,
-        // profiles/r03_uniform_box.txt: the next class began 93 GiB in -- is NOT repeated: a second scan with the first one's memory
-        // released continued deeper in one trial (89 chunks in all, a good output) and re-read the same memory in the next (138
-        // chunks and nothing): when the driver hands released memory out again is not in the caller's hands.  Reaching the next
-        // class for certain means holding what was scanned, i.e. a larger byte budget: smfft_malloc_pair_budget / SMFFT_PAIR_BUDGET_FRAC.)
-        if (!done && in) done = pick_candidate_output(bytes, in, budget, info.read_ms, rec, info);
-        if (done && probe_in) info.copy_ms = probe_ms(probe_in, rec.b, window, 3);
-        info.search_ms = budget.elapsed_ms();
-    }
-    if (!rec.b) {
-        if (hipMalloc(&rec.b, bytes) != hipSuccess) { (void)hipGetLastError(); if (in) (void)hipFree(in); return 1; }
-    }
-    {
-        std::lock_guard<std::mutex> lock(g_pairs_mutex);
-        g_pairs[with_input ? rec.a : rec.b] = rec;
-        g_last_pair_info = info;
-        publish_out_ranges_locked();
-    }
-    if (d_a) *d_a = rec.a;
-    *d_b = rec.b;
-    return 0;
+    if (smfft::pairs::cache_would_serve(pair_bytes_each, device)) return true;
+    const size_t available = free_mem + smfft::pairs::cached_bytes(device);
+    if (DEBUG) printf("  The device buffers need %0.3f MB; while they are allocated the placement search may hold up to %0.3f MB.\n", (float)needed / (1024.0 * 1024.0),
+                      (float)smfft::pairs::wrapper_peak_bytes(pair_bytes_each, available) / (1024.0 * 1024.0));
+    return needed <= available;
 }
 
-int free_pair(void* d_a) {
-    if (!d_a) return 0;
-    PairRec rec, evicted;
-    {
-        std::lock_guard<std::mutex> lock(g_pairs_mutex);
-        auto it = g_pairs.find(d_a);
-        if (it == g_pairs.end()) return (int)hipErrorInvalidValue;   // not a pair of this allocator: nothing is freed
-        rec = it->second;
-        g_pairs.erase(it);
-        publish_out_ranges_locked();
-        if (rec.searched && rec.a && (rec.from_wrapper || getenv("SMFFT_PAIR_CACHE"))) {
-            evicted = g_pair_cache;
-            g_pair_cache = rec;
-            rec = evicted;
-            if (!rec.a) return 0;
-        }
-    }
-    int rc = rec.a ? (int)hipFree(rec.a) : 0;
-    release_output(rec);
-    return rc;
-}
-
-int release_pair_cache() {
-    PairRec rec;
-    {
-        std::lock_guard<std::mutex> lock(g_pairs_mutex);
-        rec = g_pair_cache;
-        g_pair_cache = PairRec();
-    }
-    if (!rec.a) return 0;
-    (void)hipFree(rec.a);
-    release_output(rec);
-    return 0;
-}
-
-// The L3 wrappers own their two device buffers (CT:850-853 allocates them, uses them once, frees them) and take them from
-// the pair allocator: 80-550 ms per call (two plain allocations: under a millisecond, plus 150 ms of first touch once) and the
-// external kernel then runs at 0.80-0.83 of the HBM peak instead of 0.69-0.76.  SMFFT_WRAPPER_PLACEMENT=0: two plain
-// allocations, exactly as upstream (the hipFFT comparator of the harness follows the same switch, so that both libraries
-// are always timed on the same kind of buffers).
-// One search per process and buffer size: the wrappers (and the hipFFT comparator, which calls in here through
-// smfft_malloc_pair) keep the pair they release for the next wrapper call of the same size, so a harness run -- comparator,
-// then smFFT -- pays for one scan, not two; smfft_pair_cache_release() (or the end of the process) gives it back.
-int alloc_pair_for_wrapper(size_t bytes, void** d_a, void** d_b) {
-    const char* e = getenv("SMFFT_WRAPPER_PLACEMENT");
-    const bool search = !(e && atoi(e) == 0);
-    return alloc_pair(bytes, d_a, d_b, search, -1.0, -1.0, true, nullptr, search);
-}
 
 int select_device() {
     read_env();
@@ -944,7 +234,7 @@ int smfft_gpu_ct(const void* h_input, void* h_output, int FFT_size, int nFFTs, i
     checkHipErrors(hipMemGetInfo(&free_mem, &total_mem));
     if (DEBUG) printf("\n  Device has %0.3f MB of total memory, which %0.3f MB is available.\n", (float)total_mem / (1024.0 * 1024.0), (float)free_mem / (1024.0 * 1024.0));
     const size_t bytes = (size_t)FFT_size * nFFTs * sizeof(float2);
-    if (2 * bytes > free_mem) {
+    if (!wrapper_memory_ok(bytes, 2 * bytes, free_mem)) {
         printf("Error: Not enough memory! Input data is too big for the device.\n");
         return 1;
     }
@@ -993,7 +283,7 @@ int smfft_gpu_st(const void* h_input, void* h_output, int FFT_size, int nFFTs, i
     size_t free_mem, total_mem;
     checkHipErrors(hipMemGetInfo(&free_mem, &total_mem));
     const size_t bytes = (size_t)FFT_size * nFFTs * sizeof(float2);
-    if (2 * bytes > free_mem) {
+    if (!wrapper_memory_ok(bytes, 2 * bytes, free_mem)) {
         printf("Error: Not enough memory! Input data is too big for the device.\n");
         return 1;
     }
@@ -1033,7 +323,7 @@ int smfft_gpu_r2c(void* h_output, const float* h_input, int FFT_size, int nFFTs,
     double FFT_external_time = 0, FFT_multiple_time = 0;
     const size_t input_size_bytes = (size_t)FFT_size * nFFTs * sizeof(float);
     const size_t output_size_bytes = (size_t)(FFT_size >> 1) * nFFTs * sizeof(float2);
-    if ((input_size_bytes + output_size_bytes) > free_memory) {
+    if (!wrapper_memory_ok(input_size_bytes, input_size_bytes + output_size_bytes, free_memory)) {
         printf("Error not enough free memory!\n");
         return 1;
     }
@@ -1067,7 +357,7 @@ int smfft_gpu_c2r(float* h_output, const void* h_input, int FFT_size, int nFFTs,
     double FFT_external_time = 0;
     const size_t input_size_bytes = (size_t)(FFT_size >> 1) * nFFTs * sizeof(float2);
     const size_t output_size_bytes = (size_t)FFT_size * nFFTs * sizeof(float);
-    if ((input_size_bytes + output_size_bytes) > free_memory) {
+    if (!wrapper_memory_ok(input_size_bytes, input_size_bytes + output_size_bytes, free_memory)) {
         printf("Error not enough free memory!\n");
         return 1;
     }
@@ -1094,14 +384,14 @@ void smfft_set_nreuses(int n) { t_state.nreuses = n > 0 ? n : 0; }
 int smfft_get_nreuses(void) { read_env(); return cur_nreuses(); }
 int smfft_get_grid_cap(void) { read_env(); return cur_grid_cap(); }
 void smfft_set_pacing(int k) { t_state.pacing = k < 0 ? -2 : k; }
+int smfft_pacing_for_output(const void* d_output, int family, int FFT_size) {
+    read_env();
+    const Pacing p = family == 2 ? rc_pacing(FFT_size / 2) : c2c_pacing(FFT_size);
+    return pacing_for(d_output, p.ordinary, p.mixed);
+}
 int smfft_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 int smfft_set_device(int device) { read_env(); t_state.device = device; return (int)hipSetDevice(device); }
-int smfft_va_window(unsigned long long* first, unsigned long long* next) {
-    std::lock_guard<std::mutex> lock(g_va_mutex);
-    if (first) *first = kVaBase;
-    if (next) *next = g_va_next;
-    return (int)g_tombstones;
-}
+int smfft_va_window(unsigned long long* first, unsigned long long* next) { return smfft::pairs::va_window(first, next); }
 const char* smfft_version(void) { return "smfft_amd 0.1 (gfx950)"; }
 
 int smfft_malloc_pair(unsigned long long bytes, void** d_read, void** d_written) { read_env(); return alloc_pair((size_t)bytes, d_read, d_written, true); }
@@ -1118,12 +408,11 @@ int smfft_malloc_pair_budget(unsigned long long bytes, void** d_read, void** d_w
 }
 int smfft_last_pair_info(SmfftPairInfo* out) {
     if (!out) return 1;
-    std::lock_guard<std::mutex> lock(g_pairs_mutex);
-    *out = g_last_pair_info;
+    smfft::pairs::last_pair_info(out);
     return 0;
 }
 int smfft_free_pair(void* d_read) { return free_pair(d_read); }
-int smfft_pair_cache_release(void) { return release_pair_cache(); }
+int smfft_pair_cache_release(void) { return smfft::pairs::release_pair_cache(-1); }
 void* smfft_malloc(unsigned long long bytes) { void* p = nullptr; return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr; }
 int smfft_free(void* d_ptr) { return (int)hipFree(d_ptr); }
 int smfft_memcpy_h2d(void* d_dst, const void* h_src, unsigned long long bytes) { return (int)hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice); }

@@ -249,7 +249,7 @@ def test_harness_programs(sm, prog, args, expect):
     import subprocess
     exe = os.path.join(os.path.dirname(__file__), "..", "harness", prog)
     if not os.path.exists(exe):
-        pytest.skip("harness not built")
+        pytest.fail("harness/*.exe is missing: the harness build is part of __graft_entry__.build() -- a GPU run without it is a broken build, not a skip")
     p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600, env=dict(os.environ, SMFFT_SEED="7"))
     assert p.returncode == 0, p.stdout + p.stderr
     assert p.stdout.count("PASSED") == expect and "FAILED" not in p.stdout, p.stdout
@@ -271,7 +271,7 @@ def test_example_convolution_kernel(sm, n, sym):
     import os
     path = os.path.join(os.path.dirname(sm.LIB_PATH), "libsmfft_examples.so")
     if not os.path.exists(path):
-        pytest.skip("examples not built")
+        pytest.fail("libsmfft_examples.so is missing: it is built by smfft_amd/csrc/Makefile -- a GPU run without it is a broken build, not a skip")
     ex = ctypes.CDLL(path)
     fn = getattr(ex, sym)
     fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
@@ -296,7 +296,7 @@ def _examples(sm):
     import os
     path = os.path.join(os.path.dirname(sm.LIB_PATH), "libsmfft_examples.so")
     if not os.path.exists(path):
-        pytest.skip("examples not built")
+        pytest.fail("libsmfft_examples.so is missing: it is built by smfft_amd/csrc/Makefile -- a GPU run without it is a broken build, not a skip")
     return ctypes.CDLL(path)
 
 
@@ -414,6 +414,29 @@ def test_reference_shaped_r2c_c2r_kernel(sm, oracle_lib, n):
     ref.assert_close_fp32(back, oa.c2r(oracle_lib, packed, "f64"), f"reference-shaped C2R N={n}")
 
 
+def test_planar_stores_preserve_m0(sm):
+    """The planar engine's store block writes M0 inside inline assembly (ds_write_addtid_b32 takes its base from there) and
+    restores it: a kernel that has the compiler's own M0 users around it -- two LDS-DMA loads that SHARE one M0 set-up
+    (examples/planar_with_lds_dma.hip) -- gets every byte where it belongs (ADVICE r03 / VERDICT r03 item 8)."""
+    import ctypes
+    ex = _examples(sm)
+    ex.smfft_example_planar_with_lds_dma.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    x = np.random.default_rng(11).random(256, dtype=np.float32)
+    d_in, d_out = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(640 * 4)
+    sm.lib.smfft_memset(d_out.ptr, 0xFF, 640 * 4)
+    assert ex.smfft_example_planar_with_lds_dma(d_in.ptr, d_out.ptr, None) == 0 and sm.lib.smfft_synchronize() == 0
+    got = np.empty(640, np.float32)
+    sm.lib.smfft_memcpy_d2h(got.ctypes.data, d_out.ptr, got.nbytes)
+    lane = np.arange(64, dtype=np.float32)
+    assert np.array_equal(got[:64], x[:64]), "first LDS-DMA load"
+    assert np.array_equal(got[64:128], x[64:128]), "second LDS-DMA load (shares the first one's M0 set-up)"
+    for k in range(4):
+        assert np.array_equal(got[128 + 64 * k: 192 + 64 * k], lane + 100.0 * k), f"planar real row {k}"
+        assert np.array_equal(got[384 + 64 * k: 448 + 64 * k], -lane - 100.0 * k), f"planar imaginary row {k}"
+    d_in.free()
+    d_out.free()
+
+
 def test_reference_shaped_multiple_kernels_launch(sm):
     """SMFFT_DIT_multiple<P>(in, out), FFT_GPU_multiple<P>(in, out), FFT_GPU_R2C_C2R_multiple<P,D>(in, out) in the reference's
     launch shape (CT:553-572, ST:260-278, RC:367-384): they launch and finish (their 100 applications overflow fp32 by design)."""
@@ -437,7 +460,7 @@ def test_harness_with_wrapper_placement(sm, placement):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "harness", "FFT_CooleyTukey_C2C.exe")
     if not os.path.exists(exe):
-        pytest.skip("harness not built")
+        pytest.fail("harness/*.exe is missing: the harness build is part of __graft_entry__.build() -- a GPU run without it is a broken build, not a skip")
     env = dict(os.environ, SMFFT_WRAPPER_PLACEMENT=placement, SMFFT_PAIR_BUDGET_FRAC="0.05")
     p = subprocess.run([exe, "1024", "262144", "3", "0", "1"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "PASSED" in p.stdout and "FAILED" not in p.stdout, p.stdout + p.stderr
@@ -607,7 +630,7 @@ def test_virtual_shards_harness(sm, n, total, shards):
     import subprocess
     exe = os.path.join(os.path.dirname(__file__), "..", "harness", "FFT_multi_gpu.exe")
     if not os.path.exists(exe):
-        pytest.skip("harness not built")
+        pytest.fail("harness/*.exe is missing: the harness build is part of __graft_entry__.build() -- a GPU run without it is a broken build, not a skip")
     p = subprocess.run([exe, str(n), str(total), "2", "0", "1", "0", "0", str(shards)], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "bit-identical" in p.stdout and "PASSED" in p.stdout and "FAILED" not in p.stdout, p.stdout
@@ -704,7 +727,8 @@ def test_malloc_pair_bounded_search(sm, monkeypatch):
     assert info["search_ms"] <= 2000 + 2500 and took < 8.0, (info, took)   # the time budget (+ the last chunks and the timed candidates)
     # not worse than the first chunk seen (on a device of ONE class the fallback output measured up to 6 % slower than the
     # 1 GiB window into a single chunk)
-    assert info["copy_ms"] <= info["first_copy_ms"] * 1.10, info
+    # (1.03 when the scan told its chunks apart; 1.10 only on such a single-class device, where nothing better exists)
+    assert info["copy_ms"] <= info["first_copy_ms"] * (1.03 if info["classification"] == 1 and info["good_enough"] else 1.10), info
     assert _settled_usage(sm, free0, 2 * nbytes + (256 << 20)) <= 2 * nbytes + (256 << 20)   # only the pair (+ page tables) is still allocated
     print("smfft_malloc_pair:", info)
     assert sm.lib.smfft_free_pair(a.value) == 0
@@ -829,6 +853,74 @@ def test_malloc_written_with_a_callers_own_input(sm):
     assert _settled_usage(sm, free0, 256 << 20) <= (256 << 20)
 
 
+def test_pacing_of_a_written_buffer_follows_what_it_consists_of(sm):
+    """smfft_malloc_written (no input to time a copy from): the kernels pace their stores into the buffer by what it CONSISTS
+    of -- an output that is at least half mixed / interleaved memory (or that the scan called good) gets the light count,
+    K = 4 at N = 1024, never the K = 12 of ordinary memory (rec.mixed was left false on this path); a plain
+    buffer gets the ordinary count; smfft_set_pacing overrides both."""
+    import ctypes
+    nbytes = 1 << 30
+    out = ctypes.c_void_p()
+    assert sm.lib.smfft_malloc_written(nbytes, ctypes.byref(out)) == 0 and out.value
+    info = sm.last_pair_info()
+    light = info["good_enough"] or 2 * (info["mixed_bytes"] + info["interleaved_bytes"]) >= nbytes
+    want = 4 if light else 12
+    assert sm.lib.smfft_pacing_for_output(out.value, 0, 1024) == want, info
+    assert sm.lib.smfft_pacing_for_output(out.value + nbytes - 8, 1, 1024) == want
+    assert sm.lib.smfft_pacing_for_output(out.value, 0, 4096) == (0 if light else 8)
+    plain = sm.DeviceBuffer(1 << 20)
+    assert sm.lib.smfft_pacing_for_output(plain.ptr, 0, 1024) == 12 and sm.lib.smfft_pacing_for_output(plain.ptr, 2, 2048) == 8
+    sm.lib.smfft_set_pacing(7)
+    assert sm.lib.smfft_pacing_for_output(out.value, 0, 1024) == 7 and sm.lib.smfft_pacing_for_output(plain.ptr, 0, 1024) == 7
+    sm.lib.smfft_set_pacing(-1)
+    assert sm.lib.smfft_pacing_for_output(out.value, 0, 1024) == want
+    plain.free()
+    assert sm.lib.smfft_free_written(out.value) == 0
+    assert sm.lib.smfft_pacing_for_output(out.value, 0, 1024) == 12        # the range is gone from the snapshot
+
+
+def test_wrapper_calls_share_the_device_with_their_own_cache(sm, capfd):
+    """Two L3 wrapper calls in one process on a device with little free memory: the pair the first call leaves in
+    the cache is re-used by a second call of the same size (no memory test, no allocation) and RELEASED before a call of
+    another size allocates -- with 2 * bytes > free memory at that moment the round-3 code answered 'Not enough memory'; the
+    reference, which frees per call (CT:904-905), handles both."""
+    import ctypes
+    gib = 1 << 30
+    free0 = _free_bytes(sm)
+    left = 10 * gib                                    # what the wrappers get to work with
+    ballast = sm.DeviceBuffer(free0 - left)
+    n = 1024
+    rng = np.random.default_rng(5)
+
+    def call(nffts):
+        x = rng.random((nffts, n, 2), dtype=np.float32).view(np.complex64).reshape(nffts, n)
+        y = np.empty_like(x)
+        t1, t2 = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        rc = sm.lib.smfft_gpu_ct(x.ctypes.data, y.ctypes.data, n, nffts, 0, 1, 1, ctypes.byref(t1), ctypes.byref(t2))
+        if rc == 0:
+            ref.assert_close_fp32(y[:8], ref.ct_c2c(x[:8], False, True), "wrapper output")
+            ref.assert_close_fp32(y[-8:], ref.ct_c2c(x[-8:], False, True), "wrapper output, tail")
+        return rc
+
+    try:
+        small, large = 2 * gib // (n * 8), 7 * gib // 2 // (n * 8)
+        assert call(small) == 0                       # 2 x 2 GiB, searched (more than a quarter of what is free), kept in the cache
+        held = free0 - _free_bytes(sm) - ballast.nbytes
+        assert 4 * gib <= held <= 4 * gib + (512 << 20), held
+        assert call(small) == 0                       # same size: served from the cache
+        assert call(large) == 0                       # 2 x 3.5 GiB = 7 GiB > the 6 GiB free at that moment: the cache is released first
+        assert call(small) == 0                       # and back
+        out = capfd.readouterr().out
+        assert "Not enough memory" not in out
+        # a request that really does not fit is still refused, with the reference's line (CT:844-847)
+        assert call(6 * gib // (n * 8)) == 1
+        assert "Not enough memory" in capfd.readouterr().out
+    finally:
+        sm.lib.smfft_pair_cache_release()
+        ballast.free()
+    assert _settled_usage(sm, free0, 256 << 20) <= (256 << 20)
+
+
 def test_allocator_returns_memory_on_the_system_runtime():
     """The allocator in a process WITHOUT torch -- the library then runs on the system's HIP runtime, as the C harness does,
     where the physical memory of released handles comes back only when their virtual range is freed (ROCm 7.2): six pairs
@@ -860,7 +952,7 @@ def test_malloc_pair_plain_policy_and_many_pairs(sm, monkeypatch):
         assert sm.lib.smfft_free_pair(p) == 0
 
 
-@pytest.mark.parametrize("n", [32, 1024, 4096])
+@pytest.mark.parametrize("n", C2C_SIZES)
 def test_config3_full_batch_multiple_path(sm, oracle_lib, n):
     """Config 3 at the README batch (2^29/N FFTs, 4 GiB buffers), in-LDS `multiple` path:
       * reorder, 4 applications: F^4 = N^2 * identity (size-independent property), every slot;
@@ -902,7 +994,7 @@ def test_config3_full_batch_multiple_path(sm, oracle_lib, n):
         sm.lib.smfft_set_nreuses(0)
     rc, ms = sm.FFT_multiple_benchmark(a.ptr, b.ptr, n, nffts, False, False)
     assert rc == 0 and ms > 0
-    done = (nffts // 400 * 400) if n == 32 else (nffts // 100 * 100)
+    done = (nffts // 400 * 400) if n == 32 else (nffts // 200 * 200) if n == 64 else (nffts // 100 * 100)
     print(f"config3 N={n}: {ms:.3f} ms, {done / ms * 1e3:.3e} FFT/s (no-reorder, 100 applications)")
 
 
@@ -1132,7 +1224,7 @@ def test_harness_per_length_readme_batch(sm, n):
     import subprocess
     exe = os.path.join(os.path.dirname(__file__), "..", "harness", "FFT_CooleyTukey_C2C.exe")
     if not os.path.exists(exe):
-        pytest.skip("harness not built")
+        pytest.fail("harness/*.exe is missing: the harness build is part of __graft_entry__.build() -- a GPU run without it is a broken build, not a skip")
     p = subprocess.run([exe, str(n), str((1 << 29) // n), "2", "0", "1"], capture_output=True, text=True, timeout=900, env=dict(os.environ, SMFFT_SEED="11"))
     assert p.returncode == 0, p.stdout + p.stderr
     # N >= 2048 with U[0,1) data: the reference's metric flags fp32 round-off of the DC-heavy spectrum;
@@ -1150,7 +1242,7 @@ def test_harness_noreorder_is_verified(sm, n):
     import subprocess
     exe = os.path.join(os.path.dirname(__file__), "..", "harness", "FFT_CooleyTukey_C2C.exe")
     if not os.path.exists(exe):
-        pytest.skip("harness not built")
+        pytest.fail("harness/*.exe is missing: the harness build is part of __graft_entry__.build() -- a GPU run without it is a broken build, not a skip")
     p = subprocess.run([exe, str(n), str(4096 * 64 // n), "2", "0", "0"], capture_output=True, text=True, timeout=600, env=dict(os.environ, SMFFT_SEED="13"))
     assert p.returncode == 0, p.stdout + p.stderr
     assert "bit-reversed input" in p.stdout and "PASSED" in p.stdout and "FAILED" not in p.stdout, p.stdout
