@@ -910,10 +910,13 @@ def test_wrapper_calls_share_the_device_with_their_own_cache(sm, capfd):
         assert call(small) == 0                       # same size: served from the cache
         assert call(large) == 0                       # 2 x 3.5 GiB = 7 GiB > the 6 GiB free at that moment: the cache is released first
         assert call(small) == 0                       # and back
+        flush = ctypes.CDLL(None).fflush          # the library prints through C stdio (fully buffered on a pipe)
+        flush(None)
         out = capfd.readouterr().out
-        assert "Not enough memory" not in out
+        assert "Not enough memory" not in out and out.count("SH FFT normal") == 4, out
         # a request that really does not fit is still refused, with the reference's line (CT:844-847)
         assert call(6 * gib // (n * 8)) == 1
+        flush(None)
         assert "Not enough memory" in capfd.readouterr().out
     finally:
         sm.lib.smfft_pair_cache_release()
