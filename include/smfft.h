@@ -42,6 +42,10 @@ int smfft_ct_external_benchmark(const void* d_input, void* d_output, int FFT_siz
  * LDS.  Returns 1 and sets *FFT_time = -1 when nFFTs/100 == 0 (CT:669-673). */
 int smfft_ct_multiple_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs,
                                 int inverse, int reorder, double* FFT_time);
+/* The same benchmark on the natural-order compact kernel WITHOUT cross-application fusion: every one of the NREUSES applications
+ * reads its input from the LDS image and leaves its output there -- what one call of do_SMFFT_CT_DIT costs a kernel whose data
+ * live in LDS (CT:553-572).  N = 32 and the no-reorder variants have no fused form: use smfft_ct_multiple_benchmark. */
+int smfft_ct_multiple_unfused_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, int inverse, double* FFT_time);
 
 /* ---- Stockham C2C family (un-normalised INVERSE transform, ST:76), N = 32 .. 4096 ------------
  * (upstream: 256 .. 4096; the smaller lengths are an extension) */
@@ -186,6 +190,15 @@ int smfft_last_pair_info(SmfftPairInfo* out);
 int smfft_va_window(unsigned long long* first, unsigned long long* next);
 /* K >= 0: the external kernels of THIS host thread run their rate limiter with K loads whatever the output buffer; < 0: automatic */
 void smfft_set_pacing(int k);
+/* The multiple paths' schedule for THIS host thread: 1 (default; SMFFT_MULT_BALANCE) = when a launch holds more chains than fit on
+   the chip at once, a persistent grid of the co-resident workgroups shares the launch's applications evenly -- a chain that straddles
+   two workgroups is parked once in its own output slot and resumed (same bits); 0 = one chain per workgroup,
+   grid-strided, as in rounds 1-3; n >= 2 (tests): balanced over n workgroups, as if the chip held no more; < 0: back to the process default */
+void smfft_set_multiple_balance(int on);
+int smfft_get_multiple_balance(void);
+/* How many workgroups of a multiple kernel the device holds at once, COUNTED by a calibration launch over scratch buffers (family 0
+   CT / 1 Stockham, path 1 or 2); *assumed = what the balanced schedule computes from the kernel's registers and LDS.  < 0: error. */
+int smfft_measure_multiple_residency(int family, int FFT_size, int inverse, int reorder, int path, int* assumed);
 /* the K an external launch of `family` (0 CT, 1 Stockham, 2 R2C/C2R: FFT_size = the real length) and length FFT_size would run
    with for this output buffer right now (introspection for the tests: what pacing_for chooses per launch) */
 int smfft_pacing_for_output(const void* d_output, int family, int FFT_size);

@@ -470,18 +470,22 @@ __device__ __forceinline__ void tile_to_planes(const float2* __restrict__ g, flo
     using E = PlanarEngine<N, DIR, REORDER>;
     using P = PlanarGeometry<N, REORDER>;
     constexpr int T = E::T, TW = E::TW;
+    // (opaque copy of the thread index: the sixteen addresses below are computed where they are used, once per chain, instead
+    //  of being hoisted out of the loop over chains and kept in registers across the applications)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     float2 val[16];
     const bool full = first_fft + P::F <= limit_fft;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        const int e = threadIdx.x + TW * c;
+        const int e = tid + TW * c;
         const bool ok = full || (first_fft + e / N < limit_fft);
         const float2 t = g[ok ? e : 0];
         val[c] = ok ? t : make_float2(0.f, 0.f);
     }
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        const int e = threadIdx.x + TW * c;
+        const int e = tid + TW * c;
         const int f = e / N, n = e % N, u = n % T, row = n / T;
         const int pos = E::kForward ? E::position_of_role(u) : u;
         float* p = planes + P::image_row(row) + f * T + pos;
@@ -494,10 +498,12 @@ __device__ __forceinline__ void planes_to_tile(float2* __restrict__ g, const flo
     using E = PlanarEngine<N, DIR, REORDER>;
     using P = PlanarGeometry<N, REORDER>;
     constexpr int T = E::T, TW = E::TW;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     const bool full = first_fft + P::F <= limit_fft;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        const int e = threadIdx.x + TW * c;
+        const int e = tid + TW * c;
         const int f = e / N, n = e % N, u = n % T, row = n / T;
         const int pos = E::kForward ? E::position_of_role(u) : u;
         const float* p = planes + P::image_row(row) + f * T + pos;

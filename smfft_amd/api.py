@@ -29,6 +29,7 @@ _SIGS = {
     "smfft_init": (None, []),
     "smfft_ct_external_benchmark": (_i, [_vp, _vp, _i, _i, _i, _i, _dp]),
     "smfft_ct_multiple_benchmark": (_i, [_vp, _vp, _i, _i, _i, _i, _dp]),
+    "smfft_ct_multiple_unfused_benchmark": (_i, [_vp, _vp, _i, _i, _i, _dp]),
     "smfft_st_external_benchmark": (_i, [_vp, _vp, _i, _i, _dp]),
     "smfft_st_external_benchmark_dir": (_i, [_vp, _vp, _i, _i, _i, _dp]),
     "smfft_st_multiple_benchmark": (_i, [_vp, _vp, _i, _i, _dp]),
@@ -49,6 +50,9 @@ _SIGS = {
     "smfft_set_nreuses": (None, [_i]),
     "smfft_set_pacing": (None, [_i]),
     "smfft_pacing_for_output": (_i, [_vp, _i, _i]),
+    "smfft_measure_multiple_residency": (_i, [_i, _i, _i, _i, _i, ctypes.POINTER(_i)]),
+    "smfft_set_multiple_balance": (None, [_i]),
+    "smfft_get_multiple_balance": (_i, []),
     "smfft_va_window": (_i, [ctypes.POINTER(_ull), ctypes.POINTER(_ull)]),
     "smfft_get_nreuses": (_i, []),
     "smfft_device_count": (_i, []),
@@ -185,7 +189,7 @@ def launch(family, path, d_input, d_output, FFT_size, nFFTs, inverse=None, reord
     inverse=None: the program's own direction (Stockham: inverse, ST:76; otherwise forward)."""
     if inverse is None:
         inverse = (family == "st")
-    rc = lib.smfft_launch(_FAMILY[family], 0 if path == "external" else 1, d_input, d_output, FFT_size, nFFTs, int(inverse), int(reorder), stream)
+    rc = lib.smfft_launch(_FAMILY[family], {"external": 0, "multiple": 1, "multiple_unfused": 2}[path], d_input, d_output, FFT_size, nFFTs, int(inverse), int(reorder), stream)
     if rc != 0:
         raise RuntimeError(f"smfft_launch({family},{path},N={FFT_size}) -> {rc}")
 
@@ -205,6 +209,11 @@ def c2c(x, inverse=False, reorder=True, path="external"):
     """x: (nFFTs, N) complex64 host array -> CT-family result through the HIP library."""
     x = np.ascontiguousarray(x, dtype=np.complex64)
     nffts, n = x.shape
+    if path == "multiple_unfused":      # launch-only entry point (no *_benchmark call exists for it)
+        def fn(i, o):
+            launch("ct", path, i, o, n, nffts, inverse, reorder)
+            return lib.smfft_synchronize(), 0.0
+        return _run(x, np.complex64, x.shape, fn)
     f = FFT_external_benchmark if path == "external" else FFT_multiple_benchmark
     return _run(x, np.complex64, x.shape, lambda i, o: f(i, o, n, nffts, inverse, reorder, "ct"))
 

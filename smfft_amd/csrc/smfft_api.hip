@@ -8,7 +8,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <climits>
+#include <map>
 #include <mutex>
+#include <utility>
 
 #include "../../include/smfft.h"
 #include "../../include/smfft_reference_api.h"
@@ -24,9 +26,9 @@ namespace {
 // prototypes (GPU_smFFT_4elements and friends included); a value a thread has not set falls back to the process default
 // (environment: SMFFT_DEVICE, SMFFT_GRID_CAP, SMFFT_PACING, read once).  The lanes of smfft_host_transform inherit the
 // state of the thread that called it (smfft_state.hpp).
-smfft::LaunchState g_defaults = {0, 12288, SMFFT_NREUSES, -1};   // 12288 workgroups per launch: grid-stride over tiles, 12 or 16
+smfft::LaunchState g_defaults = {0, 12288, SMFFT_NREUSES, -1, 1};   // 12288 workgroups per launch: grid-stride over tiles, 12 or 16
                                                                  // rounds of the 4 or 3 resident workgroups per CU (measured sweet spot)
-thread_local smfft::LaunchState t_state = {-1, smfft::kUnsetGridCap, 0, -2};
+thread_local smfft::LaunchState t_state = {-1, smfft::kUnsetGridCap, 0, -2, -1};
 std::once_flag g_env_once;
 
 // launches may come from several host threads (per-GPU threads of a multi-GPU driver, the lanes of
@@ -36,11 +38,13 @@ void read_env() {
         if (const char* e = getenv("SMFFT_GRID_CAP")) g_defaults.grid_cap = atoi(e);
         if (const char* e = getenv("SMFFT_DEVICE")) g_defaults.device = atoi(e);
         if (const char* e = getenv("SMFFT_PACING")) g_defaults.pacing = atoi(e) > 0 ? atoi(e) : 0;
+        if (const char* e = getenv("SMFFT_MULT_BALANCE")) g_defaults.balance = atoi(e) > 0 ? atoi(e) : 0;
     });
 }
 int cur_device() { return t_state.device >= 0 ? t_state.device : g_defaults.device; }
 int cur_grid_cap() { return t_state.grid_cap != smfft::kUnsetGridCap ? t_state.grid_cap : g_defaults.grid_cap; }
 int cur_nreuses() { return t_state.nreuses > 0 ? t_state.nreuses : g_defaults.nreuses; }
+int cur_balance() { return t_state.balance >= 0 ? t_state.balance : g_defaults.balance; }
 int cur_pacing() { return t_state.pacing != -2 ? t_state.pacing : g_defaults.pacing; }   // -1: chosen per launch from the output buffer
 
 // count of FFT slots the `multiple` path touches (CT:669-683; ST:351; RC:438)
@@ -67,28 +71,28 @@ using smfft::launch_st;
 int dispatch_ct(const float2* in, float2* out, int N, int count, int inverse, int reorder, int path, hipStream_t st) {
     const int pace = pacing_for(out, c2c_pacing(N).ordinary, c2c_pacing(N).mixed);
     switch (N) {
-        case 32:   return launch_ct<32>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, st);
-        case 64:   return launch_ct<64>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, st);
-        case 128:  return launch_ct<128>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, st);
-        case 256:  return launch_ct<256>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, st);
-        case 512:  return launch_ct<512>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, st);
-        case 1024: return launch_ct<1024>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, st);
-        case 2048: return launch_ct<2048>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, st);
-        case 4096: return launch_ct<4096>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 32:   return launch_ct<32>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 64:   return launch_ct<64>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 128:  return launch_ct<128>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 256:  return launch_ct<256>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 512:  return launch_ct<512>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 1024: return launch_ct<1024>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 2048: return launch_ct<2048>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 4096: return launch_ct<4096>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
         default:   return -1;
     }
 }
 int dispatch_st(const float2* in, float2* out, int N, int count, int path, hipStream_t st) {
     const int pace = pacing_for(out, c2c_pacing(N).ordinary, c2c_pacing(N).mixed);
     switch (N) {
-        case 32:   return launch_st<32>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, st);
-        case 64:   return launch_st<64>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, st);
-        case 128:  return launch_st<128>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, st);
-        case 256:  return launch_st<256>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, st);
-        case 512:  return launch_st<512>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, st);
-        case 1024: return launch_st<1024>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, st);
-        case 2048: return launch_st<2048>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, st);
-        case 4096: return launch_st<4096>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 32:   return launch_st<32>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 64:   return launch_st<64>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 128:  return launch_st<128>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 256:  return launch_st<256>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 512:  return launch_st<512>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 1024: return launch_st<1024>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 2048: return launch_st<2048>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 4096: return launch_st<4096>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
         default:   return -1;
     }
 }
@@ -96,10 +100,10 @@ int dispatch_st(const float2* in, float2* out, int N, int count, int path, hipSt
 int dispatch_rc(const float2* in, float2* out, int FFT_size, int count, int inverse, int path, hipStream_t st) {
     const int pace = pacing_for(out, rc_pacing(FFT_size / 2).ordinary, rc_pacing(FFT_size / 2).mixed);
     switch (FFT_size) {
-        case 512:  return launch_rc<256>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, st);
-        case 1024: return launch_rc<512>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, st);
-        case 2048: return launch_rc<1024>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, st);
-        case 4096: return launch_rc<2048>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, st);
+        case 512:  return launch_rc<256>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 1024: return launch_rc<512>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 2048: return launch_rc<1024>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 4096: return launch_rc<2048>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
         default:   return -1;
     }
 }
@@ -155,6 +159,64 @@ int select_device() {
 namespace smfft {
 LaunchState get_thread_state() { return t_state; }
 void set_thread_state(const LaunchState& s) { t_state = s; }
+
+// ---- host side of the multiple paths' balanced schedule (smfft_kernels.hpp, MultipleSchedule) -----------------------------
+// Workgroups of `kernel` that the device holds at once, from the kernel's own resources and the CU's (MI355X_MICROARCH.md):
+// 512 vector registers per SIMD lane, handed out in blocks of 8 per wave; at most 8 waves per SIMD; 160 KiB of LDS per CU.
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor counts the LDS only: it answered 19 per CU for a 126-register single-wave
+//  kernel of which 16 run -- workgroup traces, profiles/r04_workgroup_trace.txt; tests/test_gpu_parity.py checks this function
+//  against smfft_measure_multiple_residency, which counts the workgroups that are alive at once, for every kernel.)
+int resident_workgroups(const void* kernel, int threads) {
+    static std::mutex mutex;
+    static std::map<std::pair<const void*, int>, int> known;      // (kernel, device) -> workgroups
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    std::lock_guard<std::mutex> lock(mutex);
+    auto it = known.find({kernel, device});
+    if (it != known.end()) return it->second;
+    hipFuncAttributes attr = {};
+    int cus = 0, result = 0;
+    if (hipFuncGetAttributes(&attr, kernel) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && attr.numRegs > 0) {
+        const int regs = (attr.numRegs + 7) / 8 * 8;
+        int waves_per_simd = 512 / regs;
+        if (waves_per_simd > 8) waves_per_simd = 8;
+        const int waves_per_wg = (threads + 63) / 64;
+        int per_cu = waves_per_simd * 4 / waves_per_wg;
+        if (attr.sharedSizeBytes > 0) {
+            const int by_lds = (int)((160u << 10) / attr.sharedSizeBytes);
+            if (by_lds < per_cu) per_cu = by_lds;
+        }
+        if (per_cu > 32) per_cu = 32;
+        result = per_cu * cus;
+    } else {
+        (void)hipGetLastError();
+    }
+    return known[{kernel, device}] = result;
+}
+thread_local unsigned* t_residency_probe = nullptr;
+thread_local int t_last_slots = 0;
+void note_resident_workgroups(int slots) { t_last_slots = slots; }
+int last_noted_slots() { return t_last_slots; }
+unsigned* residency_probe() { return t_residency_probe; }
+unsigned* schedule_flags(int nchains, hipStream_t stream, unsigned* epoch) {
+    struct Entry { unsigned* flags = nullptr; int capacity = 0; unsigned epoch = 0; };
+    static std::mutex mutex;
+    static std::map<std::pair<int, hipStream_t>, Entry> entries;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> lock(mutex);
+    Entry& e = entries[{device, stream}];
+    if (e.capacity < nchains || e.epoch == 0xFFFFFFFFu) {
+        if (e.flags) (void)hipFree(e.flags);          // (waits for the launches that still use it)
+        e = Entry();
+        const int capacity = nchains < 8192 ? 8192 : nchains;
+        if (hipMalloc((void**)&e.flags, (size_t)capacity * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); e.flags = nullptr; return nullptr; }
+        if (hipMemsetAsync(e.flags, 0, (size_t)capacity * sizeof(unsigned), stream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(e.flags); e.flags = nullptr; return nullptr; }
+        e.capacity = capacity;
+    }
+    *epoch = ++e.epoch;
+    return e.flags;
+}
 }  // namespace smfft
 
 // =================================================================================================
@@ -178,6 +240,15 @@ int smfft_ct_multiple_benchmark(const void* d_input, void* d_output, int FFT_siz
     }
     const int slots = ct_multiple_slots(FFT_size, nFFTs);
     return timed([&] { return dispatch_ct((const float2*)d_input, (float2*)d_output, FFT_size, slots, inverse != 0, reorder != 0, 1, 0); }, FFT_time);
+}
+
+int smfft_ct_multiple_unfused_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, int inverse, double* FFT_time) {
+    if (nFFTs / SMFFT_NREUSES == 0) {
+        if (FFT_time) *FFT_time = -1;
+        return 1;
+    }
+    const int slots = ct_multiple_slots(FFT_size, nFFTs);
+    return timed([&] { return dispatch_ct((const float2*)d_input, (float2*)d_output, FFT_size, slots, inverse != 0, true, 2, 0); }, FFT_time);
 }
 
 int smfft_st_external_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, double* FFT_time) {
@@ -384,6 +455,43 @@ void smfft_set_nreuses(int n) { t_state.nreuses = n > 0 ? n : 0; }
 int smfft_get_nreuses(void) { read_env(); return cur_nreuses(); }
 int smfft_get_grid_cap(void) { read_env(); return cur_grid_cap(); }
 void smfft_set_pacing(int k) { t_state.pacing = k < 0 ? -2 : k; }
+void smfft_set_multiple_balance(int on) { t_state.balance = on < 0 ? -1 : on; }
+int smfft_get_multiple_balance(void) { read_env(); return cur_balance(); }
+// The most workgroups of the multiple kernel (family, FFT_size, inverse, reorder, path = 1 or 2) that are alive at once on the
+// current device, COUNTED: a launch of three times what the scheduler assumes fits, 20 applications each, over scratch buffers,
+// with every workgroup incrementing a counter when it starts and decrementing it when it ends.  *assumed = the scheduler's figure.
+int smfft_measure_multiple_residency(int family, int FFT_size, int inverse, int reorder, int path, int* assumed) {
+    read_env();
+    const int tile = FFT_size < 1024 ? 1024 : FFT_size;
+    unsigned* counters = nullptr;
+    float2 *in = nullptr, *out = nullptr;
+    const int chains = 3 * 256 * 20;                       // more than any kernel's residency (at most 20 per CU), three times over for the small ones
+    const size_t bytes = (size_t)chains * tile * sizeof(float2);
+    if (hipMalloc((void**)&counters, 8) != hipSuccess || hipMalloc((void**)&in, bytes) != hipSuccess || hipMalloc((void**)&out, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(counters); (void)hipFree(in); (void)hipFree(out);
+        return -2;
+    }
+    (void)hipMemset(counters, 0, 8);
+    (void)hipMemset(in, 0, bytes);
+    const smfft::LaunchState saved = t_state;
+    t_state.balance = 0;
+    t_state.nreuses = 20;
+    t_state.grid_cap = 0;
+    smfft::t_residency_probe = counters;
+    const int count = chains * (tile / FFT_size);
+    const int rc = family == 0 ? dispatch_ct(in, out, FFT_size, count, inverse != 0, reorder != 0, path, 0) : family == 1 ? dispatch_st(in, out, FFT_size, count, path, 0)
+                               : dispatch_rc(in, out, 2 * FFT_size, count, inverse != 0, path, 0);      // (family 2: FFT_size = the complex length here)
+    smfft::t_residency_probe = nullptr;
+    t_state = saved;
+    unsigned host[2] = {0, 0};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(host, counters, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(counters); (void)hipFree(in); (void)hipFree(out);
+    if (rc != 0) return -3;
+    if (assumed) *assumed = smfft::last_noted_slots();
+    return (int)host[1];
+}
 int smfft_pacing_for_output(const void* d_output, int family, int FFT_size) {
     read_env();
     const Pacing p = family == 2 ? rc_pacing(FFT_size / 2) : c2c_pacing(FFT_size);

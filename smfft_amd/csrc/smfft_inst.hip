@@ -1,5 +1,7 @@
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <vector>
 // smfft_inst.hip -- instantiates every kernel of ONE transform length; compiled once per length
 // with -DSMFFT_N=<32..4096> (see Makefile).
 #include "smfft_kernels.hpp"
@@ -15,8 +17,57 @@
 
 namespace smfft {
 
+// One launch of a compact (in-LDS) kernel over `count` FFT slots.  Unbalanced: one chain per workgroup, grid-strided under the
+// grid cap.  Balanced (the default when the batch is more chains than the chip holds at once): a persistent grid of the
+// co-resident workgroups, each owning an equal share of the launch's ntiles * nreuses applications (MultipleSchedule).
+using CompactKernel = void (*)(const float2*, float2*, int, int, MultipleSchedule);
+static int launch_compact(CompactKernel kernel, const float2* d_input, float2* d_output, int count, int grid_cap, int nreuses, int balance, hipStream_t stream) {
+    using G = Geometry<SMFFT_N>;
+    const int ntiles = (count + G::kCompactFfts - 1) / G::kCompactFfts;
+    // the waves' scheduling priority rotates every 2^15 shader clocks (14 us; smfft_kernels.hpp, WavePriority; sweep of the period:
+    // profiles/r04_priority_rotation.txt); SMFFT_PRIO_ROTATE=0 leaves the arbiter's oldest-first order alone
+    static const int rotate = getenv("SMFFT_PRIO_ROTATE") ? atoi(getenv("SMFFT_PRIO_ROTATE")) : 15;
+    MultipleSchedule sch = {0, 0u, nullptr, rotate, nullptr, nullptr};
+    int grid = grid_for(count, G::kCompactFfts, grid_cap);
+    if (balance && nreuses > 1) {
+        // balance >= 2 (tests): that many workgroups, as if the chip held no more
+        const int slots = balance >= 2 ? balance : resident_workgroups((const void*)kernel, G::kCompactThreads);
+        if (slots > 0 && ntiles > slots) {
+            const long total = (long)ntiles * nreuses;
+            const long per_wg = (total + slots - 1) / slots;            // > nreuses, so a chain straddles at most two workgroups
+            unsigned epoch = 0;
+            unsigned* flags = schedule_flags(ntiles, stream, &epoch);
+            if (flags && per_wg < (1l << 30)) {
+                sch.per_wg = (int)per_wg;
+                sch.epoch = epoch;
+                sch.flags = flags;
+                grid = (int)((total + per_wg - 1) / per_wg);
+            }
+        }
+    }
+    sch.residency = residency_probe();
+    if (sch.residency) note_resident_workgroups(resident_workgroups((const void*)kernel, G::kCompactThreads));          // non-null only inside smfft_measure_multiple_residency
+    static const bool debug = getenv("SMFFT_SCHEDULE_DEBUG") != nullptr;
+    if (debug) printf("smfft multiple N=%d: %d chains x %d applications, %d co-resident workgroups (occupancy query), grid %d, %d applications per workgroup%s\n", SMFFT_N, ntiles, nreuses,
+                      resident_workgroups((const void*)kernel, G::kCompactThreads), grid, sch.per_wg, sch.per_wg ? "" : " (one chain at a time)");
+    static const char* trace_file = getenv("SMFFT_SCHEDULE_TRACE");          // experiments: one line per workgroup of the LAST launch
+    if (trace_file && hipMalloc((void**)&sch.trace, (size_t)grid * 32) != hipSuccess) sch.trace = nullptr;
+    kernel<<<dim3(grid), dim3(G::kCompactThreads), 0, stream>>>(d_input, d_output, count, nreuses, sch);
+    if (sch.trace) {
+        std::vector<unsigned long long> host((size_t)grid * 4);
+        (void)hipMemcpy(host.data(), sch.trace, host.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(sch.trace);
+        if (FILE* f = fopen(trace_file, "w")) {
+            fprintf(f, "# N=%d chains=%d nreuses=%d grid=%d per_wg=%d : block start end hw_id xcc_id\n", SMFFT_N, ntiles, nreuses, grid, sch.per_wg);
+            for (int i = 0; i < grid; ++i) fprintf(f, "%d %llu %llu %llx %llx\n", i, host[4 * i], host[4 * i + 1], host[4 * i + 2], host[4 * i + 3]);
+            fclose(f);
+        }
+    }
+    return (int)hipGetLastError();
+}
+
 template <>
-int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, int grid_cap, int nreuses, int pace, hipStream_t stream) {
+int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, int grid_cap, int nreuses, int pace, int balance, hipStream_t stream) {
     if (count <= 0) return 0;
     dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
     if (path == 0) {
@@ -29,16 +80,19 @@ int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int i
         if (!inverse && !reorder) SMFFT_DIT_external<CT_CLASS(_forward_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
         if (inverse && reorder)   SMFFT_EXTERNAL_REORDER_KERNEL<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
         if (inverse && !reorder)  SMFFT_DIT_external<CT_CLASS(_inverse_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
-    } else {
-        // in-LDS path: compact workgroups (one wave per 1024 elements for N <= 1024, one FFT per workgroup above)
-        grid = dim3(grid_for(count, Geometry<SMFFT_N>::kCompactFfts, grid_cap));
-        block = dim3(Geometry<SMFFT_N>::kCompactThreads);
-        if (!inverse && reorder)  SMFFT_DIT_multiple<CT_CLASS(_forward)><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
-        if (!inverse && !reorder) SMFFT_DIT_multiple<CT_CLASS(_forward_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
-        if (inverse && reorder)   SMFFT_DIT_multiple<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
-        if (inverse && !reorder)  SMFFT_DIT_multiple<CT_CLASS(_inverse_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
+        return (int)hipGetLastError();
     }
-    return (int)hipGetLastError();
+    // in-LDS path: compact workgroups (one wave per 1024 elements for N <= 1024, one FFT per workgroup above)
+#if SMFFT_PLANAR_SIZES(SMFFT_N)
+    if (path == 2 && reorder) {     // no cross-application fusion (what one call of the device function costs)
+        if (!inverse) return launch_compact(SMFFT_DIT_multiple_unfused<CT_CLASS(_forward)>, d_input, d_output, count, grid_cap, nreuses, balance, stream);
+        return launch_compact(SMFFT_DIT_multiple_unfused<CT_CLASS(_inverse)>, d_input, d_output, count, grid_cap, nreuses, balance, stream);
+    }
+#endif
+    if (!inverse && reorder)  return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_forward)>, d_input, d_output, count, grid_cap, nreuses, balance, stream);
+    if (!inverse && !reorder) return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_forward_noreorder)>, d_input, d_output, count, grid_cap, nreuses, balance, stream);
+    if (inverse && reorder)   return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_inverse)>, d_input, d_output, count, grid_cap, nreuses, balance, stream);
+    return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_inverse_noreorder)>, d_input, d_output, count, grid_cap, nreuses, balance, stream);
 }
 
 #if SMFFT_N == 1024
@@ -80,33 +134,30 @@ int launch_stream_read(const float2* d_input, long n_float2, int grid_cap, hipSt
 
 #define ST_CLASS SMFFT_PASTE3(FFT_, SMFFT_N, )
 template <>
-int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int path, int grid_cap, int nreuses, int pace, hipStream_t stream) {
+int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int path, int grid_cap, int nreuses, int pace, int balance, hipStream_t stream) {
     if (count <= 0) return 0;
+    if (path != 0) return launch_compact(FFT_GPU_multiple<ST_CLASS>, d_input, d_output, count, grid_cap, nreuses, balance, stream);
     dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
 #if SMFFT_N == 4096
     // same transform (Engine<4096, inverse, reorder>) through the occupancy-3 build, see SMFFT_DIT_external_occ3
-    if (path == 0) SMFFT_DIT_external_occ3<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
+    SMFFT_DIT_external_occ3<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
 #else
-    if (path == 0) FFT_GPU_external<ST_CLASS><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
+    FFT_GPU_external<ST_CLASS><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
 #endif
-    else           FFT_GPU_multiple<ST_CLASS><<<dim3(grid_for(count, Geometry<SMFFT_N>::kCompactFfts, grid_cap)), dim3(Geometry<SMFFT_N>::kCompactThreads), 0, stream>>>(d_input, d_output, count, nreuses);
     return (int)hipGetLastError();
 }
 
 #if SMFFT_N >= 256 && SMFFT_N <= 2048
 template <>
-int launch_rc<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int path, int grid_cap, int nreuses, int pace, hipStream_t stream) {
+int launch_rc<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int path, int grid_cap, int nreuses, int pace, int balance, hipStream_t stream) {
     if (count <= 0) return 0;
-    dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
-    if (path == 0) {
-        if (!inverse) FFT_GPU_R2C_C2R_external<ST_CLASS, FFT_forward><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
-        else          FFT_GPU_R2C_C2R_external<ST_CLASS, FFT_inverse><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
-    } else {
-        grid = dim3(grid_for(count, Geometry<SMFFT_N>::kCompactFfts, grid_cap));
-        block = dim3(Geometry<SMFFT_N>::kCompactThreads);
-        if (!inverse) FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_forward><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
-        else          FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_inverse><<<grid, block, 0, stream>>>(d_input, d_output, count, nreuses);
+    if (path != 0) {
+        if (!inverse) return launch_compact(FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_forward>, d_input, d_output, count, grid_cap, nreuses, balance, stream);
+        return launch_compact(FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_inverse>, d_input, d_output, count, grid_cap, nreuses, balance, stream);
     }
+    dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
+    if (!inverse) FFT_GPU_R2C_C2R_external<ST_CLASS, FFT_forward><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
+    else          FFT_GPU_R2C_C2R_external<ST_CLASS, FFT_inverse><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
     return (int)hipGetLastError();
 }
 #endif

@@ -213,6 +213,113 @@ __device__ __forceinline__ void lds_to_tile(float2* __restrict__ g, const float2
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The work of a `multiple` launch and how it is spread over the chip.
+// A CHAIN = one tile's data loaded once, transformed `nreuses` times in LDS, stored once (CT:553-572).  The README batches are
+// 5242 wave-tiles at every length -- 42.9 MB of LDS images on a chip that has 41.9 MB -- so with one chain per workgroup slot the
+// launch runs one full round of resident workgroups and then a second round of a few hundred lone ones at a quarter of the
+// rate: a 14-28 % tail (profiles/r03_*).  BALANCED schedule (round 4): the launch is a persistent grid of exactly the G
+// workgroups that are co-resident, and the total of ntiles * nreuses APPLICATIONS is cut into G equal intervals (McNaughton's
+// wrap-around rule): a workgroup's interval covers the last part of one chain, whole chains, and the first part of another.
+// A chain that straddles two workgroups is cut ONCE: the workgroup with the lower index runs its first applications -- as the
+// FIRST thing it does -- and parks the data in the chain's own output slot; the next workgroup resumes it from there as the
+// LAST thing it does (both are ordinary tile stores / loads: same bits).  Because an interval is longer than a chain, the
+// first part is finished long before the second is due, so nobody waits in practice; the hand-off is a flag per chain with
+// agent-scope release / acquire (the two workgroups sit on different XCDs, whose L2s are not coherent with each other), and
+// waiting only ever points to a LOWER block index, so the lowest unfinished workgroup can always run.  Every application still
+// happens in LDS; a cut chain pays one more tile store + load.  per_wg = 0: the old schedule (one chain at a time, grid-strided).
+struct MultipleSchedule {
+    int per_wg;              // applications per workgroup (> nreuses), or 0: grid-stride over whole chains
+    unsigned epoch;          // flags[c] == epoch: chain c has been parked in this launch
+    unsigned* flags;         // one per chain, device memory owned by the host API
+    int rotate;              // > 0: the wave's scheduling priority rotates every 2^rotate shader clocks (see WavePriority)
+    unsigned* residency;     // calibration launches only: [0] workgroups alive now, [1] the most that were alive at once
+    unsigned long long* trace;   // experiments (SMFFT_SCHEDULE_TRACE): per workgroup {start, end} of s_memrealtime + {HW_ID, XCC_ID}; nullptr otherwise
+};
+// The SIMD's arbiter serves the OLDEST wave first.  Co-resident chains therefore do not share a SIMD evenly: on a CU that holds
+// four N = 4096 workgroups the oldest finishes its 100 applications after 428 k cycles, the others after 471 k, 613 k and 745 k
+// (profiles/r04_workgroup_trace.txt) -- every round of resident chains ends in a tail of its own making in which three, two
+// and finally one workgroup are left on the CU, and a persistent schedule inherits the same staircase over its whole length.
+// s_setprio overrides the age: each wave takes priority (slot + clock / 2^rotate) mod 4, slot = its wave slot in the SIMD, so
+// that at any moment the waves of a SIMD still run in a strict order (which is what overlaps one wave's LDS phase with
+// another's arithmetic) but over four periods every wave has had every rank, and co-resident chains end together.
+struct WavePriority {
+    int slot, shift;
+    __device__ __forceinline__ WavePriority(int rotate) : shift(rotate) {
+        slot = (int)(__builtin_amdgcn_s_getreg((4 /* HW_REG_HW_ID */) | (0 << 6) | ((4 - 1) << 11)) & 3u);   // wave slot in the SIMD
+    }
+    // called once per application: the rank follows the CU's clock, so at any moment the waves of a SIMD hold a permutation of
+    // the ranks (their slots differ) and every wave holds every rank for the same share of the time
+    __device__ __forceinline__ void at_application(int) const {
+        if (shift <= 0) return;
+        const unsigned now = (unsigned)(__builtin_readcyclecounter() >> shift);
+        switch ((slot + (int)now) & 3) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    }
+};
+__device__ __forceinline__ void residency_enter(unsigned* r) {
+    if (r && threadIdx.x == 0) atomicMax(r + 1, atomicAdd(r, 1u) + 1u);
+}
+__device__ __forceinline__ void residency_leave(unsigned* r) {
+    if (r && threadIdx.x == 0) atomicSub(r, 1u);
+}
+__device__ __forceinline__ void trace_mark(unsigned long long* trace, int slot) {
+    if (trace && threadIdx.x == 0) {
+        trace[4 * blockIdx.x + slot] = __builtin_readcyclecounter();
+        if (slot == 0) {
+            trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((4 /* HW_REG_HW_ID */) | (0 << 6) | ((32 - 1) << 11));
+            trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((32 - 1) << 11));
+        }
+    }
+}
+__device__ __forceinline__ void chain_signal_parked(unsigned* flag, unsigned epoch) {
+    __syncthreads();                                    // every wave's tile stores are issued and complete at workgroup scope
+    if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_wait_parked(unsigned* flag, unsigned epoch) {
+    if (threadIdx.x == 0) {
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // L1 and the XCD's L2 drop what they hold of other XCDs' lines
+    }
+    __syncthreads();
+}
+// The parts of chains this workgroup owns, in the order the schedule needs: the chain it shares with the NEXT workgroup (its
+// head) first, the one it shares with the PREVIOUS (its tail) last.  One loop for both schedules: chain = first + k * step,
+// k < count, clipped to the workgroup's interval [lo, hi) of applications.
+struct PieceLoop {
+    long lo, hi;
+    int first, step, count, nreuses;
+    __device__ __forceinline__ PieceLoop(const MultipleSchedule& sch, int ntiles, int nreuses_) : nreuses(nreuses_) {
+        const long total = (long)ntiles * nreuses;
+        lo = 0;
+        hi = total;
+        first = blockIdx.x;
+        step = gridDim.x;
+        count = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+        if (sch.per_wg != 0) {
+            lo = (long)blockIdx.x * sch.per_wg;
+            hi = lo + sch.per_wg < total ? lo + sch.per_wg : total;
+            // (64-bit division runs on the vector unit: the quotients are wave-uniform, readfirstlane returns them to scalar registers)
+            first = __builtin_amdgcn_readfirstlane((int)((hi - 1) / nreuses));
+            step = -1;
+            count = lo < hi ? first - __builtin_amdgcn_readfirstlane((int)(lo / nreuses)) + 1 : 0;
+        }
+    }
+    __device__ __forceinline__ int tile(int k) const { return first + k * step; }
+    __device__ __forceinline__ int app0(int k) const {
+        const long c0 = (long)tile(k) * nreuses;
+        return __builtin_amdgcn_readfirstlane((int)((lo > c0 ? lo : c0) - c0));
+    }
+    __device__ __forceinline__ int app1(int k) const {
+        const long c0 = (long)tile(k) * nreuses;
+        return __builtin_amdgcn_readfirstlane((int)((hi < c0 + nreuses ? hi : c0 + nreuses) - c0));
+    }
+};
+
 // C2C, multiple, on the float2 engine (N = 32; every length with SMFFT_PLANAR=0 -- the A/B baseline of the planar engine):
 // the first nSlots FFTs are loaded once, transformed nreuses (= NREUSES = 100 in the
 // benchmark; a kernel argument so the tests can run 1, 2 and 4 applications) times in LDS, stored once.
@@ -227,20 +334,28 @@ __device__ __forceinline__ void lds_to_tile(float2* __restrict__ g, const float2
 #define SMFFT_MULT_FORWARD 1
 #endif
 template <int N, int DIR, int REORDER>
-__device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, float2* s) {
+__device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, MultipleSchedule sch, float2* s) {
     using G = Geometry<N>;
     constexpr bool kPaddedImage = !REORDER;
     Engine<N, DIR, REORDER> eng;
     eng.init(threadIdx.x);
     float2* sf = s + eng.fft * G::SF;
     const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const PieceLoop pieces(sch, ntiles, nreuses);
+    const WavePriority priority(sch.rotate);
+    trace_mark(sch.trace, 0);
+    residency_enter(sch.residency);
+    for (int k = 0; k < pieces.count; ++k) {
+        const int tile = pieces.tile(k), app0 = pieces.app0(k), app1 = pieces.app1(k);
         const long first = (long)tile * G::kCompactFfts;
+        const int napps = app1 - app0;
+        if (app0 > 0) chain_wait_parked(sch.flags + tile, sch.epoch);
         fft_sync<G::kMultiWave>();
-        tile_to_lds<N, kPaddedImage>(d_input + first * N, s, first, nSlots);
+        tile_to_lds<N, kPaddedImage>((app0 > 0 ? d_output : d_input) + first * N, s, first, nSlots);
         fft_sync<G::kMultiWave>();
         if constexpr (kPaddedImage) {
-            for (int f = 0; f < nreuses; ++f) {
+            for (int f = 0; f < napps; ++f) {
+                priority.at_application(app0 + f);
                 float2 r[16];
                 eng.bitrev_read(r, sf);
                 fft_sync<G::kMultiWave>();          // all inputs are in registers before the region is reused
@@ -256,7 +371,8 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_i
             // of the thread's own stores is forwarded from its registers: 16 of the 64 LDS operations per application.
             float2 r[16];
             eng.template load_lds<true>(r, sf);
-            for (int f = 0; f < nreuses; ++f) {
+            for (int f = 0; f < napps; ++f) {
+                priority.at_application(app0 + f);
                 fft_sync<G::kMultiWave>();
                 eng.template transform<true>(r, sf);
                 fft_sync<G::kMultiWave>();
@@ -264,7 +380,7 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_i
                 fft_sync<G::kMultiWave>();          // the reference omits this (latent race, CT:563-565)
             }
         } else {
-            for (int f = 0; f < nreuses; ++f) {
+            for (int f = 0; f < napps; ++f) {
                 float2 r[16];
                 eng.template load_lds<true>(r, sf);
                 fft_sync<G::kMultiWave>();
@@ -275,7 +391,10 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_i
             }
         }
         lds_to_tile<N, kPaddedImage>(d_output + first * N, s, first, nSlots);
+        if (app1 < nreuses) chain_signal_parked(sch.flags + tile, sch.epoch);
     }
+    trace_mark(sch.trace, 1);
+    residency_leave(sch.residency);
 }
 
 // The same kernel on the planar engine (smfft_planar.hpp): every LDS image as two planes of dwords, stored with
@@ -289,28 +408,52 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_i
 #define SMFFT_PLANAR_MIN_N 64   // N = 32 keeps the register engine and its float2 image (planar: -10 %, profiles/r03_ab_planar_small.txt)
 #endif
 #define SMFFT_PLANAR_SIZES(N) (SMFFT_PLANAR && (N) >= SMFFT_PLANAR_MIN_N)
-template <int N, int DIR, int REORDER>
-__device__ __forceinline__ void c2c_multiple_body_planar(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, float* planes) {
+#ifndef SMFFT_MULT_FUSED
+#define SMFFT_MULT_FUSED 1      // 0: no cross-application fusion -- every application re-loads its input from the LDS image (see SMFFT_DIT_multiple_unfused)
+#endif
+template <int N, int DIR, int REORDER, bool FUSED = (SMFFT_MULT_FUSED != 0)>
+__device__ __forceinline__ void c2c_multiple_body_planar(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, MultipleSchedule sch, float* planes) {
     using G = Geometry<N>;
     PlanarEngine<N, DIR, REORDER> eng;
     eng.init(threadIdx.x, planes);
     const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const PieceLoop pieces(sch, ntiles, nreuses);
+    const WavePriority priority(sch.rotate);
+    trace_mark(sch.trace, 0);
+    residency_enter(sch.residency);
+    for (int k = 0; k < pieces.count; ++k) {
+        const int tile = pieces.tile(k), app0 = pieces.app0(k), app1 = pieces.app1(k);
         const long first = (long)tile * G::kCompactFfts;
+        const int napps = app1 - app0;
+        if (app0 > 0) chain_wait_parked(sch.flags + tile, sch.epoch);
         planar_sync<G::kMultiWave>();
-        tile_to_planes<N, DIR, REORDER>(d_input + first * N, planes, first, nSlots);
+        tile_to_planes<N, DIR, REORDER>((app0 > 0 ? d_output : d_input) + first * N, planes, first, nSlots);
         planar_sync<G::kMultiWave>();
         float2 r[16];
-        if constexpr (REORDER) {
+        if constexpr (REORDER && FUSED) {
             eng.image_load_own(r, planes);
-            for (int f = 0; f < nreuses; ++f) {
+            for (int f = 0; f < napps; ++f) {
+                priority.at_application(app0 + f);
                 eng.natural_to_slots(r);
                 eng.transform_from_pass1_slots(r, planes);
                 planar_sync<G::kMultiWave>();       // the last pass's reads are done before the result overwrites them
                 eng.image_store(r);
             }
+        } else if constexpr (REORDER) {
+            // unfused: what ONE call of the device function costs when its input is data in LDS and its output is data in
+            // LDS -- the application reads its sixteen inputs back from the stored image instead of keeping them in registers
+            for (int f = 0; f < napps; ++f) {
+                priority.at_application(app0 + f);
+                planar_sync<G::kMultiWave>();       // the image is complete (stored by the threads that computed it)
+                eng.image_load_own(r, planes);
+                eng.natural_to_slots(r);
+                eng.transform_from_pass1_slots(r, planes);
+                planar_sync<G::kMultiWave>();
+                eng.image_store(r);
+            }
         } else {
-            for (int f = 0; f < nreuses; ++f) {
+            for (int f = 0; f < napps; ++f) {
+                priority.at_application(app0 + f);
                 eng.image_load_bitrev(r, planes);
                 eng.transform_from_pass1_slots(r, planes);
                 planar_sync<G::kMultiWave>();
@@ -320,7 +463,10 @@ __device__ __forceinline__ void c2c_multiple_body_planar(const float2* __restric
         }
         planar_sync<G::kMultiWave>();
         planes_to_tile<N, DIR, REORDER>(d_output + first * N, planes, first, nSlots);
+        if (app1 < nreuses) chain_signal_parked(sch.flags + tile, sch.epoch);
     }
+    trace_mark(sch.trace, 1);
+    residency_leave(sch.residency);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -477,24 +623,31 @@ __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__
 #define SMFFT_RC_MULTIPLE_PLANAR 1      // 0: the float2-image form below (A/B)
 #endif
 template <int L, int DIR>
-__device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, float2* s) {
+__device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, MultipleSchedule sch, float2* s) {
     using G = Geometry<L>;
     Engine<L, DIR, 1> eng;
     eng.init(threadIdx.x);
     HermitianRegisters<L, DIR> herm;
     herm.init(threadIdx.x);
     const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const PieceLoop pieces(sch, ntiles, nreuses);
+    const WavePriority priority(sch.rotate);
+    residency_enter(sch.residency);
+    for (int k = 0; k < pieces.count; ++k) {
+        const int tile = pieces.tile(k), app0 = pieces.app0(k), app1 = pieces.app1(k);
         const long first = (long)tile * G::kCompactFfts;
+        const int napps = app1 - app0;
+        if (app0 > 0) chain_wait_parked(sch.flags + tile, sch.epoch);
         fft_sync<G::kMultiWave>();
-        tile_to_lds<L, false>(d_input + first * L, s, first, nSlots);
+        tile_to_lds<L, false>((app0 > 0 ? d_output : d_input) + first * L, s, first, nSlots);
         fft_sync<G::kMultiWave>();
         // The split (R2C, after the FFT) / merge (C2R, before it) of an application is fused into the LOAD of the transform
         // that follows it: the partner x[L - i] is read from the resident data next to x[i] and the pair is combined in
         // registers -- two LDS round trips per application instead of three (the LDS-resident pass reads and re-writes the
-        // data once more).  R2C: the first load is plain and the last split is the LDS pass.
+        // data once more).  R2C: the first load of a piece is plain and its last split is the LDS pass.
         float2* sf = s + eng.fft * G::SF;
-        for (int f = 0; f < nreuses; ++f) {
+        for (int f = 0; f < napps; ++f) {
+            priority.at_application(app0 + f);
             float2 r[16];
             eng.load_lds(r, sf);
             if (DIR == 1 || f > 0) herm.template apply<true>(r, sf);
@@ -511,27 +664,36 @@ __device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__
             fft_sync<G::kMultiWave>();
         }
         lds_to_tile<L, false>(d_output + first * L, s, first, nSlots);
+        if (app1 < nreuses) chain_signal_parked(sch.flags + tile, sch.epoch);
     }
+    residency_leave(sch.residency);
 }
 
 // R2C / C2R in-LDS path on the planar engine: the complex transform of length L as in c2c_multiple_body_planar (reorder
 // roles, registers forwarded from one application to the next) with the Hermitian split / merge done on the registers,
 // the partners read from the stored image.  Per application: the C2C's LDS traffic + 32 dword reads.
 template <int L, int DIR>
-__device__ __forceinline__ void r2c_c2r_multiple_body_planar(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, float* planes) {
+__device__ __forceinline__ void r2c_c2r_multiple_body_planar(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, MultipleSchedule sch, float* planes) {
     using G = Geometry<L>;
     PlanarEngine<L, DIR, 1> eng;
     eng.init(threadIdx.x, planes);
     eng.init_hermitian();
     const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const PieceLoop pieces(sch, ntiles, nreuses);
+    const WavePriority priority(sch.rotate);
+    residency_enter(sch.residency);
+    for (int k = 0; k < pieces.count; ++k) {
+        const int tile = pieces.tile(k), app0 = pieces.app0(k), app1 = pieces.app1(k);
         const long first = (long)tile * G::kCompactFfts;
+        const int napps = app1 - app0;
+        if (app0 > 0) chain_wait_parked(sch.flags + tile, sch.epoch);
         planar_sync<G::kMultiWave>();
-        tile_to_planes<L, DIR, 1>(d_input + first * L, planes, first, nSlots);
+        tile_to_planes<L, DIR, 1>((app0 > 0 ? d_output : d_input) + first * L, planes, first, nSlots);
         planar_sync<G::kMultiWave>();
         float2 r[16];
         eng.image_load_own(r, planes);
-        for (int f = 0; f < nreuses; ++f) {
+        for (int f = 0; f < napps; ++f) {
+            priority.at_application(app0 + f);
             if (DIR == 1) {                          // C2R: merge (partners from the image: the tile, or the previous result), then the inverse transform
                 eng.hermitian_apply(r, planes);
                 planar_sync<G::kMultiWave>();        // every partner read precedes the exchanges' stores
@@ -551,7 +713,9 @@ __device__ __forceinline__ void r2c_c2r_multiple_body_planar(const float2* __res
             planar_sync<G::kMultiWave>();
         }
         planes_to_tile<L, DIR, 1>(d_output + first * L, planes, first, nSlots);
+        if (app1 < nreuses) chain_signal_parked(sch.flags + tile, sch.epoch);
     }
+    residency_leave(sch.residency);
 }
 
 }  // namespace smfft
@@ -635,19 +799,35 @@ SMFFT_DIT_external_occ3(const float2* d_input, float2* d_output, int nFFTs, int 
 #else
 // N = 2048 / 4096: compiled for 4 waves per SIMD (what their LDS allows, 8-9 / 4 workgroups per CU); left alone the planar
 // engine takes 133-170 registers = 3 or 2 waves per SIMD (profiles/r03_ab_planar_b.txt: +6 % / +3-17 % with the target stated)
-#define SMFFT_COMPACT_BOUNDS(N) __launch_bounds__(smfft::Geometry<N>::kCompactThreads, (N) >= 2048 ? 4 : 1)
+// (the single-wave kernels compiled for five waves per SIMD -- 96 registers, spills outside the application loop only -- measured
+//  3-8 % SLOWER than left alone at 100-128 registers = four waves per SIMD: profiles/r04_ab_balance_variants.txt, w5 against w1)
+#ifndef SMFFT_SINGLE_WAVE_MINWAVES
+#define SMFFT_SINGLE_WAVE_MINWAVES 1
+#endif
+#define SMFFT_COMPACT_BOUNDS(N) __launch_bounds__(smfft::Geometry<N>::kCompactThreads, (N) >= 2048 ? 4 : SMFFT_SINGLE_WAVE_MINWAVES)
 #endif
 
 template <class const_params>
-__global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_size) SMFFT_DIT_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
+__global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_size) SMFFT_DIT_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses, smfft::MultipleSchedule sch) {
     constexpr int N = const_params::fft_size;
     if constexpr (SMFFT_PLANAR_SIZES(N)) {
         __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<N, const_params::fft_reorder>::kLdsFloats];
-        smfft::c2c_multiple_body_planar<N, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nSlots, nreuses, s_planes);
+        smfft::c2c_multiple_body_planar<N, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nSlots, nreuses, sch, s_planes);
     } else {
         __shared__ float2 s_input[smfft::Geometry<N>::kCompactLds];
-        smfft::c2c_multiple_body<N, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nSlots, nreuses, s_input);
+        smfft::c2c_multiple_body<N, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nSlots, nreuses, sch, s_input);
     }
+}
+// The same kernel WITHOUT cross-application fusion (natural-order variants, planar lengths): every application reads its
+// input from the LDS image and leaves its output there, which is what ONE call of the device function costs a user kernel
+// whose data live in LDS (CT:553-572 calls do_SMFFT_CT_DIT on s_input NREUSES times; nothing survives a call in registers).
+// smfft_launch(..., path = 2); bench.py reports it next to the fused figure and the reference-contract path.
+template <class const_params>
+__global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_size) SMFFT_DIT_multiple_unfused(const float2* d_input, float2* d_output, int nSlots, int nreuses, smfft::MultipleSchedule sch) {
+    constexpr int N = const_params::fft_size;
+    static_assert(SMFFT_PLANAR_SIZES(N) && const_params::fft_reorder, "the no-reorder variants and N = 32 are unfused as they are");
+    __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<N, 1>::kLdsFloats];
+    smfft::c2c_multiple_body_planar<N, const_params::fft_direction, 1, false>(d_input, d_output, nSlots, nreuses, sch, s_planes);
 }
 
 // Stockham C2C program: un-normalised INVERSE (+i) transform, natural order (ST:76, :429).
@@ -657,14 +837,14 @@ __global__ void __launch_bounds__(256) FFT_GPU_external(const float2* d_input, f
     smfft::c2c_external_body<const_params::fft_length, 1, 1>(d_input, d_output, nFFTs, pace, s_input);
 }
 template <class const_params>
-__global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_length) FFT_GPU_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
+__global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_length) FFT_GPU_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses, smfft::MultipleSchedule sch) {
     constexpr int N = const_params::fft_length;
     if constexpr (SMFFT_PLANAR_SIZES(N)) {
         __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<N, 1>::kLdsFloats];
-        smfft::c2c_multiple_body_planar<N, 1, 1>(d_input, d_output, nSlots, nreuses, s_planes);
+        smfft::c2c_multiple_body_planar<N, 1, 1>(d_input, d_output, nSlots, nreuses, sch, s_planes);
     } else {
         __shared__ float2 s_input[smfft::Geometry<N>::kCompactLds];
-        smfft::c2c_multiple_body<N, 1, 1>(d_input, d_output, nSlots, nreuses, s_input);
+        smfft::c2c_multiple_body<N, 1, 1>(d_input, d_output, nSlots, nreuses, sch, s_input);
     }
 }
 
@@ -675,13 +855,13 @@ __global__ void __launch_bounds__(256) FFT_GPU_R2C_C2R_external(const float2* d_
     smfft::r2c_c2r_external_body<const_params::fft_length, const_direction::fft_direction>(d_input, d_output, nFFTs, pace, s_input);
 }
 template <class const_params, class const_direction>
-__global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_length) FFT_GPU_R2C_C2R_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses) {
+__global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_length) FFT_GPU_R2C_C2R_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses, smfft::MultipleSchedule sch) {
     constexpr int L = const_params::fft_length;
     if constexpr (SMFFT_PLANAR_SIZES(L) && SMFFT_RC_MULTIPLE_PLANAR) {
         __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<L, 1>::kLdsFloats];
-        smfft::r2c_c2r_multiple_body_planar<L, const_direction::fft_direction>(d_input, d_output, nSlots, nreuses, s_planes);
+        smfft::r2c_c2r_multiple_body_planar<L, const_direction::fft_direction>(d_input, d_output, nSlots, nreuses, sch, s_planes);
     } else {
         __shared__ float2 s_input[smfft::Geometry<L>::kCompactLds];
-        smfft::r2c_c2r_multiple_body<L, const_direction::fft_direction>(d_input, d_output, nSlots, nreuses, s_input);
+        smfft::r2c_c2r_multiple_body<L, const_direction::fft_direction>(d_input, d_output, nSlots, nreuses, sch, s_input);
     }
 }

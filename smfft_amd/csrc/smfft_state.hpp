@@ -11,6 +11,7 @@ struct LaunchState {
     int grid_cap;    // kUnsetGridCap: the process default (SMFFT_GRID_CAP, else 12288); <= 0: one workgroup per tile
     int nreuses;     // 0: NREUSES = 100
     int pacing;      // -2: the process default; -1: chosen per launch from the output buffer; K >= 0: K loads
+    int balance;     // -1: the process default (SMFFT_MULT_BALANCE, else 1); 0 / 1: the multiple paths' balanced schedule off / on
 };
 LaunchState get_thread_state();
 void set_thread_state(const LaunchState& s);

@@ -132,6 +132,110 @@ def test_ct_multiple_k_applications(sm, oracle_lib, n, inv, reo, reuses):
     assert l2 <= 5e-7 * reuses ** 0.5 and mx <= 1e-6 * reuses ** 0.5, (l2, mx)
 
 
+@pytest.mark.parametrize("n", C2C_SIZES)
+@pytest.mark.parametrize("inv,reo", [(0, 1), (0, 0), (1, 0)])
+def test_ct_multiple_balanced_schedule_is_bit_identical(sm, n, inv, reo):
+    """The balanced schedule of the multiple path (a persistent grid of G workgroups shares ntiles * nreuses applications
+    evenly; a chain that straddles two workgroups is parked once in its own output slot and resumed by the next workgroup)
+    gives the SAME BITS as one chain per workgroup: for G = 2, 3, 7 workgroups and 3, 4, 7 applications -- cuts in every
+    position, ragged last tile included -- and with the real number of co-resident workgroups on the README batch's shape."""
+    tile_ffts = max(1, 1024 // n)
+    ntiles = 23
+    slots = ntiles * tile_ffts - (tile_ffts // 2 if tile_ffts > 1 else 0)      # ragged last tile
+    nffts = slots * 100 // (4 if n == 32 else 2 if n == 64 else 1) * (4 if n == 32 else 2 if n == 64 else 1) + 37
+    slots = _slots(n, nffts)
+    rng = np.random.default_rng(4000 + n + inv + 2 * reo)
+    x = ((rng.random((nffts, n), dtype=np.float32) - 0.5) + 1j * (rng.random((nffts, n), dtype=np.float32) - 0.5)).astype(np.complex64)
+    try:
+        for reuses in (3, 4, 7):
+            sm.lib.smfft_set_nreuses(reuses)
+            sm.lib.smfft_set_multiple_balance(0)
+            want = sm.c2c(x, bool(inv), bool(reo), path="multiple")
+            for g in (2, 3, 7):
+                sm.lib.smfft_set_multiple_balance(g)
+                got = sm.c2c(x, bool(inv), bool(reo), path="multiple")
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (n, reuses, g)
+        assert (want[slots:].view(np.uint32) == 0xFFFFFFFF).all()
+    finally:
+        sm.lib.smfft_set_nreuses(0)
+        sm.lib.smfft_set_multiple_balance(-1)
+
+
+@pytest.mark.parametrize("n", R2C_SIZES)
+def test_r2c_multiple_balanced_schedule_is_bit_identical(sm, n):
+    """the same for the R2C in-LDS kernel (a piece starts from the split result the previous piece parked) and the Stockham one"""
+    half = n // 2
+    tile_ffts = max(1, 1024 // half)
+    nffts = (11 * tile_ffts - (1 if tile_ffts > 1 else 0)) * 100 + 13
+    rng = np.random.default_rng(5000 + n)
+    x = (rng.random((nffts, n), dtype=np.float32) - 0.5).astype(np.float32)
+    xc = ((rng.random((nffts, half), dtype=np.float32) - 0.5) + 1j * (rng.random((nffts, half), dtype=np.float32) - 0.5)).astype(np.complex64)
+    din, dinc = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer.from_host(xc)
+    dout = sm.DeviceBuffer(x.nbytes)
+
+    def run(fn):
+        sm.lib.smfft_memset(dout.ptr, 0xFF, dout.nbytes)
+        assert fn() == 0 and sm.lib.smfft_synchronize() == 0
+        return dout.to_host(np.uint32, (nffts, n))
+    try:
+        for reuses in (3, 5):
+            sm.lib.smfft_set_nreuses(reuses)
+            for fn in (lambda: sm.lib.smfft_rc_multiple_benchmark(din.ptr, dout.ptr, n, nffts, None),
+                       lambda: sm.lib.smfft_st_multiple_benchmark(dinc.ptr, dout.ptr, half, nffts, None)):
+                sm.lib.smfft_set_multiple_balance(0)
+                want = run(fn)
+                for g in (2, 5):
+                    sm.lib.smfft_set_multiple_balance(g)
+                    assert np.array_equal(run(fn), want), (n, reuses, g)
+    finally:
+        sm.lib.smfft_set_nreuses(0)
+        sm.lib.smfft_set_multiple_balance(-1)
+        din.free()
+        dinc.free()
+        dout.free()
+
+
+@pytest.mark.parametrize("family,n,inv,reo,path", [(0, n, 0, reo, 1) for n in C2C_SIZES for reo in (1, 0)] + [(0, n, 0, 1, 2) for n in C2C_SIZES[1:]] +
+                         [(1, n, 1, 1, 1) for n in (256, 1024, 4096)] + [(2, n // 2, 0, 1, 1) for n in R2C_SIZES])
+def test_multiple_schedule_knows_how_many_workgroups_fit(sm, family, n, inv, reo, path):
+    """The balanced schedule launches exactly as many persistent workgroups as the device holds at once; it computes that figure
+    from the kernel's registers and LDS (hipOccupancyMaxActiveBlocksPerMultiprocessor ignores the registers).  COUNTED here:
+    every workgroup of a long calibration launch increments a counter when it starts and decrements it when it ends.  More
+    than assumed would leave the chip partly idle; fewer would make late workgroups wait for a second round."""
+    import ctypes
+    assumed = ctypes.c_int(0)
+    counted = sm.lib.smfft_measure_multiple_residency(family, n, inv, reo, path, ctypes.byref(assumed))
+    assert counted > 0 and assumed.value > 0
+    assert counted <= assumed.value, (counted, assumed.value)
+    assert counted >= 0.93 * assumed.value, (counted, assumed.value)      # (workgroups of the calibration launch end and start all the time)
+
+
+@pytest.mark.parametrize("n", [64, 1024, 4096])
+def test_ct_multiple_unfused_path_matches_fused(sm, oracle_lib, n):
+    """smfft_launch(path = 2): the compact kernel WITHOUT cross-application fusion (every application re-reads its input from
+    the LDS image) computes what the fused kernel computes -- to rounding: it is another instantiation, hipcc contracts a
+    few multiply-adds differently (0.4 % of the words differ in the last bit after one application) -- and both are k
+    applications of the oracle."""
+    nffts = 100 * 40 + 7
+    rng = np.random.default_rng(n + 77)
+    x = ((rng.random((nffts, n), dtype=np.float32) - 0.5) + 1j * (rng.random((nffts, n), dtype=np.float32) - 0.5)).astype(np.complex64)
+    sm.lib.smfft_set_nreuses(3)
+    try:
+        fused = sm.c2c(x, False, True, path="multiple")
+        unfused = sm.c2c(x, False, True, path="multiple_unfused")
+    finally:
+        sm.lib.smfft_set_nreuses(0)
+    slots = _slots(n, nffts)
+    assert np.array_equal(fused[slots:].view(np.uint32), unfused[slots:].view(np.uint32))     # the same slots are left untouched
+    l2, mx = ref.fft_errors(unfused[:slots], fused[:slots].astype(np.complex128))
+    assert l2 < 2e-7 and mx < 1e-6, (l2, mx)
+    want = x[:slots].astype(np.complex128)
+    for _ in range(3):
+        want = oa.ct_c2c(oracle_lib, want, 0, 1, "f64")
+    l2, mx = ref.fft_errors(unfused[:slots], want)
+    assert l2 <= 5e-7 * 3 ** 0.5 and mx <= 1e-6 * 3 ** 0.5, (l2, mx)
+
+
 @pytest.mark.parametrize("n", ST_SIZES)
 def test_stockham_multiple_k_applications(sm, oracle_lib, n):
     nffts = 100 * (4096 // n + 1) + 50

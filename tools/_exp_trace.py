@@ -1,0 +1,14 @@
+import ctypes, sys, os
+sys.path.insert(0, os.getcwd())
+import smfft_amd as sm
+n, ntiles, bal, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+total = 1 << 29
+a, b = sm.DeviceBuffer(total * 8), sm.DeviceBuffer(total * 8)
+sm.lib.smfft_memset(a.ptr, 0, total * 8)
+tile = max(1, 1024 // n)
+sm.lib.smfft_set_multiple_balance(bal)
+for _ in range(40):
+    t = ctypes.c_double(0)
+    sm.lib.smfft_ct_multiple_benchmark(a.ptr, b.ptr, n, ntiles * tile * 100, 0, 1, ctypes.byref(t))
+print(n, ntiles, bal, "last launch ms", t.value)
+os.rename(os.environ["SMFFT_SCHEDULE_TRACE"], out)

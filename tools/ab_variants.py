@@ -31,7 +31,12 @@ args = ap.parse_args()
 names, libs = [], []
 for spec in args.libs:
     name, path = spec.split("=", 1)
+    path, _, opts = path.partition(":")          # name=path[:balance=K]
     lib = ctypes.CDLL(os.path.abspath(path))
+    for opt in filter(None, opts.split(":")):
+        key, val = opt.split("=")
+        if key == "balance":
+            lib.smfft_set_multiple_balance(int(val))
     vp, i, dp = ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)
     lib.smfft_ct_multiple_benchmark.argtypes = [vp, vp, i, i, i, i, dp]
     lib.smfft_ct_external_benchmark.argtypes = [vp, vp, i, i, i, i, dp]
