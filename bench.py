@@ -269,7 +269,9 @@ def compact_line(detail):
         # the in-LDS path at N = 1024, FFT/s: what ONE call of the device function costs (contract path; the compact kernel
         # without cross-application fusion) next to the fused compact kernel
         "in_lds_1024_contract_FFTps": _minmax([_get(cref, "ct_multiple_reorder", "FFT/s"), _get(cref, "ct_multiple_noreorder", "FFT/s")]),
-        "in_lds_1024_unfused_FFTps": _get(cfg, "in_lds_1024_unfused", "FFT/s"),
+        "in_lds_1024_unfused_FFTps": _get(c3, "1024", "reorder", "unfused", "FFT/s"),
+        "config3_unfused_frac": _minmax([_get(c3, k, "reorder", "unfused", "frac_fp32_peak") for k in c3]),
+        "config3_old_schedule_frac": _minmax([_get(c3, k, "reorder", "one_chain_per_workgroup_oldest_first", "frac_fp32_peak") for k in c3]),
         "in_lds_1024_fused_FFTps": _minmax([_get(c3, "1024", "reorder", "FFT/s"), _get(c3, "1024", "noreorder", "FFT/s")]),
         "config3_frac_fp32_peak": _minmax([_get(c3, k, o, "frac_fp32_peak") for k in c3 for o in ("reorder", "noreorder")]),
         "config3_saturating_frac": _minmax([_get(c3, k, o, "saturating_batch", "frac_fp32_peak") for k in c3 for o in ("reorder", "noreorder")]),
@@ -582,6 +584,17 @@ def main():
                 row[name] = {"ms": ms, "FFT/s": done / (ms * 1e-3), "TFLOP/s": tf, "frac_fp32_peak": tf / FP32_PEAK_TFLOPS,
                              "saturating_batch": {"slots_x": SAT, "ms": ms_sat, "FFT/s": SAT * done / (ms_sat * 1e-3),
                                                   "frac_fp32_peak": SAT * done * 5 * fn_n * math.log2(fn_n) / (ms_sat * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}}
+            # the same launch the way rounds 1-3 scheduled it (one chain per workgroup, the arbiter's oldest-first order), and the
+            # natural-order kernel WITHOUT cross-application fusion (what one call of the device function costs, N >= 64)
+            sm.lib.smfft_set_multiple_balance(0)
+            sm.lib.smfft_set_multiple_rotation(0)
+            ms_old = median_ms(lambda t: sm.lib.smfft_ct_multiple_benchmark(pa.value, pb.value, fn_n, bn, 0, 1, t), reps=7, settle_ms=SETTLE)
+            sm.lib.smfft_set_multiple_balance(-1)
+            sm.lib.smfft_set_multiple_rotation(-1)
+            row["reorder"]["one_chain_per_workgroup_oldest_first"] = {"ms": ms_old, "frac_fp32_peak": done * 5 * fn_n * math.log2(fn_n) / (ms_old * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
+            if fn_n >= 64:
+                ms_unf = median_ms(lambda t: sm.lib.smfft_ct_multiple_unfused_benchmark(pa.value, pb.value, fn_n, bn, 0, t), reps=7, settle_ms=SETTLE)
+                row["reorder"]["unfused"] = {"ms": ms_unf, "FFT/s": done / (ms_unf * 1e-3), "frac_fp32_peak": done * 5 * fn_n * math.log2(fn_n) / (ms_unf * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
             c3[str(fn_n)] = row
         # config 4: real N = 2048, 262144 FFTs (2 GiB of reals <-> 2 GiB packed spectrum) -- and the other three real lengths
         # at the same byte count; first halves of the pair for R2C, second halves for C2R
@@ -682,6 +695,7 @@ def main():
         except (OSError, AttributeError) as e:
             cref = {"error": repr(e)}
         configs = {"timing": "median of 11 (7 where many cases) event-timed launches after 3 warm-ups, buffers of `roofline`; the in-LDS (multiple) figures after a further 40 ms of untimed launches (clocks settled, profiles/r03_warm_ramp.txt)",
+                   "config3_schedule": "multiple path: persistent grid of the co-resident workgroups sharing the launch's applications evenly, wave priorities rotating every 2^15 clocks (DESIGN.md section 5.2); `one_chain_per_workgroup_oldest_first` = the schedule of rounds 1-3 on the same kernel",
                    "config2_external_by_length": c2, "config3_multiple": c3, "config4_r2c_c2r_external": c4,
                    "stockham_program": cst, "reference_contract": cref}
 

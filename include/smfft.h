@@ -196,6 +196,11 @@ void smfft_set_pacing(int k);
    grid-strided, as in rounds 1-3; n >= 2 (tests): balanced over n workgroups, as if the chip held no more; < 0: back to the process default */
 void smfft_set_multiple_balance(int on);
 int smfft_get_multiple_balance(void);
+/* The multiple paths' wave priorities for THIS host thread: k > 0 = every wave's scheduling priority rotates every 2^k shader clocks
+   (default 15; SMFFT_PRIO_ROTATE), so that the chains sharing a SIMD advance at the same average rate and end together; 0 = the
+   hardware's oldest-wave-first order (rounds 1-3); < 0: back to the process default */
+void smfft_set_multiple_rotation(int log2_clocks);
+int smfft_get_multiple_rotation(void);
 /* How many workgroups of a multiple kernel the device holds at once, COUNTED by a calibration launch over scratch buffers (family 0
    CT / 1 Stockham, path 1 or 2); *assumed = what the balanced schedule computes from the kernel's registers and LDS.  < 0: error. */
 int smfft_measure_multiple_residency(int family, int FFT_size, int inverse, int reorder, int path, int* assumed);

@@ -53,6 +53,8 @@ _SIGS = {
     "smfft_measure_multiple_residency": (_i, [_i, _i, _i, _i, _i, ctypes.POINTER(_i)]),
     "smfft_set_multiple_balance": (None, [_i]),
     "smfft_get_multiple_balance": (_i, []),
+    "smfft_set_multiple_rotation": (None, [_i]),
+    "smfft_get_multiple_rotation": (_i, []),
     "smfft_va_window": (_i, [ctypes.POINTER(_ull), ctypes.POINTER(_ull)]),
     "smfft_get_nreuses": (_i, []),
     "smfft_device_count": (_i, []),

@@ -26,9 +26,9 @@ namespace {
 // prototypes (GPU_smFFT_4elements and friends included); a value a thread has not set falls back to the process default
 // (environment: SMFFT_DEVICE, SMFFT_GRID_CAP, SMFFT_PACING, read once).  The lanes of smfft_host_transform inherit the
 // state of the thread that called it (smfft_state.hpp).
-smfft::LaunchState g_defaults = {0, 12288, SMFFT_NREUSES, -1, 1};   // 12288 workgroups per launch: grid-stride over tiles, 12 or 16
+smfft::LaunchState g_defaults = {0, 12288, SMFFT_NREUSES, -1, 1, 15};   // 12288 workgroups per launch: grid-stride over tiles, 12 or 16
                                                                  // rounds of the 4 or 3 resident workgroups per CU (measured sweet spot)
-thread_local smfft::LaunchState t_state = {-1, smfft::kUnsetGridCap, 0, -2, -1};
+thread_local smfft::LaunchState t_state = {-1, smfft::kUnsetGridCap, 0, -2, -1, -1};
 std::once_flag g_env_once;
 
 // launches may come from several host threads (per-GPU threads of a multi-GPU driver, the lanes of
@@ -39,11 +39,13 @@ void read_env() {
         if (const char* e = getenv("SMFFT_DEVICE")) g_defaults.device = atoi(e);
         if (const char* e = getenv("SMFFT_PACING")) g_defaults.pacing = atoi(e) > 0 ? atoi(e) : 0;
         if (const char* e = getenv("SMFFT_MULT_BALANCE")) g_defaults.balance = atoi(e) > 0 ? atoi(e) : 0;
+        if (const char* e = getenv("SMFFT_PRIO_ROTATE")) g_defaults.rotate = atoi(e) > 0 ? atoi(e) : 0;
     });
 }
 int cur_device() { return t_state.device >= 0 ? t_state.device : g_defaults.device; }
 int cur_grid_cap() { return t_state.grid_cap != smfft::kUnsetGridCap ? t_state.grid_cap : g_defaults.grid_cap; }
 int cur_nreuses() { return t_state.nreuses > 0 ? t_state.nreuses : g_defaults.nreuses; }
+int cur_rotate() { return t_state.rotate >= 0 ? t_state.rotate : g_defaults.rotate; }
 int cur_balance() { return t_state.balance >= 0 ? t_state.balance : g_defaults.balance; }
 int cur_pacing() { return t_state.pacing != -2 ? t_state.pacing : g_defaults.pacing; }   // -1: chosen per launch from the output buffer
 
@@ -71,28 +73,28 @@ using smfft::launch_st;
 int dispatch_ct(const float2* in, float2* out, int N, int count, int inverse, int reorder, int path, hipStream_t st) {
     const int pace = pacing_for(out, c2c_pacing(N).ordinary, c2c_pacing(N).mixed);
     switch (N) {
-        case 32:   return launch_ct<32>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
-        case 64:   return launch_ct<64>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
-        case 128:  return launch_ct<128>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
-        case 256:  return launch_ct<256>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
-        case 512:  return launch_ct<512>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
-        case 1024: return launch_ct<1024>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
-        case 2048: return launch_ct<2048>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
-        case 4096: return launch_ct<4096>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 32:   return launch_ct<32>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 64:   return launch_ct<64>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 128:  return launch_ct<128>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 256:  return launch_ct<256>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 512:  return launch_ct<512>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 1024: return launch_ct<1024>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 2048: return launch_ct<2048>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 4096: return launch_ct<4096>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
         default:   return -1;
     }
 }
 int dispatch_st(const float2* in, float2* out, int N, int count, int path, hipStream_t st) {
     const int pace = pacing_for(out, c2c_pacing(N).ordinary, c2c_pacing(N).mixed);
     switch (N) {
-        case 32:   return launch_st<32>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
-        case 64:   return launch_st<64>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
-        case 128:  return launch_st<128>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
-        case 256:  return launch_st<256>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
-        case 512:  return launch_st<512>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
-        case 1024: return launch_st<1024>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
-        case 2048: return launch_st<2048>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
-        case 4096: return launch_st<4096>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 32:   return launch_st<32>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 64:   return launch_st<64>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 128:  return launch_st<128>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 256:  return launch_st<256>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 512:  return launch_st<512>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 1024: return launch_st<1024>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 2048: return launch_st<2048>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 4096: return launch_st<4096>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
         default:   return -1;
     }
 }
@@ -100,10 +102,10 @@ int dispatch_st(const float2* in, float2* out, int N, int count, int path, hipSt
 int dispatch_rc(const float2* in, float2* out, int FFT_size, int count, int inverse, int path, hipStream_t st) {
     const int pace = pacing_for(out, rc_pacing(FFT_size / 2).ordinary, rc_pacing(FFT_size / 2).mixed);
     switch (FFT_size) {
-        case 512:  return launch_rc<256>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
-        case 1024: return launch_rc<512>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
-        case 2048: return launch_rc<1024>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
-        case 4096: return launch_rc<2048>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), st);
+        case 512:  return launch_rc<256>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 1024: return launch_rc<512>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 2048: return launch_rc<1024>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 4096: return launch_rc<2048>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
         default:   return -1;
     }
 }
@@ -457,6 +459,8 @@ int smfft_get_grid_cap(void) { read_env(); return cur_grid_cap(); }
 void smfft_set_pacing(int k) { t_state.pacing = k < 0 ? -2 : k; }
 void smfft_set_multiple_balance(int on) { t_state.balance = on < 0 ? -1 : on; }
 int smfft_get_multiple_balance(void) { read_env(); return cur_balance(); }
+void smfft_set_multiple_rotation(int log2_clocks) { t_state.rotate = log2_clocks < 0 ? -1 : log2_clocks; }
+int smfft_get_multiple_rotation(void) { read_env(); return cur_rotate(); }
 // The most workgroups of the multiple kernel (family, FFT_size, inverse, reorder, path = 1 or 2) that are alive at once on the
 // current device, COUNTED: a launch of three times what the scheduler assumes fits, 20 applications each, over scratch buffers,
 // with every workgroup incrementing a counter when it starts and decrementing it when it ends.  *assumed = the scheduler's figure.

@@ -21,12 +21,11 @@ namespace smfft {
 // grid cap.  Balanced (the default when the batch is more chains than the chip holds at once): a persistent grid of the
 // co-resident workgroups, each owning an equal share of the launch's ntiles * nreuses applications (MultipleSchedule).
 using CompactKernel = void (*)(const float2*, float2*, int, int, MultipleSchedule);
-static int launch_compact(CompactKernel kernel, const float2* d_input, float2* d_output, int count, int grid_cap, int nreuses, int balance, hipStream_t stream) {
+static int launch_compact(CompactKernel kernel, const float2* d_input, float2* d_output, int count, int grid_cap, int nreuses, int balance, int rotate, hipStream_t stream) {
     using G = Geometry<SMFFT_N>;
     const int ntiles = (count + G::kCompactFfts - 1) / G::kCompactFfts;
-    // the waves' scheduling priority rotates every 2^15 shader clocks (14 us; smfft_kernels.hpp, WavePriority; sweep of the period:
-    // profiles/r04_priority_rotation.txt); SMFFT_PRIO_ROTATE=0 leaves the arbiter's oldest-first order alone
-    static const int rotate = getenv("SMFFT_PRIO_ROTATE") ? atoi(getenv("SMFFT_PRIO_ROTATE")) : 15;
+    // (rotate: the waves' scheduling priority rotates every 2^15 shader clocks = 14 us by default; smfft_kernels.hpp, WavePriority;
+    //  sweep of the period: profiles/r04_priority_rotation.txt)
     MultipleSchedule sch = {0, 0u, nullptr, rotate, nullptr, nullptr};
     int grid = grid_for(count, G::kCompactFfts, grid_cap);
     if (balance && nreuses > 1) {
@@ -67,7 +66,7 @@ static int launch_compact(CompactKernel kernel, const float2* d_input, float2* d
 }
 
 template <>
-int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, int grid_cap, int nreuses, int pace, int balance, hipStream_t stream) {
+int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, int grid_cap, int nreuses, int pace, int balance, int rotate, hipStream_t stream) {
     if (count <= 0) return 0;
     dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
     if (path == 0) {
@@ -85,14 +84,14 @@ int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int i
     // in-LDS path: compact workgroups (one wave per 1024 elements for N <= 1024, one FFT per workgroup above)
 #if SMFFT_PLANAR_SIZES(SMFFT_N)
     if (path == 2 && reorder) {     // no cross-application fusion (what one call of the device function costs)
-        if (!inverse) return launch_compact(SMFFT_DIT_multiple_unfused<CT_CLASS(_forward)>, d_input, d_output, count, grid_cap, nreuses, balance, stream);
-        return launch_compact(SMFFT_DIT_multiple_unfused<CT_CLASS(_inverse)>, d_input, d_output, count, grid_cap, nreuses, balance, stream);
+        if (!inverse) return launch_compact(SMFFT_DIT_multiple_unfused<CT_CLASS(_forward)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
+        return launch_compact(SMFFT_DIT_multiple_unfused<CT_CLASS(_inverse)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
     }
 #endif
-    if (!inverse && reorder)  return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_forward)>, d_input, d_output, count, grid_cap, nreuses, balance, stream);
-    if (!inverse && !reorder) return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_forward_noreorder)>, d_input, d_output, count, grid_cap, nreuses, balance, stream);
-    if (inverse && reorder)   return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_inverse)>, d_input, d_output, count, grid_cap, nreuses, balance, stream);
-    return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_inverse_noreorder)>, d_input, d_output, count, grid_cap, nreuses, balance, stream);
+    if (!inverse && reorder)  return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_forward)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
+    if (!inverse && !reorder) return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_forward_noreorder)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
+    if (inverse && reorder)   return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_inverse)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
+    return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_inverse_noreorder)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
 }
 
 #if SMFFT_N == 1024
@@ -134,9 +133,9 @@ int launch_stream_read(const float2* d_input, long n_float2, int grid_cap, hipSt
 
 #define ST_CLASS SMFFT_PASTE3(FFT_, SMFFT_N, )
 template <>
-int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int path, int grid_cap, int nreuses, int pace, int balance, hipStream_t stream) {
+int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int path, int grid_cap, int nreuses, int pace, int balance, int rotate, hipStream_t stream) {
     if (count <= 0) return 0;
-    if (path != 0) return launch_compact(FFT_GPU_multiple<ST_CLASS>, d_input, d_output, count, grid_cap, nreuses, balance, stream);
+    if (path != 0) return launch_compact(FFT_GPU_multiple<ST_CLASS>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
     dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
 #if SMFFT_N == 4096
     // same transform (Engine<4096, inverse, reorder>) through the occupancy-3 build, see SMFFT_DIT_external_occ3
@@ -149,11 +148,11 @@ int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int p
 
 #if SMFFT_N >= 256 && SMFFT_N <= 2048
 template <>
-int launch_rc<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int path, int grid_cap, int nreuses, int pace, int balance, hipStream_t stream) {
+int launch_rc<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int path, int grid_cap, int nreuses, int pace, int balance, int rotate, hipStream_t stream) {
     if (count <= 0) return 0;
     if (path != 0) {
-        if (!inverse) return launch_compact(FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_forward>, d_input, d_output, count, grid_cap, nreuses, balance, stream);
-        return launch_compact(FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_inverse>, d_input, d_output, count, grid_cap, nreuses, balance, stream);
+        if (!inverse) return launch_compact(FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_forward>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
+        return launch_compact(FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_inverse>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
     }
     dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
     if (!inverse) FFT_GPU_R2C_C2R_external<ST_CLASS, FFT_forward><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);

@@ -11,16 +11,17 @@ namespace smfft {
 // fusion (natural-order variants of the planar lengths; everything else runs path 1).  grid_cap <= 0: one workgroup per 4096-element tile.
 // balance != 0 (multiple paths): when the batch is more chains than fit on the chip at once, the launch is a persistent grid of the
 // co-resident workgroups with the applications spread evenly over them (smfft_kernels.hpp, MultipleSchedule); 0: one chain per workgroup, grid-strided.
+// rotate = k > 0 (multiple paths): the waves' scheduling priority rotates every 2^k shader clocks (WavePriority); 0: the arbiter's oldest-first order.
 // pace = K > 0: the external kernels run their rate limiter with K serialised loads (smfft_kernels.hpp, vmem_throttle); the host API decides it per launch.
 // Returns hipSuccess (0) or the launch error.
 template <int N>
-int launch_ct(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, int grid_cap, int nreuses, int pace, int balance, hipStream_t stream);
+int launch_ct(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, int grid_cap, int nreuses, int pace, int balance, int rotate, hipStream_t stream);
 // Stockham C2C program (inverse sign), N = 256..4096.
 template <int N>
-int launch_st(const float2* d_input, float2* d_output, int count, int path, int grid_cap, int nreuses, int pace, int balance, hipStream_t stream);
+int launch_st(const float2* d_input, float2* d_output, int count, int path, int grid_cap, int nreuses, int pace, int balance, int rotate, hipStream_t stream);
 // R2C (inverse = 0) / C2R (inverse = 1) of real length 2L, L = 256..2048.
 template <int L>
-int launch_rc(const float2* d_input, float2* d_output, int count, int inverse, int path, int grid_cap, int nreuses, int pace, int balance, hipStream_t stream);
+int launch_rc(const float2* d_input, float2* d_output, int count, int inverse, int path, int grid_cap, int nreuses, int pace, int balance, int rotate, hipStream_t stream);
 
 // calibration copy of n_float2 elements (multiple of 4096) with the external kernels' access shape
 int launch_stream_copy(const float2* d_input, float2* d_output, long n_float2, int grid_cap, int pace, hipStream_t stream);

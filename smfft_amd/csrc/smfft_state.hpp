@@ -12,6 +12,7 @@ struct LaunchState {
     int nreuses;     // 0: NREUSES = 100
     int pacing;      // -2: the process default; -1: chosen per launch from the output buffer; K >= 0: K loads
     int balance;     // -1: the process default (SMFFT_MULT_BALANCE, else 1); 0 / 1: the multiple paths' balanced schedule off / on
+    int rotate;      // -1: the process default (SMFFT_PRIO_ROTATE, else 15); 0: the arbiter's oldest-first order; k: priorities rotate every 2^k clocks
 };
 LaunchState get_thread_state();
 void set_thread_state(const LaunchState& s);

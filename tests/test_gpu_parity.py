@@ -228,7 +228,7 @@ def test_ct_multiple_unfused_path_matches_fused(sm, oracle_lib, n):
     slots = _slots(n, nffts)
     assert np.array_equal(fused[slots:].view(np.uint32), unfused[slots:].view(np.uint32))     # the same slots are left untouched
     l2, mx = ref.fft_errors(unfused[:slots], fused[:slots].astype(np.complex128))
-    assert l2 < 2e-7 and mx < 1e-6, (l2, mx)
+    assert l2 < 5e-7 and mx < 2e-6, (l2, mx)
     want = x[:slots].astype(np.complex128)
     for _ in range(3):
         want = oa.ct_c2c(oracle_lib, want, 0, 1, "f64")
