@@ -282,6 +282,8 @@ def compact_line(detail):
         "contract_in_lds_ratio_to_compact": _minmax([_get(by_len, k, o, "in_lds_ratio_to_compact") for k in by_len for o in ("reorder", "noreorder")]),
         "contract_small_N_external_ratio": [_get(by_len, k, "reorder", "external_ratio_to_tiled") for k in ("32", "64", "128")],
         "contract_small_N_in_lds_ratio": [_get(by_len, k, "reorder", "in_lds_ratio_to_compact") for k in ("32", "64", "128")],
+        "contract_wave64_small_N_external_ratio": [_get(by_len, k, "reorder", "wave64", "external_ratio_to_tiled") for k in ("32", "64", "128")],
+        "contract_wave64_small_N_in_lds_ratio": [_get(by_len, k, "reorder", "wave64", "in_lds_ratio_to_compact") for k in ("32", "64", "128")],
         "hipfft_ms_on_pair": _get(detail, "vendor_hipfft", "ms_on_pair"),
     }
     line = {k: detail.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -675,6 +677,7 @@ def main():
                 cref[key] = {"ms": ms, "FFT/s": slots * 100 / (ms * 1e-3), "ratio_to_compact": compact / ms}
             # every length: the CT kernels in the reference's shape, external (reorder / no reorder) and in-LDS (README batch)
             ex.smfft_example_reference_shape_ct_multiple.argtypes = [vp, vp, ci, ci, ci, vp]
+            ex.smfft_example_reference_shape_ct_multiple_wave64.argtypes = [vp, vp, ci, ci, ci, vp]
             by_len = {}
             for fn_n in (32, 64, 128, 256, 512, 1024, 2048, 4096):
                 bn = min(total // fn_n, nffts * n // fn_n)
@@ -690,6 +693,18 @@ def main():
                     row[name] = {"external_ms": ms, "external_ratio_to_tiled": tiled / ms, "user_kernel_external_ms": ms_user,
                                  "user_kernel_external_ratio_to_tiled": tiled / ms_user, "in_lds_ms": msm,
                                  "in_lds_FFT/s": blocks * per_block * 100 / (msm * 1e-3), "in_lds_ratio_to_compact": compact / msm}
+                    if fn_n <= 128:
+                        # the wave64-full classes FFT_<N>_..._wave64 (blockDim.x = 64: a whole wavefront per block; upstream's 32-thread
+                        # block, CT:586-595, is half of one): same contract, same kernels
+                        per64 = 256 // fn_n
+                        blocks64 = (bn // 100) // per64
+                        ms64 = event_ms(lambda r=reo, fn_n=fn_n, bn=bn: ex.smfft_example_reference_shape_ct(pa.value, pb.value, fn_n, bn, 0, r, 3, sh), reps=5)
+                        ms64_user = event_ms(lambda r=reo, fn_n=fn_n, bn=bn: ex.smfft_example_reference_shape_ct(pa.value, pb.value, fn_n, bn, 0, r, 2, sh), reps=5)
+                        msm64 = event_ms(lambda r=reo, fn_n=fn_n, blocks64=blocks64: ex.smfft_example_reference_shape_ct_multiple_wave64(pa.value, pb.value, fn_n, blocks64, r, sh), reps=5, settle_launches=20)
+                        compact64 = c3[str(fn_n)][name]["ms"] * (blocks64 * per64 * 100) / c3[str(fn_n)]["FFTs_executed"]
+                        row[name]["wave64"] = {"external_ms": ms64, "external_ratio_to_tiled": tiled / ms64, "user_kernel_external_ms": ms64_user,
+                                               "user_kernel_external_ratio_to_tiled": tiled / ms64_user, "in_lds_ms": msm64,
+                                               "in_lds_FFT/s": blocks64 * per64 * 100 / (msm64 * 1e-3), "in_lds_ratio_to_compact": compact64 / msm64}
                 by_len[str(fn_n)] = row
             cref["by_length"] = by_len
         except (OSError, AttributeError) as e:

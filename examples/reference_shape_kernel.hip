@@ -31,6 +31,37 @@ static int launch_ct(float2* in, float2* out, int nFFTs, int which, hipStream_t 
     return (int)hipGetLastError();
 }
 
+// The wave64-full classes of N = 32 / 64 / 128 (FFT_<N>_..._wave64: blockDim.x = 64, 256 elements per block): whole blocks of
+// 256 / N transforms run on them, the last nFFTs mod (256 / N) transforms -- upstream only requires a multiple of 128 / N,
+// CT:835-836 -- on the upstream-shaped class.  which = 2: the user's kernel, 3: the library's two-argument kernel.
+template <class P64, class P32>
+static int launch_ct_wave64(float2* in, float2* out, int nFFTs, int which, hipStream_t st) {
+    constexpr int per64 = P64::fft_length / P64::fft_size, per32 = P32::fft_length / P32::fft_size;
+    const int full = nFFTs / per64, rest = (nFFTs - full * per64) / per32;
+    if (full > 0) {
+        if (which == 2) user_fft_kernel<P64><<<dim3(full), dim3(P64::fft_length / 4), 0, st>>>(in, out);
+        else SMFFT_DIT_external<P64><<<dim3(full), dim3(P64::fft_length / 4), 0, st>>>(in, out);
+    }
+    if (rest > 0) {
+        float2 *in_tail = in + (size_t)full * P64::fft_length, *out_tail = out + (size_t)full * P64::fft_length;
+        if (which == 2) user_fft_kernel<P32><<<dim3(rest), dim3(P32::fft_length / 4), 0, st>>>(in_tail, out_tail);
+        else SMFFT_DIT_external<P32><<<dim3(rest), dim3(P32::fft_length / 4), 0, st>>>(in_tail, out_tail);
+    }
+    return (int)hipGetLastError();
+}
+#define CT_CASE_SMALL(N)                                                                                                                                   \
+    case N:                                                                                                                                                \
+        if (which >= 2) {                                                                                                                                  \
+            if (!inverse && reorder) return launch_ct_wave64<FFT_##N##_forward_wave64, FFT_##N##_forward>(in, out, nFFTs, which, st);                      \
+            if (!inverse && !reorder) return launch_ct_wave64<FFT_##N##_forward_noreorder_wave64, FFT_##N##_forward_noreorder>(in, out, nFFTs, which, st); \
+            if (inverse && reorder) return launch_ct_wave64<FFT_##N##_inverse_wave64, FFT_##N##_inverse>(in, out, nFFTs, which, st);                       \
+            return launch_ct_wave64<FFT_##N##_inverse_noreorder_wave64, FFT_##N##_inverse_noreorder>(in, out, nFFTs, which, st);                           \
+        }                                                                                                                                                  \
+        if (!inverse && reorder) return launch_ct<FFT_##N##_forward>(in, out, nFFTs, which, st);                                                           \
+        if (!inverse && !reorder) return launch_ct<FFT_##N##_forward_noreorder>(in, out, nFFTs, which, st);                                                \
+        if (inverse && reorder) return launch_ct<FFT_##N##_inverse>(in, out, nFFTs, which, st);                                                            \
+        return launch_ct<FFT_##N##_inverse_noreorder>(in, out, nFFTs, which, st);
+
 #define CT_CASE(N)                                                                                              \
     case N:                                                                                                     \
         if (!inverse && reorder) return launch_ct<FFT_##N##_forward>(in, out, nFFTs, which, st);               \
@@ -41,8 +72,9 @@ static int launch_ct(float2* in, float2* out, int nFFTs, int which, hipStream_t 
 extern "C" int smfft_example_reference_shape_ct(void* d_in, void* d_out, int FFT_size, int nFFTs, int inverse, int reorder, int which, void* stream) {
     float2 *in = (float2*)d_in, *out = (float2*)d_out;
     hipStream_t st = (hipStream_t)stream;
+    if (which >= 2 && FFT_size >= 256) which -= 2;      // (the wave64-full classes exist for N <= 128 only)
     switch (FFT_size) {
-        CT_CASE(32) CT_CASE(64) CT_CASE(128) CT_CASE(256) CT_CASE(512) CT_CASE(1024) CT_CASE(2048) CT_CASE(4096)
+        CT_CASE_SMALL(32) CT_CASE_SMALL(64) CT_CASE_SMALL(128) CT_CASE(256) CT_CASE(512) CT_CASE(1024) CT_CASE(2048) CT_CASE(4096)
         default: return -1;
     }
 }
@@ -113,6 +145,16 @@ extern "C" int smfft_example_reference_shape_ct_multiple(void* d_in, void* d_out
     hipStream_t st = (hipStream_t)stream;
     switch (FFT_size) {
         CTM_CASE(32) CTM_CASE(64) CTM_CASE(128) CTM_CASE(256) CTM_CASE(512) CTM_CASE(1024) CTM_CASE(2048) CTM_CASE(4096)
+        default: return -1;
+    }
+}
+// the same with the wave64-full classes of N = 32 / 64 / 128: nBlocks blocks of 64 threads, 256 elements each
+#define CTM64_CASE(N) case N: return reorder ? launch_ct_multiple<FFT_##N##_forward_wave64>(in, out, nBlocks, st) : launch_ct_multiple<FFT_##N##_forward_noreorder_wave64>(in, out, nBlocks, st);
+extern "C" int smfft_example_reference_shape_ct_multiple_wave64(void* d_in, void* d_out, int FFT_size, int nBlocks, int reorder, void* stream) {
+    float2 *in = (float2*)d_in, *out = (float2*)d_out;
+    hipStream_t st = (hipStream_t)stream;
+    switch (FFT_size) {
+        CTM64_CASE(32) CTM64_CASE(64) CTM64_CASE(128)
         default: return -1;
     }
 }

@@ -114,6 +114,19 @@ def test_parameter_classes_match_reference_names_and_values(tmp_path):
             assert v["fft_sm_required"] >= ref[name]["fft_sm_required"]
     if ref:
         assert ref["FFT_4096_inverse_noreorder"]["fft_direction"] == 0   # the upstream typo this library does not reproduce
+    # the wave64-full extension classes of the small lengths: one full 64-lane wave per block, everything else as their namesakes
+    wave64 = [f"FFT_{n}_{suf}_wave64" for n in (32, 64, 128) for suf in ("forward", "forward_noreorder", "inverse", "inverse_noreorder")]
+    for flags, block_of_upstream_names in (([], 128), (["-DSMFFT_WAVE64_SMALL=1"], 256)):
+        body = "".join('printf("%s' % name + " %d" * len(members) + '\\n", ' + ", ".join(f"(int){name}::{m}" for m in members) + ");\n" for name in wave64 + names[:12])
+        src.write_text('#include <cstdio>\n#include "smfft/SM_FFT_parameters.hpp"\nint main() {\n' + body + "return 0; }\n")
+        subprocess.run(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)] + flags, check=True)
+        for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines():
+            f = line.split()
+            v = dict(zip(members, map(int, f[1:])))
+            n = int(f[0].split("_")[1])
+            length = 256 if f[0].endswith("_wave64") else block_of_upstream_names
+            assert v["fft_length"] == length and v["fft_length_quarter"] == length // 4 and v["fft_sm_required"] == 17 * length // 16, f[0]
+            assert v["fft_exp"] == n.bit_length() - 1 and v["fft_direction"] == int("inverse" in f[0]) and v["fft_reorder"] == int("noreorder" not in f[0]), f[0]
 
 
 def test_shard_range_tiles_batch():

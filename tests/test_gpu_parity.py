@@ -429,6 +429,52 @@ def test_reference_shaped_kernel_matches_oracle(sm, oracle_lib, n, inv, reo, whi
     ref.assert_close_fp32(got, sm.c2c(x, inverse=bool(inv), reorder=bool(reo)).astype(np.complex128), "reference-shaped vs tiled kernel")
 
 
+@pytest.mark.parametrize("n", [32, 64, 128])
+@pytest.mark.parametrize("inv,reo", [(0, 1), (1, 1), (0, 0), (1, 0)])
+@pytest.mark.parametrize("which", [2, 3])
+def test_wave64_full_small_length_classes_match_oracle(sm, oracle_lib, n, inv, reo, which):
+    """The wave64-full parameter classes of N = 32 / 64 / 128 (FFT_<N>_..._wave64: fft_length = 256, blockDim.x = 64 -- one full
+    wavefront holding 8 / 4 / 2 transforms where upstream's 32-thread block, CT:586-595, is half of one): the same
+    do_SMFFT_CT_DIT<P>(s) contract, the oracle's result.  The batch is deliberately ragged (whole 64-thread blocks + upstream-
+    shaped blocks for the rest).  which = 2: a user's fill / call / drain kernel, 3: the two-argument SMFFT_DIT_external<P>."""
+    import ctypes
+    ex = _examples(sm)
+    fn = ex.smfft_example_reference_shape_ct
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    per64, per32 = 256 // n, 128 // n
+    nffts = 37 * per64 + per32 * (1 if per64 > per32 else 0)            # a tail that only the upstream shape can hold
+    rng = np.random.default_rng(2000 * n + 10 * inv + reo + which)
+    x = (rng.random((nffts, n), dtype=np.float32) + 1j * rng.random((nffts, n), dtype=np.float32)).astype(np.complex64)
+    dx, dy = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
+    sm.lib.smfft_memset(dy.ptr, 0xFF, x.nbytes)
+    assert fn(dx.ptr, dy.ptr, n, nffts, inv, reo, which, None) == 0
+    assert sm.lib.smfft_synchronize() == 0
+    got = dy.to_host(np.complex64, x.shape)
+    ref.assert_close_fp32(got, oa.ct_c2c(oracle_lib, x, inv, reo, "f64"), f"wave64-full class N={n} inv={inv} reorder={reo}")
+    # bit-identical to the upstream-shaped class: the same four-elements-per-thread ladder, only the block is a whole wave
+    assert fn(dx.ptr, dy.ptr, n, nffts, inv, reo, which - 2, None) == 0 and sm.lib.smfft_synchronize() == 0
+    assert np.array_equal(dy.to_host(np.uint32, (nffts, 2 * n)), got.view(np.uint32))
+    dx.free()
+    dy.free()
+
+
+@pytest.mark.parametrize("n", [32, 64, 128])
+@pytest.mark.parametrize("reo", [1, 0])
+def test_wave64_full_multiple_kernel_runs(sm, n, reo):
+    """SMFFT_DIT_multiple<FFT_<N>_..._wave64> (100 applications in LDS, timing only as upstream) launches and finishes in the
+    64-thread shape at the README batch's block count."""
+    import ctypes
+    ex = _examples(sm)
+    fn = ex.smfft_example_reference_shape_ct_multiple_wave64
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    blocks = ((1 << 29) // n // 100) // (256 // n)
+    a, b = sm.DeviceBuffer(blocks * 256 * 8), sm.DeviceBuffer(blocks * 256 * 8)
+    sm.lib.smfft_memset(a.ptr, 0, a.nbytes)
+    assert fn(a.ptr, b.ptr, n, blocks, reo, None) == 0 and sm.lib.smfft_synchronize() == 0
+    a.free()
+    b.free()
+
+
 @pytest.mark.parametrize("n", C2C_SIZES)
 @pytest.mark.parametrize("reo", [1, 0])
 @pytest.mark.parametrize("which", [0, 1])
