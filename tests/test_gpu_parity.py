@@ -1052,6 +1052,9 @@ def test_wrapper_calls_share_the_device_with_their_own_cache(sm, capfd):
             ref.assert_close_fp32(y[-8:], ref.ct_c2c(x[-8:], False, True), "wrapper output, tail")
         return rc
 
+    flush = ctypes.CDLL(None).fflush              # the library prints through C stdio (fully buffered on a pipe):
+    flush(None)                                   # what earlier tests of this process left in the buffer is not this test's
+    capfd.readouterr()
     try:
         small, large = 2 * gib // (n * 8), 7 * gib // 2 // (n * 8)
         assert call(small) == 0                       # 2 x 2 GiB, searched (more than a quarter of what is free), kept in the cache
@@ -1060,7 +1063,6 @@ def test_wrapper_calls_share_the_device_with_their_own_cache(sm, capfd):
         assert call(small) == 0                       # same size: served from the cache
         assert call(large) == 0                       # 2 x 3.5 GiB = 7 GiB > the 6 GiB free at that moment: the cache is released first
         assert call(small) == 0                       # and back
-        flush = ctypes.CDLL(None).fflush          # the library prints through C stdio (fully buffered on a pipe)
         flush(None)
         out = capfd.readouterr().out
         assert "Not enough memory" not in out and out.count("SH FFT normal") == 4, out
