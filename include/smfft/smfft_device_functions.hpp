@@ -400,6 +400,12 @@ __device__ void do_FFT_Stockham_R2C_C2R(float2* s_input) {
 #ifndef SMFFT_CONTRACT_FUSED_IO
 #define SMFFT_CONTRACT_FUSED_IO 1
 #endif
+#ifndef SMFFT_CONTRACT_ROTATE_PRIORITY
+// log2 of the rotation period of the two-argument `multiple` kernels' wave priorities in shader clocks; 0 (default): off.  In the
+// reference's launch shape a launch is several rounds of short-lived blocks, where the arbiter's oldest-first order does no harm:
+// with 15 the in-LDS contract path measured 1-4 % SLOWER (the library's own persistent schedule gains 10-14 % from it).
+#define SMFFT_CONTRACT_ROTATE_PRIORITY 0
+#endif
 template <class const_params>
 __global__ void SMFFT_DIT_external(float2* d_input, float2* d_output) {
     __shared__ float2 s_input[const_params::fft_sm_required];
@@ -437,7 +443,11 @@ __global__ void SMFFT_DIT_multiple(float2* d_input, float2* d_output) {
     s_input[threadIdx.x + const_params::fft_length_half] = d_input[base + const_params::fft_length_half];
     s_input[threadIdx.x + const_params::fft_length_three_quarters] = d_input[base + const_params::fft_length_three_quarters];
     __syncthreads();
+    // (SMFFT_CONTRACT_ROTATE_PRIORITY: the blocks that share a SIMD advance at the same average rate instead of oldest first --
+    //  smfft_engine.hpp, WavePriority; a user's own loop around the device function can do the same)
+    const smfft::WavePriority priority(SMFFT_CONTRACT_ROTATE_PRIORITY);
     for (int f = 0; f < NREUSES; f++) {
+        priority.at_application(f);
         do_SMFFT_CT_DIT<const_params>(s_input);
         __syncthreads();   // the reference has none here (latent race, CT:563-565)
     }
@@ -479,7 +489,11 @@ __global__ void FFT_GPU_multiple(float2* d_input, float2* d_output) {   // ST:26
 #pragma unroll
     for (int k = 0; k < 4; ++k) s_input[threadIdx.x + k * const_params::fft_quarter] = d_input[base + k * const_params::fft_quarter];
     __syncthreads();
-    for (int f = 0; f < NREUSES; f++) do_FFT_Stockham_mk6<const_params>(s_input);   // the function ends with a barrier
+    const smfft::WavePriority priority(SMFFT_CONTRACT_ROTATE_PRIORITY);
+    for (int f = 0; f < NREUSES; f++) {
+        priority.at_application(f);
+        do_FFT_Stockham_mk6<const_params>(s_input);   // the function ends with a barrier
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) d_output[base + k * const_params::fft_quarter] = s_input[threadIdx.x + k * const_params::fft_quarter];
 }
@@ -530,7 +544,11 @@ __global__ void FFT_GPU_R2C_C2R_multiple(float2* d_input, float2* d_output) {   
 #pragma unroll
     for (int k = 0; k < 4; ++k) s_input[threadIdx.x + k * const_params::fft_quarter] = d_input[base + k * const_params::fft_quarter];
     __syncthreads();
-    for (int f = 0; f < NREUSES; f++) do_FFT_Stockham_R2C_C2R<const_params, const_direction>(s_input);   // ends with a barrier
+    const smfft::WavePriority priority(SMFFT_CONTRACT_ROTATE_PRIORITY);
+    for (int f = 0; f < NREUSES; f++) {
+        priority.at_application(f);
+        do_FFT_Stockham_R2C_C2R<const_params, const_direction>(s_input);   // ends with a barrier
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) d_output[base + k * const_params::fft_quarter] = s_input[threadIdx.x + k * const_params::fft_quarter];
 }

@@ -150,6 +150,35 @@ __device__ __forceinline__ void fft_sync() {
     }
 }
 
+// The SIMD's arbiter serves the OLDEST wave first.  Co-resident chains therefore do not share a SIMD evenly: on a CU that holds
+// four N = 4096 workgroups the oldest finishes its 100 applications after 428 k cycles, the others after 471 k, 613 k and 745 k
+// (profiles/r04_workgroup_trace.txt) -- every round of resident chains ends in a tail of its own making in which three, two
+// and finally one workgroup are left on the CU, and a persistent schedule inherits the same staircase over its whole length.
+// s_setprio overrides the age: each wave takes priority (slot + clock / 2^rotate) mod 4, slot = its wave slot in the SIMD, so
+// that at any moment the waves of a SIMD still run in a strict order (which is what overlaps one wave's LDS phase with
+// another's arithmetic) but over four periods every wave has had every rank, and co-resident chains end together.
+// For any kernel that keeps several long-running waves on a SIMD (the in-LDS `multiple` kernels; a user kernel that calls the
+// device functions in a loop): construct once, call at_application() once per iteration.  rotate = log2 of the period in shader
+// clocks (15 = 14 us measured best, profiles/r04_priority_rotation.txt); 0: leave the arbiter alone.
+struct WavePriority {
+    int slot, shift;
+    __device__ __forceinline__ explicit WavePriority(int rotate = 15) : shift(rotate) {
+        slot = (int)(__builtin_amdgcn_s_getreg((4 /* HW_REG_HW_ID */) | (0 << 6) | ((4 - 1) << 11)) & 3u);   // wave slot in the SIMD
+    }
+    // called once per application: the rank follows the CU's clock, so at any moment the waves of a SIMD hold a permutation of
+    // the ranks (their slots differ) and every wave holds every rank for the same share of the time
+    __device__ __forceinline__ void at_application(int = 0) const {
+        if (shift <= 0) return;
+        const unsigned now = (unsigned)(__builtin_readcyclecounter() >> shift);
+        switch ((slot + (int)now) & 3) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    }
+};
+
 // Sixteen reads base[STRIDE * i].  SINGLE = false: plain C++, which hipcc merges pairwise into ds_read2_b64 -- half
 // the instructions, and measured faster wherever the merged accesses are conflict free (the natural-order loads and the
 // t-major last layout: N = 32, 64, 512, 1024 in-LDS path 10-20 % faster than single reads, profiles/r02_ab_mult.txt).

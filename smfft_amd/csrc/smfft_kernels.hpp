@@ -236,31 +236,7 @@ struct MultipleSchedule {
     unsigned* residency;     // calibration launches only: [0] workgroups alive now, [1] the most that were alive at once
     unsigned long long* trace;   // experiments (SMFFT_SCHEDULE_TRACE): per workgroup {start, end} of s_memrealtime + {HW_ID, XCC_ID}; nullptr otherwise
 };
-// The SIMD's arbiter serves the OLDEST wave first.  Co-resident chains therefore do not share a SIMD evenly: on a CU that holds
-// four N = 4096 workgroups the oldest finishes its 100 applications after 428 k cycles, the others after 471 k, 613 k and 745 k
-// (profiles/r04_workgroup_trace.txt) -- every round of resident chains ends in a tail of its own making in which three, two
-// and finally one workgroup are left on the CU, and a persistent schedule inherits the same staircase over its whole length.
-// s_setprio overrides the age: each wave takes priority (slot + clock / 2^rotate) mod 4, slot = its wave slot in the SIMD, so
-// that at any moment the waves of a SIMD still run in a strict order (which is what overlaps one wave's LDS phase with
-// another's arithmetic) but over four periods every wave has had every rank, and co-resident chains end together.
-struct WavePriority {
-    int slot, shift;
-    __device__ __forceinline__ WavePriority(int rotate) : shift(rotate) {
-        slot = (int)(__builtin_amdgcn_s_getreg((4 /* HW_REG_HW_ID */) | (0 << 6) | ((4 - 1) << 11)) & 3u);   // wave slot in the SIMD
-    }
-    // called once per application: the rank follows the CU's clock, so at any moment the waves of a SIMD hold a permutation of
-    // the ranks (their slots differ) and every wave holds every rank for the same share of the time
-    __device__ __forceinline__ void at_application(int) const {
-        if (shift <= 0) return;
-        const unsigned now = (unsigned)(__builtin_readcyclecounter() >> shift);
-        switch ((slot + (int)now) & 3) {
-            case 0: __builtin_amdgcn_s_setprio(0); break;
-            case 1: __builtin_amdgcn_s_setprio(1); break;
-            case 2: __builtin_amdgcn_s_setprio(2); break;
-            default: __builtin_amdgcn_s_setprio(3); break;
-        }
-    }
-};
+// (WavePriority -- the rotation of the waves' scheduling priorities -- lives in smfft/smfft_engine.hpp: user kernels may use it too)
 __device__ __forceinline__ void residency_enter(unsigned* r) {
     if (r && threadIdx.x == 0) atomicMax(r + 1, atomicAdd(r, 1u) + 1u);
 }
@@ -282,7 +258,15 @@ __device__ __forceinline__ void chain_signal_parked(unsigned* flag, unsigned epo
 }
 __device__ __forceinline__ void chain_wait_parked(unsigned* flag, unsigned epoch) {
     if (threadIdx.x == 0) {
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(8);
+        // Nobody waits here in practice (the first part of a chain is finished long before its second part is due), and a wait can
+        // only point to a lower block index, which the dispatcher has started earlier (per XCD in order), so it always ends.  Should
+        // that reasoning ever fail on some device, the kernel TRAPS after three seconds instead of hanging the GPU: the launch then
+        // returns an error (SMFFT_MULT_BALANCE=0 is the schedule without hand-offs).
+        const unsigned long long t0 = wall_clock64();                   // 100 MHz
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > 300000000ull) __builtin_trap();
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // L1 and the XCD's L2 drop what they hold of other XCDs' lines
     }
     __syncthreads();
