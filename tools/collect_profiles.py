@@ -31,7 +31,7 @@ def counters(sub):
 # 1. kernel stats of the bench command
 for f in newest(os.path.join(src, "stats", "**", "*kernel_stats.csv")):
     shutil.copy(f, f"profiles/{tag}_bench_kernel_stats.csv")
-for name in ("bench.json", "bench_under_rocprof.json", "configs.json", "mult_saturation.txt"):
+for name in ("bench.json", "bench_detail.json", "bench_under_rocprof.json", "configs.json", "mult_saturation.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), f"profiles/{tag}_{name}")
 

@@ -1,3 +1,5 @@
+"""One round of co-resident chains (reorder kernels, old schedule) with 1 ... 100 applications per chain: the intercept is what a
+`multiple` launch pays whatever the applications (dispatch, the tile loads and stores of all workgroups at once, the event bracket)."""
 import ctypes, sys, os
 sys.path.insert(0, os.getcwd())
 import smfft_amd as sm

@@ -1,3 +1,6 @@
+"""In-LDS reorder kernels, one round of co-resident chains / the README batch / a saturating batch, one chain per workgroup
+(balance 0) against the balanced schedule, for the rotation period of the wave priorities given by SMFFT_PRIO_ROTATE (log2 of
+shader clocks, 0 = off):   for k in 0 9 11 13 15 17 19; do SMFFT_PRIO_ROTATE=$k python tools/priority_rotation_sweep.py; done"""
 import ctypes, sys, os
 sys.path.insert(0, os.getcwd())
 import smfft_amd as sm
@@ -12,7 +15,7 @@ def med(fn, reps=7):
     for _ in range(reps):
         t = ctypes.c_double(0); fn(ctypes.byref(t)); ts.append(t.value)
     return sorted(ts)[len(ts)//2]
-print("SMFFT_STAGGER =", os.environ.get("SMFFT_STAGGER"), "SMFFT_PRIO_ROTATE =", os.environ.get("SMFFT_PRIO_ROTATE"))
+print("SMFFT_PRIO_ROTATE =", os.environ.get("SMFFT_PRIO_ROTATE"))
 for n, slots in ((4096, 1024), (1024, 4096), (2048, 2048), (256, 4096)):
     tile = max(1, 1024 // n)
     for label, ntiles in (("1 x slots", slots), ("README", (total // n) // 100 // tile), ("8 x slots + 37%", int(8.37 * slots))):

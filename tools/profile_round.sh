@@ -9,6 +9,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+cp bench_detail.json $OUT/bench_detail.json     # the full record behind the compact line (later runs overwrite bench_detail.json)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-plain > $OUT/bench_under_rocprof.json 2>/dev/null
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1

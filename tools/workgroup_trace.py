@@ -1,3 +1,5 @@
+"""One `multiple` launch with per-workgroup traces: SMFFT_SCHEDULE_TRACE=<tmp file> python tools/workgroup_trace.py N chains balance out.txt
+(each line: block, start and end of s_memtime on its CU, HW_ID, XCC_ID; counters of different CUs are not aligned)"""
 import ctypes, sys, os
 sys.path.insert(0, os.getcwd())
 import smfft_amd as sm
