@@ -463,16 +463,52 @@ struct PlanarEngine {
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// TWO VIRTUAL THREADS PER LANE (round 4; the in-LDS kernels of N = 2048 / 4096).  The engine above gives a thread sixteen elements,
+// so N = 2048 / 4096 take two / four waves and pay five to six workgroup barriers per application (SQ_WAIT_ANY 21 % / 15 % of
+// the wave cycles).  Here a lane stands in for the threads tid and tid + TW/2 -- two PlanarEngine objects with their own roles,
+// offsets and pass-1 twiddles (the middle twiddles depend on t2 only and are the same) -- and runs every phase for both:
+// N = 2048 lives in ONE wave (no barrier anywhere, as N <= 1024), N = 4096 in two.  The LDS images, the store rows
+// (ds_write_addtid_b32 with the other virtual wave's base in M0) and every result are exactly the sixteen-elements-per-thread
+// engine's; the phases of the two virtual threads are independent instruction streams the scheduler interleaves.
+// MULTI_WAVE: whether the PHYSICAL workgroup has more than one wave.
+template <bool MULTI_WAVE, int N, int DIR, int REORDER>
+__device__ __forceinline__ void transform2_from_pass1_slots(const PlanarEngine<N, DIR, REORDER>& ea, float2 (&ra)[16], const PlanarEngine<N, DIR, REORDER>& eb, float2 (&rb)[16],
+                                                            float* planes) {
+    using E = PlanarEngine<N, DIR, REORDER>;
+    static_assert(E::kThreePass && !E::kRegisterX1, "N = 2048 / 4096");
+    ea.pass1(ra);
+    eb.pass1(rb);
+    planar_sync<MULTI_WAVE>();          // every read of the previous image is done
+    ea.x1_store(ra);
+    eb.x1_store(rb);
+    planar_sync<MULTI_WAVE>();
+    ea.x1_load(ra, planes);
+    eb.x1_load(rb, planes);
+    ea.middle(ra);
+    eb.middle(rb);
+    planar_sync<MULTI_WAVE>();
+    ea.x2_store(ra);
+    eb.x2_store(rb);
+    planar_sync<MULTI_WAVE>();
+    float2 xa[16], xb[16];
+    ea.x2_load(xa, planes);
+    eb.x2_load(xb, planes);
+    SmallDft<16, 1, DIR>::run(xa, ra);
+    SmallDft<16, 1, DIR>::run(xb, rb);
+}
+
 // tile <-> planar image (once per tile): element e = fft * N + n of the tile, n = u + T*c, lies in row c at dword
 // fft * T + position(u); position(u) = u, or the position of the thread whose pass-1 role is u (reorder)
+// thread = threadIdx.x, or the index of the VIRTUAL thread this lane stands in for (the two-threads-per-lane kernels of N >= 2048)
 template <int N, int DIR, int REORDER>
-__device__ __forceinline__ void tile_to_planes(const float2* __restrict__ g, float* planes, long first_fft, long limit_fft) {
+__device__ __forceinline__ void tile_to_planes(const float2* __restrict__ g, float* planes, long first_fft, long limit_fft, int thread = -1) {
     using E = PlanarEngine<N, DIR, REORDER>;
     using P = PlanarGeometry<N, REORDER>;
     constexpr int T = E::T, TW = E::TW;
     // (opaque copy of the thread index: the sixteen addresses below are computed where they are used, once per chain, instead
     //  of being hoisted out of the loop over chains and kept in registers across the applications)
-    int tid = threadIdx.x;
+    int tid = thread < 0 ? (int)threadIdx.x : thread;
     asm volatile("" : "+v"(tid));
     float2 val[16];
     const bool full = first_fft + P::F <= limit_fft;
@@ -494,11 +530,11 @@ __device__ __forceinline__ void tile_to_planes(const float2* __restrict__ g, flo
     }
 }
 template <int N, int DIR, int REORDER>
-__device__ __forceinline__ void planes_to_tile(float2* __restrict__ g, const float* planes, long first_fft, long limit_fft) {
+__device__ __forceinline__ void planes_to_tile(float2* __restrict__ g, const float* planes, long first_fft, long limit_fft, int thread = -1) {
     using E = PlanarEngine<N, DIR, REORDER>;
     using P = PlanarGeometry<N, REORDER>;
     constexpr int T = E::T, TW = E::TW;
-    int tid = threadIdx.x;
+    int tid = thread < 0 ? (int)threadIdx.x : thread;
     asm volatile("" : "+v"(tid));
     const bool full = first_fft + P::F <= limit_fft;
 #pragma unroll

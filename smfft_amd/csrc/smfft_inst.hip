@@ -21,16 +21,23 @@ namespace smfft {
 // grid cap.  Balanced (the default when the batch is more chains than the chip holds at once): a persistent grid of the
 // co-resident workgroups, each owning an equal share of the launch's ntiles * nreuses applications (MultipleSchedule).
 using CompactKernel = void (*)(const float2*, float2*, int, int, MultipleSchedule);
-static int launch_compact(CompactKernel kernel, const float2* d_input, float2* d_output, int count, int grid_cap, int nreuses, int balance, int rotate, hipStream_t stream) {
+static int launch_compact(CompactKernel kernel, const float2* d_input, float2* d_output, int count, int grid_cap, int nreuses, int balance, int rotate, hipStream_t stream,
+                          int threads = Geometry<SMFFT_N>::kCompactThreads) {
     using G = Geometry<SMFFT_N>;
     const int ntiles = (count + G::kCompactFfts - 1) / G::kCompactFfts;
     // (rotate: the waves' scheduling priority rotates every 2^15 shader clocks = 14 us by default; smfft_kernels.hpp, WavePriority;
     //  sweep of the period: profiles/r04_priority_rotation.txt)
     MultipleSchedule sch = {0, 0u, nullptr, rotate, nullptr, nullptr};
     int grid = grid_for(count, G::kCompactFfts, grid_cap);
-    if (balance && nreuses > 1) {
-        // balance >= 2 (tests): that many workgroups, as if the chip held no more
-        const int slots = balance >= 2 ? balance : resident_workgroups((const void*)kernel, G::kCompactThreads);
+    // Which schedule.  Up to four rounds' worth of chains: the balanced persistent grid (when there is
+    // more than one round) and rotating priorities -- no tail, co-resident chains end together: +14-24 % on the README batches.
+    // A long launch (more than four rounds) is in a steady state of its own: workgroups start whenever an older one ends, the
+    // tail is a few percent, and there the persistent grid measured 0-7 % SLOWER (N = 2048 most): one chain per workgroup,
+    // grid-strided, the arbiter's own order.  balance >= 2 (tests): that many workgroups, as if the chip held no more.
+    const int slots = balance >= 2 ? balance : resident_workgroups((const void*)kernel, threads);
+    const bool short_launch = slots <= 0 || balance >= 2 || (long)ntiles <= 4l * slots;
+    if (!short_launch) sch.rotate = 0;
+    if (balance && nreuses > 1 && short_launch) {
         if (slots > 0 && ntiles > slots) {
             const long total = (long)ntiles * nreuses;
             const long per_wg = (total + slots - 1) / slots;            // > nreuses, so a chain straddles at most two workgroups
@@ -45,13 +52,13 @@ static int launch_compact(CompactKernel kernel, const float2* d_input, float2* d
         }
     }
     sch.residency = residency_probe();
-    if (sch.residency) note_resident_workgroups(resident_workgroups((const void*)kernel, G::kCompactThreads));          // non-null only inside smfft_measure_multiple_residency
+    if (sch.residency) note_resident_workgroups(resident_workgroups((const void*)kernel, threads));          // non-null only inside smfft_measure_multiple_residency
     static const bool debug = getenv("SMFFT_SCHEDULE_DEBUG") != nullptr;
     if (debug) printf("smfft multiple N=%d: %d chains x %d applications, %d co-resident workgroups (occupancy query), grid %d, %d applications per workgroup%s\n", SMFFT_N, ntiles, nreuses,
-                      resident_workgroups((const void*)kernel, G::kCompactThreads), grid, sch.per_wg, sch.per_wg ? "" : " (one chain at a time)");
+                      resident_workgroups((const void*)kernel, threads), grid, sch.per_wg, sch.per_wg ? "" : " (one chain at a time)");
     static const char* trace_file = getenv("SMFFT_SCHEDULE_TRACE");          // experiments: one line per workgroup of the LAST launch
     if (trace_file && hipMalloc((void**)&sch.trace, (size_t)grid * 32) != hipSuccess) sch.trace = nullptr;
-    kernel<<<dim3(grid), dim3(G::kCompactThreads), 0, stream>>>(d_input, d_output, count, nreuses, sch);
+    kernel<<<dim3(grid), dim3(threads), 0, stream>>>(d_input, d_output, count, nreuses, sch);
     if (sch.trace) {
         std::vector<unsigned long long> host((size_t)grid * 4);
         (void)hipMemcpy(host.data(), sch.trace, host.size() * 8, hipMemcpyDeviceToHost);
@@ -86,6 +93,15 @@ int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int i
     if (path == 2 && reorder) {     // no cross-application fusion (what one call of the device function costs)
         if (!inverse) return launch_compact(SMFFT_DIT_multiple_unfused<CT_CLASS(_forward)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
         return launch_compact(SMFFT_DIT_multiple_unfused<CT_CLASS(_inverse)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
+    }
+#endif
+#if SMFFT_X2_SIZES(SMFFT_N)
+    if (path == 1) {                // two virtual threads per lane: N = 2048 in one wave, N = 4096 in two
+        constexpr int kThreads = Geometry<SMFFT_N>::kCompactThreads / 2;
+        if (!inverse && reorder)  return launch_compact(SMFFT_DIT_multiple_x2<CT_CLASS(_forward)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream, kThreads);
+        if (!inverse && !reorder) return launch_compact(SMFFT_DIT_multiple_x2<CT_CLASS(_forward_noreorder)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream, kThreads);
+        if (inverse && reorder)   return launch_compact(SMFFT_DIT_multiple_x2<CT_CLASS(_inverse)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream, kThreads);
+        return launch_compact(SMFFT_DIT_multiple_x2<CT_CLASS(_inverse_noreorder)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream, kThreads);
     }
 #endif
     if (!inverse && reorder)  return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_forward)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);

@@ -453,6 +453,72 @@ __device__ __forceinline__ void c2c_multiple_body_planar(const float2* __restric
     residency_leave(sch.residency);
 }
 
+// The same kernel with two virtual threads per lane (smfft_planar.hpp, transform2_from_pass1_slots): N = 2048 in one wave,
+// N = 4096 in two.  Launched with Geometry<N>::kCompactThreads / 2 threads.
+// MEASURED AND NOT USED (profiles/r04_ab_two_virtual_threads.txt): 20-25 % slower than the sixteen-elements-per-thread kernels at
+// both lengths, README and saturating batch alike -- two or three waves per SIMD hide less latency than four, and the two
+// instruction streams of a lane interleave worse statically than four waves do in hardware.  Kept as an A/B build.
+#ifndef SMFFT_MULT_X2
+#define SMFFT_MULT_X2 0          // 1: N = 2048 / 4096 on two virtual threads per lane
+#endif
+#define SMFFT_X2_SIZES(N) (SMFFT_MULT_X2 && SMFFT_PLANAR && (N) >= 2048)
+template <int N, int DIR, int REORDER>
+__device__ __forceinline__ void c2c_multiple_body_planar_x2(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, MultipleSchedule sch, float* planes) {
+    using G = Geometry<N>;
+    constexpr int H = G::kCompactThreads / 2;               // physical threads; the second virtual thread of a lane is tid + H
+    constexpr bool kMW = H > 64;
+    PlanarEngine<N, DIR, REORDER> ea, eb;
+    ea.init(threadIdx.x, planes);
+    eb.init(threadIdx.x + H, planes);
+    const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
+    const PieceLoop pieces(sch, ntiles, nreuses);
+    const WavePriority priority(sch.rotate);
+    trace_mark(sch.trace, 0);
+    residency_enter(sch.residency);
+    for (int k = 0; k < pieces.count; ++k) {
+        const int tile = pieces.tile(k), app0 = pieces.app0(k), app1 = pieces.app1(k);
+        const long first = (long)tile * G::kCompactFfts;
+        const int napps = app1 - app0;
+        if (app0 > 0) chain_wait_parked(sch.flags + tile, sch.epoch);
+        planar_sync<kMW>();
+        const float2* src = (app0 > 0 ? d_output : d_input) + first * N;
+        tile_to_planes<N, DIR, REORDER>(src, planes, first, nSlots, threadIdx.x);
+        tile_to_planes<N, DIR, REORDER>(src, planes, first, nSlots, threadIdx.x + H);
+        planar_sync<kMW>();
+        float2 ra[16], rb[16];
+        if constexpr (REORDER) {
+            ea.image_load_own(ra, planes);
+            eb.image_load_own(rb, planes);
+            for (int f = 0; f < napps; ++f) {
+                priority.at_application(app0 + f);
+                ea.natural_to_slots(ra);
+                eb.natural_to_slots(rb);
+                transform2_from_pass1_slots<kMW>(ea, ra, eb, rb, planes);
+                planar_sync<kMW>();                 // the last pass's reads are done before the result overwrites them
+                ea.image_store(ra);
+                eb.image_store(rb);
+            }
+        } else {
+            for (int f = 0; f < napps; ++f) {
+                priority.at_application(app0 + f);
+                ea.image_load_bitrev(ra, planes);
+                eb.image_load_bitrev(rb, planes);
+                transform2_from_pass1_slots<kMW>(ea, ra, eb, rb, planes);
+                planar_sync<kMW>();
+                ea.image_store(ra);
+                eb.image_store(rb);
+                planar_sync<kMW>();                 // the reference omits this (latent race, CT:563-565)
+            }
+        }
+        planar_sync<kMW>();
+        planes_to_tile<N, DIR, REORDER>(d_output + first * N, planes, first, nSlots, threadIdx.x);
+        planes_to_tile<N, DIR, REORDER>(d_output + first * N, planes, first, nSlots, threadIdx.x + H);
+        if (app1 < nreuses) chain_signal_parked(sch.flags + tile, sch.epoch);
+    }
+    trace_mark(sch.trace, 1);
+    residency_leave(sch.residency);
+}
+
 // ------------------------------------------------------------------------------------------------
 // R2C / C2R external kernels (real length 2L through a complex FFT of length L, RC:269-365): tiled form.
 // ------------------------------------------------------------------------------------------------
@@ -812,6 +878,15 @@ __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_size) SMFFT_DIT_multiple_
     static_assert(SMFFT_PLANAR_SIZES(N) && const_params::fft_reorder, "the no-reorder variants and N = 32 are unfused as they are");
     __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<N, 1>::kLdsFloats];
     smfft::c2c_multiple_body_planar<N, const_params::fft_direction, 1, false>(d_input, d_output, nSlots, nreuses, sch, s_planes);
+}
+
+// N = 2048 / 4096 with two virtual threads per lane: half the threads, at most 256 registers (two waves per SIMD)
+template <class const_params>
+__global__ void __launch_bounds__(smfft::Geometry<const_params::fft_size>::kCompactThreads / 2, 2)
+SMFFT_DIT_multiple_x2(const float2* d_input, float2* d_output, int nSlots, int nreuses, smfft::MultipleSchedule sch) {
+    constexpr int N = const_params::fft_size;
+    __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<N, const_params::fft_reorder>::kLdsFloats];
+    smfft::c2c_multiple_body_planar_x2<N, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nSlots, nreuses, sch, s_planes);
 }
 
 // Stockham C2C program: un-normalised INVERSE (+i) transform, natural order (ST:76, :429).
