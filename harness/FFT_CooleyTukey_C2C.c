@@ -48,19 +48,26 @@ int main(int argc, char **argv) {
 		GPU_smFFT_4elements(h_input, h_output_smFFT, FFT_size, nFFTs, inverse, reorder, nRuns, &smFFT_execution_time, &smFFT_multiple_execution_time);
 		print_verdict(Compare_data(h_output_cuFFT, h_output_smFFT, FFT_size, nFFTs, &cumulative_error, &mean_error));
 	}
+	else if (getenv("SMFFT_HARNESS_VERIFY_NOREORDER") == NULL) {
+		// exactly as upstream (FFT.c:150-163): the transform runs and is timed, nothing is compared
+		GPU_smFFT_4elements(h_input, h_output_smFFT, FFT_size, nFFTs, inverse, reorder, nRuns, &smFFT_execution_time, &smFFT_multiple_execution_time);
+		printf("  There is no verification of the results if FFT are not reordered.\n");
+	}
 	else {
-		// Upstream prints "There is no verification of the results if FFT are not reordered." (FFT.c:162).  Without reorder the
-		// transform is the DFT of the bit-reversed input (the DIT ladder applied to natural-order data), so it IS checkable:
-		// the comparator transforms a bit-reversed copy of the input.
+		// SMFFT_HARNESS_VERIFY_NOREORDER=1 (an extension).  Without reorder the transform is the DFT of the bit-reversed input
+		// (the DIT ladder applied to natural-order data), so it IS checkable: the comparator transforms a bit-reversed copy of
+		// the input.  (Upstream's metric, max_error = 1e-4 absolute on U[0,1) data, flags fp32 round-off itself at N >= 2048;
+		// the stated tolerance of this repository is checked by the parity tests.)
 		int bits = 0;
 		while ((1 << bits) < FFT_size) bits++;
 		float2 *h_bitrev = (float2 *) calloc(count, sizeof(float2));
-		if (!h_bitrev) { printf("Host memory allocation failed.\n"); return 1; }
-		for (int i = 0; i < FFT_size; i++) {
-			int r = 0;
-			for (int b = 0; b < bits; b++) r |= ((i >> b) & 1) << (bits - 1 - b);
-			for (int f = 0; f < nFFTs; f++) h_bitrev[(size_t) f*FFT_size + i] = h_input[(size_t) f*FFT_size + r];
-		}
+		int *rev = (int *) calloc(FFT_size, sizeof(int));
+		if (!h_bitrev || !rev) { printf("Host memory allocation failed.\n"); return 1; }
+		for (int i = 0; i < FFT_size; i++)
+			for (int b = 0; b < bits; b++) rev[i] |= ((i >> b) & 1) << (bits - 1 - b);
+		for (int f = 0; f < nFFTs; f++)          // FFT-major: one pass over the batch
+			for (int i = 0; i < FFT_size; i++) h_bitrev[(size_t) f*FFT_size + i] = h_input[(size_t) f*FFT_size + rev[i]];
+		free(rev);
 		GPU_cuFFT(h_bitrev, h_output_cuFFT, FFT_size, nFFTs, inverse, nRuns, &cuFFT_execution_time);
 		free(h_bitrev);
 		GPU_smFFT_4elements(h_input, h_output_smFFT, FFT_size, nFFTs, inverse, reorder, nRuns, &smFFT_execution_time, &smFFT_multiple_execution_time);
