@@ -37,7 +37,11 @@ static int launch_compact(CompactKernel kernel, const float2* d_input, float2* d
     const int slots = balance >= 2 ? balance : resident_workgroups((const void*)kernel, threads);
     const bool short_launch = slots <= 0 || balance >= 2 || (long)ntiles <= 4l * slots;
     if (!short_launch) sch.rotate = 0;
-    if (balance && nreuses > 1 && short_launch) {
+    // a launch that is being CAPTURED into a graph keeps one chain per workgroup: the balanced grid's hand-off flags carry the
+    // epoch of one launch (a replayed graph would find them set), and their buffer may have to be allocated here
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (stream != nullptr && hipStreamIsCapturing(stream, &capture) != hipSuccess) { (void)hipGetLastError(); capture = hipStreamCaptureStatusNone; }
+    if (balance && nreuses > 1 && short_launch && capture == hipStreamCaptureStatusNone) {
         if (slots > 0 && ntiles > slots) {
             const long total = (long)ntiles * nreuses;
             const long per_wg = (total + slots - 1) / slots;            // > nreuses, so a chain straddles at most two workgroups

@@ -161,6 +161,48 @@ def test_ct_multiple_balanced_schedule_is_bit_identical(sm, n, inv, reo):
         sm.lib.smfft_set_multiple_balance(-1)
 
 
+def test_multiple_launch_captured_into_a_graph_replays_correctly(sm):
+    """smfft_launch on a stream that is being captured (callers may capture their launches): the in-LDS path then
+    keeps one chain per workgroup -- the balanced grid's hand-off flags carry the epoch of ONE launch and would be found set by a
+    replay -- so the graph can be launched any number of times: three replays, each the bits of a direct launch."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    vp = ctypes.c_void_p
+    n, reuses = 1024, 3
+    nffts = 100 * 23 + 5
+    rng = np.random.default_rng(91)
+    x = ((rng.random((nffts, n), dtype=np.float32) - 0.5) + 1j * (rng.random((nffts, n), dtype=np.float32) - 0.5)).astype(np.complex64)
+    din, dout = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
+    stream, graph, exe = vp(), vp(), vp()
+    sm.lib.smfft_set_nreuses(reuses)
+    sm.lib.smfft_set_multiple_balance(7)          # more chains than "fit": a direct launch is balanced over 7 workgroups
+    try:
+        sm.lib.smfft_memset(dout.ptr, 0xFF, x.nbytes)
+        sm.launch("ct", "multiple", din.ptr, dout.ptr, n, nffts, False, True)
+        assert sm.lib.smfft_synchronize() == 0
+        want = dout.to_host(np.uint32, (nffts, 2 * n))
+        assert hip.hipStreamCreate(ctypes.byref(stream)) == 0
+        assert hip.hipStreamBeginCapture(stream, 0) == 0                      # hipStreamCaptureModeGlobal
+        sm.launch("ct", "multiple", din.ptr, dout.ptr, n, nffts, False, True, stream=stream.value)
+        assert hip.hipStreamEndCapture(stream, ctypes.byref(graph)) == 0
+        assert hip.hipGraphInstantiate(ctypes.byref(exe), graph, None, None, 0) == 0
+        for _ in range(3):
+            sm.lib.smfft_memset(dout.ptr, 0xFF, x.nbytes)
+            assert hip.hipGraphLaunch(exe, stream) == 0 and hip.hipStreamSynchronize(stream) == 0
+            assert np.array_equal(dout.to_host(np.uint32, (nffts, 2 * n)), want)
+    finally:
+        sm.lib.smfft_set_nreuses(0)
+        sm.lib.smfft_set_multiple_balance(-1)
+        if exe.value:
+            hip.hipGraphExecDestroy(exe)
+        if graph.value:
+            hip.hipGraphDestroy(graph)
+        if stream.value:
+            hip.hipStreamDestroy(stream)
+        din.free()
+        dout.free()
+
+
 @pytest.mark.parametrize("n", R2C_SIZES)
 def test_r2c_multiple_balanced_schedule_is_bit_identical(sm, n):
     """the same for the R2C in-LDS kernel (a piece starts from the split result the previous piece parked) and the Stockham one"""
