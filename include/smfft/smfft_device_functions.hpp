@@ -162,6 +162,119 @@ __host__ __device__ constexpr int quarter_swizzle(int i) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// N <= 256 (round 4): the same radix-2^2 ladder with NO LDS between its passes.  The N/4 threads of a transform are 8 ... 64
+// lanes of one wave, so the exchange between two passes -- the four elements a thread holds swap their two slot bits with the
+// two lane bits that hold the next two index bits -- is a pair of one-bit lane <-> register transposes: v_permlane32_swap /
+// v_permlane16_swap for lane bits 5 / 4 (one instruction per dword pair), two row-DPP moves per dword pair for bits 3 / 2, a
+// quad-perm move and three selects for bits 1 / 0 (the primitives of smfft_engine.hpp).  N = 256: 56 such instructions per
+// thread replace three LDS round trips of the whole transform (12 ds_write_b64 + 12 ds_read_b64 per thread); the contract's
+// first read and last write of s[] remain.  Index bookkeeping (checked by a NumPy model of the lanes and slots against numpy.fft,
+// tools/quarter_lanes_model.py, and by the GPU parity tests of every contract kernel):
+//   in:   natural order: thread t loads x[t + m N/4] into slot rev2(m) -> it holds y[4 rev(t) + slot] of the bit-reversed input y,
+//         i.e. index bits 0, 1 in the slots and index bit 2 + b in lane bit T_BITS - 1 - b; no reorder: x[4 t + slot], bit 2 + b in lane bit b
+//   pass p >= 1 (P = 4^p): slot bits 0 / 1 (index bits 2p - 2, 2p - 1) <-> the lane bits that hold index bits 2p, 2p + 1 (lane_bit_of
+//         below), then the butterfly of quarter_fft with k = base mod P, base = rev(t) (natural order) or t (no reorder)
+//   odd log2 N: slot bit 0 <-> the last lane bit, two radix-2 butterflies with W_N^base and -+i W_N^base
+//   out:  slot i holds result element base + (N/4) * sigma(i), sigma = identity (even log2 N) or (0, 2, 1, 3) (odd)
+// Measured (profiles/r04_contract_lanes.txt; in-LDS loop of 100 calls, README batch): N = 32 +40...+60 %, N = 128 +9...+13 %,
+// N = 64 -7...+4 %, N = 256 -1...-3.5 % against the LDS form -- the quad-perm transposes of lane bits 0 / 1 cost 32 of a
+// thread's 56 exchange instructions.  So do_SMFFT_CT_DIT uses the lane form for N = 32 and 128 and the LDS form otherwise.
+// Around an HBM-bound fill / call / drain the two are within 6 % of each other (the lane form ahead in upstream's 32-thread
+// blocks, behind in 64-thread blocks), which is why the two-argument external kernels below choose per shape.
+#ifndef SMFFT_QUARTER_LANES
+#define SMFFT_QUARTER_LANES 1          // 0: every length through LDS (A/B); 2: the lane form for every N <= 256
+#endif
+constexpr bool quarter_lanes_default(int n) { return SMFFT_QUARTER_LANES == 2 ? n <= 256 : SMFFT_QUARTER_LANES == 1 ? (n == 32 || n == 128) : false; }
+template <int LANE_BIT>
+__device__ __forceinline__ void lane_slot_swap(float2& A, float2& B, int lane) {
+    using X = Engine<1024, 0, 1>;                // (the transposes are static members; the length is immaterial)
+    if constexpr (LANE_BIT >= 4) {
+        X::template swap_bit<LANE_BIT>(A, B);
+    } else {
+        const bool hi = (lane >> LANE_BIT) & 1;
+        X::template swap_bit_dpp_dword<LANE_BIT>(A.x, B.x, hi);
+        X::template swap_bit_dpp_dword<LANE_BIT>(A.y, B.y, hi);
+    }
+}
+// slot bit SLOT_BIT of the thread's four elements <-> lane bit LANE_BIT
+template <int SLOT_BIT, int LANE_BIT>
+__device__ __forceinline__ void slots_swap(float2 (&e)[4], int lane) {
+    if constexpr (SLOT_BIT == 0) {
+        lane_slot_swap<LANE_BIT>(e[0], e[1], lane);
+        lane_slot_swap<LANE_BIT>(e[2], e[3], lane);
+    } else {
+        lane_slot_swap<LANE_BIT>(e[0], e[2], lane);
+        lane_slot_swap<LANE_BIT>(e[1], e[3], lane);
+    }
+}
+template <int N, int DIR, int REORDER>
+struct QuarterLanes {
+    using R = QuarterTwiddleRows<N>;
+    static constexpr int Q = N / 4, T_BITS = ilog2c(Q), N_BITS = ilog2c(N);
+    static_assert(N >= 32 && N <= 256, "the transform's N / 4 threads must be lanes of one wave");
+    // the lane bit that holds index bit 2 + b at the start
+    static constexpr int lane_bit_of(int b) { return REORDER ? T_BITS - 1 - b : b; }
+    // result element of slot i, relative to base: (N/4) * sigma(i)
+    static constexpr int out_offset(int i) { return Q * (R::kOdd ? (((i & 1) << 1) | (i >> 1)) : i); }
+    __device__ static __forceinline__ int base_of(int t) { return REORDER ? (int)(__brev((unsigned)t) >> (32 - T_BITS)) : t; }
+
+    template <int P_INDEX>
+    __device__ static __forceinline__ void passes(float2 (&e)[4], int base, int lane) {
+        if constexpr (P_INDEX < R::kPasses) {
+            constexpr int P = 1 << (2 * P_INDEX);
+            slots_swap<0, lane_bit_of(2 * P_INDEX - 2)>(e, lane);
+            slots_swap<1, lane_bit_of(2 * P_INDEX - 1)>(e, lane);
+            const TwiddleValue tv = quarter_twiddle_rows<N>.w[R::row_start(P_INDEX) + (base & (P - 1))];
+            const float2 w2 = make_float2(tv.x, DIR ? -tv.y : tv.y);
+            const float2 w1 = make_float2(w2.x * w2.x - w2.y * w2.y, 2.f * w2.x * w2.y);
+            const float2 t1 = cmul(e[1], w1), t3 = cmul(e[3], w1);
+            const float2 y0 = cadd(e[0], t1), y1 = csub(e[0], t1), y2 = cadd(e[2], t3), y3 = csub(e[2], t3);
+            const float2 u2 = cmul(y2, w2), v3 = cmul(y3, w2);
+            const float2 u3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);   // y3 * w2 * (-+i)
+            e[0] = cadd(y0, u2), e[1] = cadd(y1, u3), e[2] = csub(y0, u2), e[3] = csub(y1, u3);
+            passes<P_INDEX + 1>(e, base, lane);
+        }
+    }
+    // e[slot]: natural order e[rev2(m)] = x[t + m N/4], no reorder e[i] = x[4 t + i]; on return e[i] = result element base + out_offset(i)
+    __device__ static __forceinline__ void run(float2 (&e)[4], int t, int lane) {
+        const int base = base_of(t);
+        {   // pass 0: twiddles 1, 1, -+i
+            const float2 s0 = cadd(e[0], e[1]), d0 = csub(e[0], e[1]), s1 = cadd(e[2], e[3]), d1 = csub(e[2], e[3]);
+            const float2 jd1 = DIR ? make_float2(-d1.y, d1.x) : make_float2(d1.y, -d1.x);
+            e[0] = cadd(s0, s1), e[1] = cadd(d0, jd1), e[2] = csub(s0, s1), e[3] = csub(d0, jd1);
+        }
+        passes<1>(e, base, lane);
+        if constexpr (R::kOdd) {
+            slots_swap<0, lane_bit_of(N_BITS - 3)>(e, lane);
+            const TwiddleValue tv = quarter_twiddle_rows<N>.w[R::row_start(R::kPasses) + base];
+            const float2 w = make_float2(tv.x, DIR ? -tv.y : tv.y);
+            const float2 t1 = cmul(e[1], w), v3 = cmul(e[3], w);
+            const float2 t3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);
+            const float2 x0 = e[0], x2 = e[2];
+            e[0] = cadd(x0, t1), e[1] = csub(x0, t1), e[2] = cadd(x2, t3), e[3] = csub(x2, t3);
+        }
+    }
+    // the contract's form: data in s[region_offset .. + N) natural order in and out (IN_REGS: the inputs come in x[] instead)
+    template <bool IN_REGS>
+    __device__ static __forceinline__ void lds_to_lds(float2 (&x)[4], float2* s, int t, int region_offset) {
+        float2* sf = s + region_offset;
+        float2 e[4];
+        if constexpr (REORDER) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) e[((m & 1) << 1) | (m >> 1)] = IN_REGS ? x[m] : sf[t + m * Q];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) e[i] = IN_REGS ? x[i] : sf[4 * t + i];
+        }
+        run(e, t, (int)(threadIdx.x & 63));
+        if constexpr (!IN_REGS) fft_sync<false>();                  // every load of the transform's lanes precedes the stores (one wave)
+        const int base = base_of(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sf[base + out_offset(i)] = e[i];
+    }
+};
+
 // BLOCK_THREADS: threads the caller's block has (what decides between a wave-level fence and a workgroup barrier);
 // s: the block's LDS region, region_offset: where this thread's transform starts in it (f * N).
 // IN_REGS: the first pass takes its four inputs from x[] instead of loading them from s -- x[m] = element t + m N/4 (natural
@@ -169,8 +282,13 @@ __host__ __device__ constexpr int quarter_swizzle(int i) {
 // call; OUT_REGS: the last pass leaves its four results, elements t + m N/4, in x[] instead of storing them.  Both:
 // the transform of a thread block's registers with s as scratch -- one LDS round trip and one synchronisation less at
 // either end (the kernels in the reference's launch shape below use it for N >= 256).
-template <int N, int DIR, int REORDER, int BLOCK_THREADS, bool IN_REGS = false, bool OUT_REGS = false>
+// ENGINE: 0 = the default of the length (quarter_lanes_default), 1 = the LDS form, 2 = the lane form (N <= 256)
+template <int N, int DIR, int REORDER, int BLOCK_THREADS, bool IN_REGS = false, bool OUT_REGS = false, int ENGINE = 0>
 __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, int region_offset = 0) {
+    if constexpr ((ENGINE == 2 || (ENGINE == 0 && quarter_lanes_default(N))) && N <= 256 && !OUT_REGS) {   // the ladder on lanes and registers (QuarterLanes above)
+        QuarterLanes<N, DIR, REORDER>::template lds_to_lds<IN_REGS>(x, s, t, region_offset);
+        return;
+    }
     using R = QuarterTwiddleRows<N>;
     constexpr int Q = N / 4;
     constexpr bool kBarrier = BLOCK_THREADS > 64;
@@ -263,10 +381,10 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
     }
 }
 // in place on the LDS region (the reference's contract)
-template <int N, int DIR, int REORDER, int BLOCK_THREADS>
+template <int N, int DIR, int REORDER, int BLOCK_THREADS, int ENGINE = 0>
 __device__ __forceinline__ void quarter_fft_inplace(float2* s, int t, int region_offset = 0) {
     float2 unused[4];
-    quarter_fft<N, DIR, REORDER, BLOCK_THREADS, false, false>(unused, s, t, region_offset);
+    quarter_fft<N, DIR, REORDER, BLOCK_THREADS, false, false, ENGINE>(unused, s, t, region_offset);
 }
 
 // Hermitian split / merge on the reference's thread shape (L/4 threads, two pairs each: i = t + 1 and t + 1 + L/4, RC:289-328)
@@ -406,8 +524,36 @@ __device__ void do_FFT_Stockham_R2C_C2R(float2* s_input) {
 // with 15 the in-LDS contract path measured 1-4 % SLOWER (the library's own persistent schedule gains 10-14 % from it).
 #define SMFFT_CONTRACT_ROTATE_PRIORITY 0
 #endif
+// SMFFT_CONTRACT_LANES_IO: in upstream's 32-thread blocks of N <= 128 the two-argument external kernel loads a thread's four
+// elements from global memory straight into the lane-and-register ladder (QuarterLanes) and stores its four results from there:
+// no LDS at all (0.84 -> 0.91 of the tiled rate at N = 32 / 64, 0.71 -> 0.82 at N = 128).  Natural order: the lanes of a
+// transform store bit-reversed positions of a contiguous run of N/4 elements.  The 64-thread blocks of the _wave64 classes keep
+// fill / transform in LDS / drain on the LDS form of the ladder, which measured 3-6 % faster there (profiles/r04_contract_lanes.txt).
+#ifndef SMFFT_CONTRACT_LANES_IO
+#define SMFFT_CONTRACT_LANES_IO 1
+#endif
 template <class const_params>
 __global__ void SMFFT_DIT_external(float2* d_input, float2* d_output) {
+    if constexpr (SMFFT_CONTRACT_FUSED_IO && SMFFT_QUARTER_LANES && SMFFT_CONTRACT_LANES_IO && const_params::fft_size <= 128 && const_params::fft_length_quarter == 32) {
+        constexpr int N = const_params::fft_size, Q = N / 4;
+        using L = smfft::QuarterLanes<N, const_params::fft_direction, const_params::fft_reorder>;
+        const int t = threadIdx.x % Q;
+        const float2* in = d_input + (size_t)blockIdx.x * const_params::fft_length + (threadIdx.x / Q) * N;
+        float2* out = d_output + (size_t)blockIdx.x * const_params::fft_length + (threadIdx.x / Q) * N;
+        float2 e[4];
+        if constexpr (const_params::fft_reorder) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) e[((m & 1) << 1) | (m >> 1)] = in[t + m * Q];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) e[i] = in[4 * t + i];
+        }
+        L::run(e, t, (int)(threadIdx.x & 63));
+        const int base = L::base_of(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[base + L::out_offset(i)] = e[i];
+        return;
+    }
     __shared__ float2 s_input[const_params::fft_sm_required];
     if constexpr (SMFFT_CONTRACT_FUSED_IO && const_params::fft_size >= 256) {
         const int block = blockIdx.x * const_params::fft_length;
@@ -426,7 +572,12 @@ __global__ void SMFFT_DIT_external(float2* d_input, float2* d_output) {
     s_input[threadIdx.x + const_params::fft_length_half] = d_input[base + const_params::fft_length_half];
     s_input[threadIdx.x + const_params::fft_length_three_quarters] = d_input[base + const_params::fft_length_three_quarters];
     __syncthreads();
-    do_SMFFT_CT_DIT<const_params>(s_input);
+    if constexpr (const_params::fft_size <= 128) {       // (the LDS form of the ladder whatever do_SMFFT_CT_DIT's default is: see above)
+        constexpr int N = const_params::fft_size;
+        smfft::quarter_fft_inplace<N, const_params::fft_direction, const_params::fft_reorder, const_params::fft_length / 4, 1>(s_input, threadIdx.x % (N / 4), (threadIdx.x / (N / 4)) * N);
+    } else {
+        do_SMFFT_CT_DIT<const_params>(s_input);
+    }
     __syncthreads();
     d_output[base] = s_input[threadIdx.x];
     d_output[base + const_params::fft_length_quarter] = s_input[threadIdx.x + const_params::fft_length_quarter];

@@ -51,3 +51,14 @@ int main() {
                           stderr=subprocess.DEVNULL)
     got = [int(v) for v in subprocess.check_output([str(exe)], text=True).split()]
     assert got == [qs.product_swizzle(i) for i in range(4096)]
+
+
+def test_lane_and_register_form_of_the_ladder_is_the_dft():
+    """tools/quarter_lanes_model.py: the N <= 256 form of the reference-contract engine (exchanges between passes as lane <-> slot
+    bit transposes, no LDS) computes the DFT (natural order) / the DFT of the bit-reversed input (no reorder) for N = 32 ... 256,
+    and its results end where QuarterLanes::out_offset says."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import quarter_lanes_model
+    assert quarter_lanes_model.check() < 1e-14

@@ -1,29 +1,42 @@
-"""Prints the config-3 table of DESIGN.md section 5.2 from profiles/<tag>_bench.json (round-2 fractions in brackets):
-python tools/design_tables.py [r03]"""
+"""Prints the tables of DESIGN.md section 5.2 / 5.4 from profiles/<tag>_bench_detail.json (the full record behind a bench line):
+python tools/design_tables.py [r04]"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
-d = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_bench.json")))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+d = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_bench_detail.json")))
 c = d["configs"]["config3_multiple"]
+by_len = d["configs"]["reference_contract"]["by_length"]
 sup = str.maketrans("0123456789", "⁰¹²³⁴⁵⁶⁷⁸⁹")
-r2 = {"32": ("0.39", "0.41"), "64": ("0.34", "0.36"), "128": ("0.36", "0.36"), "256": ("0.40", "0.40"), "512": ("0.39", "0.39"),
-      "1024": ("0.37", "0.38"), "2048": ("0.36", "0.36"), "4096": ("0.39", "0.37")}
+r3 = {"32": ("0.398", "0.413"), "64": ("0.428", "0.493"), "128": ("0.481", "0.524"), "256": ("0.507", "0.542"), "512": ("0.437", "0.447"),
+      "1024": ("0.465", "0.481"), "2048": ("0.471", "0.476"), "4096": ("0.423", "0.441")}       # round 3's README-batch fractions (no reorder, reorder)
+SIZES = ("32", "64", "128", "256", "512", "1024", "2048", "4096")
 
 
 def sci(x):
     e = len(str(int(x))) - 1
-    return ("%.2f" % (x / 10 ** e)) + "·10" + str(e).translate(sup)
+    return ("%.2f" % (x / 10 ** e)).rstrip("0").rstrip(".") + "·10" + str(e).translate(sup)
 
 
-def bold(s, cond):
-    return "**%s**" % s if cond else s
-
-
-for n in ("32", "64", "128", "256", "512", "1024", "2048", "4096"):
+print("what one call costs (FFT/s): contract (wave64 class) | unfused | fused")
+for n in SIZES:
+    b = c[n]["reorder"]
+    con = by_len[n]["reorder"]
+    w = con.get("wave64")
+    print("| %s | %s%s | %s | %s |" % (n, sci(con["in_lds_FFT/s"]), " (%s)" % sci(w["in_lds_FFT/s"]) if w else "",
+                                     sci(b["unfused"]["FFT/s"]) if "unfused" in b else "= fused", sci(b["FFT/s"])))
+print("\nconfig 3: | N | reorder FFT/s | frac (round 3) | oldest-first | saturating | no reorder FFT/s | frac (round 3) | saturating |")
+for n in SIZES:
     a, b = c[n]["noreorder"], c[n]["reorder"]
-    print("| %s | %s | %s (%s) | %.3f | %s | %.3f (%s) | %.3f |" % (
-        n, bold(sci(a["FFT/s"]), n == "1024"), bold("%.3f" % a["frac_fp32_peak"], n in ("64", "2048", "4096")), r2[n][0], a["saturating_batch"]["frac_fp32_peak"],
-        bold(sci(b["FFT/s"]), n == "1024"), b["frac_fp32_peak"], r2[n][1], b["saturating_batch"]["frac_fp32_peak"]))
+    print("| %s | %s | %.3f (%s) | %.3f | %.3f | %s | %.3f (%s) | %.3f |" % (
+        n, sci(b["FFT/s"]), b["frac_fp32_peak"], r3[n][1], b["one_chain_per_workgroup_oldest_first"]["frac_fp32_peak"], b["saturating_batch"]["frac_fp32_peak"],
+        sci(a["FFT/s"]), a["frac_fp32_peak"], r3[n][0], a["saturating_batch"]["frac_fp32_peak"]))
+print("\ncontract: | N | external two-argument / user kernel (reorder) | in-LDS ratio (reorder / no reorder) | in-LDS FFT/s |")
+for n in SIZES:
+    r, nr = by_len[n]["reorder"], by_len[n]["noreorder"]
+    print("| %s | %.2f / %.2f | %.2f / %.2f | %s |" % (n, r["external_ratio_to_tiled"], r["user_kernel_external_ratio_to_tiled"], r["in_lds_ratio_to_compact"], nr["in_lds_ratio_to_compact"], sci(r["in_lds_FFT/s"])))
+    if "wave64" in r:
+        w, wn = r["wave64"], nr["wave64"]
+        print("| %s _wave64 | %.2f / %.2f | %.2f / %.2f | %s |" % (n, w["external_ratio_to_tiled"], w["user_kernel_external_ratio_to_tiled"], w["in_lds_ratio_to_compact"], wn["in_lds_ratio_to_compact"], sci(w["in_lds_FFT/s"])))

@@ -26,6 +26,9 @@ ex.smfft_example_reference_shape_st.argtypes = [vp, vp, i, i, vp]
 ex.smfft_example_reference_shape_rc.argtypes = [vp, vp, i, i, i, vp]
 ex.smfft_example_reference_shape_multiple_one.argtypes = [vp, vp, i, i, vp]
 ex.smfft_example_reference_shape_ct_multiple.argtypes = [vp, vp, i, i, i, vp]
+has_wave64 = hasattr(ex, "smfft_example_reference_shape_ct_multiple_wave64")
+if has_wave64:
+    ex.smfft_example_reference_shape_ct_multiple_wave64.argtypes = [vp, vp, i, i, i, vp]
 
 TOTAL = 1 << 29
 nbytes = TOTAL * 8
@@ -81,6 +84,12 @@ for n in [int(v) for v in args.sizes.split(",")]:
         lib = lib_ms(lambda t: sm.lib.smfft_ct_multiple_benchmark(a, b, n, nffts, 0, reo, t))
         done = blocks * per_block * 100
         print(f"in-LDS N={n} reorder={reo}: reference contract {ref:.3f} ms {done / ref * 1e3:.3e} FFT/s | compact {lib:.3f} ms | ratio {lib / ref:.2f}", flush=True)
+        if n <= 128 and has_wave64:       # the wave64-full classes: 64-thread blocks of 256 elements
+            per64 = 256 // n
+            blocks64 = (nffts // 100) // per64
+            ref64 = timed(lambda: ex.smfft_example_reference_shape_ct_multiple_wave64(a, b, n, blocks64, reo, None), reps=15, warm=25)
+            done64 = blocks64 * per64 * 100
+            print(f"in-LDS N={n} reorder={reo} _wave64: reference contract {ref64:.3f} ms {done64 / ref64 * 1e3:.3e} FFT/s | ratio to compact {lib * done64 / done / ref64:.2f}", flush=True)
     if args.in_lds_only:
         continue
     for reo in (1, 0):
@@ -88,6 +97,10 @@ for n in [int(v) for v in args.sizes.split(",")]:
         usr = timed(lambda: ex.smfft_example_reference_shape_ct(a, b, n, nffts, 0, reo, 0, None))
         lib = lib_ms(lambda t: sm.lib.smfft_ct_external_benchmark(a, b, n, nffts, 0, reo, t))
         print(f"external N={n} reorder={reo}: two-argument kernel {ref:.3f} ms {gb / ref:.2f} TB/s | user kernel (fill / call / drain) {usr:.3f} ms | tiled {lib:.3f} ms {gb / lib:.2f} TB/s | ratios {lib / ref:.2f} {lib / usr:.2f}", flush=True)
+        if n <= 128 and has_wave64:
+            ref64 = timed(lambda: ex.smfft_example_reference_shape_ct(a, b, n, nffts, 0, reo, 3, None))
+            usr64 = timed(lambda: ex.smfft_example_reference_shape_ct(a, b, n, nffts, 0, reo, 2, None))
+            print(f"external N={n} reorder={reo} _wave64: two-argument kernel {ref64:.3f} ms | user kernel {usr64:.3f} ms | ratios {lib / ref64:.2f} {lib / usr64:.2f}", flush=True)
     if n >= 256:
         ref = timed(lambda: ex.smfft_example_reference_shape_st(a, b, n, nffts, None))
         lib = lib_ms(lambda t: sm.lib.smfft_st_external_benchmark(a, b, n, nffts, t))
