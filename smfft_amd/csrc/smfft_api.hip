@@ -462,8 +462,9 @@ int smfft_get_multiple_balance(void) { read_env(); return cur_balance(); }
 void smfft_set_multiple_rotation(int log2_clocks) { t_state.rotate = log2_clocks < 0 ? -1 : log2_clocks; }
 int smfft_get_multiple_rotation(void) { read_env(); return cur_rotate(); }
 // The most workgroups of the multiple kernel (family, FFT_size, inverse, reorder, path = 1 or 2) that are alive at once on the
-// current device, COUNTED: a launch of three times what the scheduler assumes fits, 20 applications each, over scratch buffers,
-// with every workgroup incrementing a counter when it starts and decrementing it when it ends.  *assumed = the scheduler's figure.
+// current device, COUNTED: a launch of three times what any kernel's residency can be, 60 applications each, over scratch buffers,
+// with every workgroup incrementing a counter when it starts and decrementing it when it ends (workgroups of such a launch end and
+// start all the time, so the count stays a few percent under what fits).  *assumed = the scheduler's figure.
 int smfft_measure_multiple_residency(int family, int FFT_size, int inverse, int reorder, int path, int* assumed) {
     read_env();
     const int tile = FFT_size < 1024 ? 1024 : FFT_size;
@@ -480,7 +481,7 @@ int smfft_measure_multiple_residency(int family, int FFT_size, int inverse, int 
     (void)hipMemset(in, 0, bytes);
     const smfft::LaunchState saved = t_state;
     t_state.balance = 0;
-    t_state.nreuses = 20;
+    t_state.nreuses = 60;
     t_state.grid_cap = 0;
     smfft::t_residency_probe = counters;
     const int count = chains * (tile / FFT_size);

@@ -1,9 +1,10 @@
+// smfft_inst.hip -- instantiates every kernel of ONE transform length; compiled once per length
+// with -DSMFFT_N=<32..4096> (see Makefile).
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
-// smfft_inst.hip -- instantiates every kernel of ONE transform length; compiled once per length
-// with -DSMFFT_N=<32..4096> (see Makefile).
+
 #include "smfft_kernels.hpp"
 #include "smfft_launch.hpp"
 
@@ -58,7 +59,7 @@ static int launch_compact(CompactKernel kernel, const float2* d_input, float2* d
     sch.residency = residency_probe();
     if (sch.residency) note_resident_workgroups(resident_workgroups((const void*)kernel, threads));          // non-null only inside smfft_measure_multiple_residency
     static const bool debug = getenv("SMFFT_SCHEDULE_DEBUG") != nullptr;
-    if (debug) printf("smfft multiple N=%d: %d chains x %d applications, %d co-resident workgroups (occupancy query), grid %d, %d applications per workgroup%s\n", SMFFT_N, ntiles, nreuses,
+    if (debug) printf("smfft multiple N=%d: %d chains x %d applications, %d co-resident workgroups (from the kernel's registers and LDS), grid %d, %d applications per workgroup%s\n", SMFFT_N, ntiles, nreuses,
                       resident_workgroups((const void*)kernel, threads), grid, sch.per_wg, sch.per_wg ? "" : " (one chain at a time)");
     static const char* trace_file = getenv("SMFFT_SCHEDULE_TRACE");          // experiments: one line per workgroup of the LAST launch
     if (trace_file && hipMalloc((void**)&sch.trace, (size_t)grid * 32) != hipSuccess) sch.trace = nullptr;

@@ -249,7 +249,7 @@ def test_multiple_schedule_knows_how_many_workgroups_fit(sm, family, n, inv, reo
     counted = sm.lib.smfft_measure_multiple_residency(family, n, inv, reo, path, ctypes.byref(assumed))
     assert counted > 0 and assumed.value > 0
     assert counted <= assumed.value, (counted, assumed.value)
-    assert counted >= 0.93 * assumed.value, (counted, assumed.value)      # (workgroups of the calibration launch end and start all the time)
+    assert counted >= 0.88 * assumed.value, (counted, assumed.value)      # (workgroups of the calibration launch end and start all the time: 0.93-1.0 seen)
 
 
 @pytest.mark.parametrize("n", [64, 1024, 4096])
