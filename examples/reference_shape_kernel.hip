@@ -229,6 +229,43 @@ __global__ void user_fft_twice_kernel(float2* d_input, float2* d_output) {
     }
     for (int k = 0; k < 4; k++) d_output[offset + threadIdx.x + k * const_params::fft_length_quarter] = s_data[threadIdx.x + k * const_params::fft_length_quarter];
 }
+// the same with a RUN-TIME number of applications (a loop the compiler cannot unroll: whatever the device function does to the
+// wave's scalar state -- its inline assembly writes VCC and SCC -- must leave the loop's own control intact)
+template <class const_params>
+__global__ void user_fft_times_kernel(float2* d_input, float2* d_output, int times) {
+    __shared__ float2 s_data[const_params::fft_sm_required];
+    const int offset = blockIdx.x * const_params::fft_length;
+    for (int k = 0; k < 4; k++) s_data[threadIdx.x + k * const_params::fft_length_quarter] = d_input[offset + threadIdx.x + k * const_params::fft_length_quarter];
+    __syncthreads();
+    for (int f = 0; f < times; f++) {
+        do_SMFFT_CT_DIT<const_params>(s_data);
+        __syncthreads();
+    }
+    for (int k = 0; k < 4; k++) d_output[offset + threadIdx.x + k * const_params::fft_length_quarter] = s_data[threadIdx.x + k * const_params::fft_length_quarter];
+}
+template <class P>
+static int launch_ct_times(float2* in, float2* out, int nFFTs, int times, hipStream_t st) {
+    user_fft_times_kernel<P><<<dim3(nFFTs / (P::fft_length / P::fft_size)), dim3(P::fft_length / 4), 0, st>>>(in, out, times);
+    return (int)hipGetLastError();
+}
+#define CTT_CASE(N) case N: return reorder ? launch_ct_times<FFT_##N##_forward>(in, out, nFFTs, times, st) : launch_ct_times<FFT_##N##_forward_noreorder>(in, out, nFFTs, times, st);
+#define CTT64_CASE(N) case N: return reorder ? launch_ct_times<FFT_##N##_forward_wave64>(in, out, nFFTs, times, st) : launch_ct_times<FFT_##N##_forward_noreorder_wave64>(in, out, nFFTs, times, st);
+// wave64 != 0: the 64-thread classes of N <= 128 (nFFTs a multiple of 256 / N)
+extern "C" int smfft_example_reference_shape_ct_times(void* d_in, void* d_out, int FFT_size, int nFFTs, int reorder, int times, int wave64, void* stream) {
+    float2 *in = (float2*)d_in, *out = (float2*)d_out;
+    hipStream_t st = (hipStream_t)stream;
+    if (wave64 && FFT_size <= 128) {
+        switch (FFT_size) {
+            CTT64_CASE(32) CTT64_CASE(64) CTT64_CASE(128)
+            default: return -1;
+        }
+    }
+    switch (FFT_size) {
+        CTT_CASE(32) CTT_CASE(64) CTT_CASE(128) CTT_CASE(256) CTT_CASE(512) CTT_CASE(1024) CTT_CASE(2048) CTT_CASE(4096)
+        default: return -1;
+    }
+}
+
 template <class P>
 static int launch_ct_twice(float2* in, float2* out, int nFFTs, hipStream_t st) {
     user_fft_twice_kernel<P><<<dim3(nFFTs / (P::fft_length / P::fft_size)), dim3(P::fft_length / 4), 0, st>>>(in, out);

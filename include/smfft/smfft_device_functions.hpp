@@ -166,8 +166,8 @@ __host__ __device__ constexpr int quarter_swizzle(int i) {
 // N <= 256 (round 4): the same radix-2^2 ladder with NO LDS between its passes.  The N/4 threads of a transform are 8 ... 64
 // lanes of one wave, so the exchange between two passes -- the four elements a thread holds swap their two slot bits with the
 // two lane bits that hold the next two index bits -- is a pair of one-bit lane <-> register transposes: v_permlane32_swap /
-// v_permlane16_swap for lane bits 5 / 4 (one instruction per dword pair), two row-DPP moves per dword pair for bits 3 / 2, a
-// quad-perm move and three selects for bits 1 / 0 (the primitives of smfft_engine.hpp).  N = 256: 56 such instructions per
+// v_permlane16_swap for lane bits 5 / 4 (one instruction per dword pair), two row-DPP moves per dword pair for bits 3 / 2, two
+// DPP-fed selects per dword pair for bits 1 / 0 (the primitives of smfft_engine.hpp).  N = 256: 40 such instructions per
 // thread replace three LDS round trips of the whole transform (12 ds_write_b64 + 12 ds_read_b64 per thread); the contract's
 // first read and last write of s[] remain.  Index bookkeeping (checked by a NumPy model of the lanes and slots against numpy.fft,
 // tools/quarter_lanes_model.py, and by the GPU parity tests of every contract kernel):
@@ -177,20 +177,23 @@ __host__ __device__ constexpr int quarter_swizzle(int i) {
 //         below), then the butterfly of quarter_fft with k = base mod P, base = rev(t) (natural order) or t (no reorder)
 //   odd log2 N: slot bit 0 <-> the last lane bit, two radix-2 butterflies with W_N^base and -+i W_N^base
 //   out:  slot i holds result element base + (N/4) * sigma(i), sigma = identity (even log2 N) or (0, 2, 1, 3) (odd)
-// Measured (profiles/r04_contract_lanes.txt; in-LDS loop of 100 calls, README batch): N = 32 +40...+60 %, N = 128 +9...+13 %,
-// N = 64 -7...+4 %, N = 256 -1...-3.5 % against the LDS form -- the quad-perm transposes of lane bits 0 / 1 cost 32 of a
-// thread's 56 exchange instructions.  So do_SMFFT_CT_DIT uses the lane form for N = 32 and 128 and the LDS form otherwise.
-// Around an HBM-bound fill / call / drain the two are within 6 % of each other (the lane form ahead in upstream's 32-thread
-// blocks, behind in 64-thread blocks), which is why the two-argument external kernels below choose per shape.
+// Measured (profiles/r04_contract_lanes.txt; in-LDS loop of 100 calls, README batch, against the LDS form): with the quad
+// transposes as two DPP-fed selects per dword pair (smfft_engine.hpp, swap_bit_quad) N = 32 +83...+99 %, N = 64 +21...+26 %, N = 128
+// +30...+32 %, N = 256 +2...+9 % (with hipcc's own v_mov_b32_dpp + v_cndmask pairs: +40...60 / -7...+4 / +9...13 / -1...-3.5 %),
+// so do_SMFFT_CT_DIT uses the lane form for every N <= 256.  Around an HBM-bound fill / call / drain the two forms are within a
+// few percent of each other (the lane form ahead in upstream's 32-thread blocks, behind in 64-thread blocks), which is why the
+// two-argument external kernels below choose per shape.
 #ifndef SMFFT_QUARTER_LANES
-#define SMFFT_QUARTER_LANES 1          // 0: every length through LDS (A/B); 2: the lane form for every N <= 256
+#define SMFFT_QUARTER_LANES 1          // 0: every length through LDS (A/B)
 #endif
-constexpr bool quarter_lanes_default(int n) { return SMFFT_QUARTER_LANES == 2 ? n <= 256 : SMFFT_QUARTER_LANES == 1 ? (n == 32 || n == 128) : false; }
+constexpr bool quarter_lanes_default(int n) { return SMFFT_QUARTER_LANES != 0 && n <= 256; }
 template <int LANE_BIT>
 __device__ __forceinline__ void lane_slot_swap(float2& A, float2& B, int lane) {
     using X = Engine<1024, 0, 1>;                // (the transposes are static members; the length is immaterial)
     if constexpr (LANE_BIT >= 4) {
         X::template swap_bit<LANE_BIT>(A, B);
+    } else if constexpr (LANE_BIT <= 1) {
+        X::template swap_bit_quad<LANE_BIT>(A, B, (lane >> LANE_BIT) & 1);
     } else {
         const bool hi = (lane >> LANE_BIT) & 1;
         X::template swap_bit_dpp_dword<LANE_BIT>(A.x, B.x, hi);
@@ -534,7 +537,8 @@ __device__ void do_FFT_Stockham_R2C_C2R(float2* s_input) {
 #endif
 template <class const_params>
 __global__ void SMFFT_DIT_external(float2* d_input, float2* d_output) {
-    if constexpr (SMFFT_CONTRACT_FUSED_IO && SMFFT_QUARTER_LANES && SMFFT_CONTRACT_LANES_IO && const_params::fft_size <= 128 && const_params::fft_length_quarter == 32) {
+    if constexpr (SMFFT_CONTRACT_FUSED_IO && SMFFT_QUARTER_LANES != 0 &&
+                  ((SMFFT_CONTRACT_LANES_IO == 1 && const_params::fft_size <= 128 && const_params::fft_length_quarter == 32) || (SMFFT_CONTRACT_LANES_IO == 2 && const_params::fft_size <= 256))) {
         constexpr int N = const_params::fft_size, Q = N / 4;
         using L = smfft::QuarterLanes<N, const_params::fft_direction, const_params::fft_reorder>;
         const int t = threadIdx.x % Q;
@@ -572,9 +576,12 @@ __global__ void SMFFT_DIT_external(float2* d_input, float2* d_output) {
     s_input[threadIdx.x + const_params::fft_length_half] = d_input[base + const_params::fft_length_half];
     s_input[threadIdx.x + const_params::fft_length_three_quarters] = d_input[base + const_params::fft_length_three_quarters];
     __syncthreads();
-    if constexpr (const_params::fft_size <= 128) {       // (the LDS form of the ladder whatever do_SMFFT_CT_DIT's default is: see above)
+#ifndef SMFFT_CONTRACT_WAVE64_EXTERNAL_ENGINE
+#define SMFFT_CONTRACT_WAVE64_EXTERNAL_ENGINE 1      // 1: the LDS form of the ladder between fill and drain (N <= 128); 0: do_SMFFT_CT_DIT's default
+#endif
+    if constexpr (const_params::fft_size <= 128 && SMFFT_CONTRACT_WAVE64_EXTERNAL_ENGINE != 0) {
         constexpr int N = const_params::fft_size;
-        smfft::quarter_fft_inplace<N, const_params::fft_direction, const_params::fft_reorder, const_params::fft_length / 4, 1>(s_input, threadIdx.x % (N / 4), (threadIdx.x / (N / 4)) * N);
+        smfft::quarter_fft_inplace<N, const_params::fft_direction, const_params::fft_reorder, const_params::fft_length / 4, SMFFT_CONTRACT_WAVE64_EXTERNAL_ENGINE>(s_input, threadIdx.x % (N / 4), (threadIdx.x / (N / 4)) * N);
     } else {
         do_SMFFT_CT_DIT<const_params>(s_input);
     }

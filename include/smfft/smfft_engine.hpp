@@ -613,6 +613,45 @@ struct Engine {
         A = __int_as_float(na);
         B = __int_as_float(nb);
     }
+    // The same transpose for lane bits 0 / 1 on a float2 pair in FOUR instructions instead of eight: v_cndmask_b32 takes its first
+    // source through DPP, so "keep mine or take the partner's" is one instruction per dword and side -- hipcc does not fold the
+    // quad-perm move into the select (it emits v_mov_b32_dpp + v_cndmask_b32), hence the inline assembly.  The lane masks are
+    // constants because every transform's lanes start at a multiple of their count.  s_nop 1: the two wait states a DPP read
+    // needs after a VALU write of the same register (the assembler does not see into the block).
+#ifndef SMFFT_QUAD_SWAP_ASM
+#define SMFFT_QUAD_SWAP_ASM 1
+#endif
+    template <int LANE_BIT>
+    __device__ static __forceinline__ void swap_bit_quad(float2& A, float2& B, bool hi) {
+        static_assert(LANE_BIT == 0 || LANE_BIT == 1, "inside a quad");
+#if SMFFT_QUAD_SWAP_ASM
+        constexpr unsigned long long lo = LANE_BIT == 0 ? 0x5555555555555555ull : 0x3333333333333333ull;   // lanes with the bit clear
+        float nax, nay, nbx, nby;
+        if constexpr (LANE_BIT == 0) {
+            asm volatile("s_nop 1\n\ts_mov_b64 vcc, %8\n\t"
+                         "v_cndmask_b32_dpp %0, %6, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_cndmask_b32_dpp %1, %7, %5, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "s_not_b64 vcc, vcc\n\t"
+                         "v_cndmask_b32_dpp %2, %4, %6, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_cndmask_b32_dpp %3, %5, %7, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                         : "=&v"(nax), "=&v"(nay), "=&v"(nbx), "=&v"(nby) : "v"(A.x), "v"(A.y), "v"(B.x), "v"(B.y), "s"(lo) : "vcc", "scc");      // (s_not_b64 writes SCC)
+        } else {
+            asm volatile("s_nop 1\n\ts_mov_b64 vcc, %8\n\t"
+                         "v_cndmask_b32_dpp %0, %6, %4, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_cndmask_b32_dpp %1, %7, %5, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                         "s_not_b64 vcc, vcc\n\t"
+                         "v_cndmask_b32_dpp %2, %4, %6, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_cndmask_b32_dpp %3, %5, %7, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                         : "=&v"(nax), "=&v"(nay), "=&v"(nbx), "=&v"(nby) : "v"(A.x), "v"(A.y), "v"(B.x), "v"(B.y), "s"(lo) : "vcc", "scc");      // (s_not_b64 writes SCC)
+        }
+        A = make_float2(nax, nay);     // lanes with the bit clear keep A; the others take the partner's B
+        B = make_float2(nbx, nby);     // lanes with the bit set keep B; the others take the partner's A
+        (void)hi;
+#else
+        swap_bit_dpp_dword<LANE_BIT>(A.x, B.x, hi);
+        swap_bit_dpp_dword<LANE_BIT>(A.y, B.y, hi);
+#endif
+    }
     // all 8 register pairs (c, c | 1 << reg_bit), c with that bit clear
     __device__ __forceinline__ void swap_lane_bit_with_register_bit(float2 (&r)[16], int lane_bit, int reg_bit) const {
         const bool hi = (u >> lane_bit) & 1;
@@ -622,8 +661,8 @@ struct Engine {
             float2& A = r[c];
             float2& B = r[c | (1 << reg_bit)];
             switch (lane_bit + kLaneShift) {
-                case 0: swap_bit_dpp_dword<0>(A.x, B.x, hi); swap_bit_dpp_dword<0>(A.y, B.y, hi); break;
-                case 1: swap_bit_dpp_dword<1>(A.x, B.x, hi); swap_bit_dpp_dword<1>(A.y, B.y, hi); break;
+                case 0: swap_bit_quad<0>(A, B, hi); break;
+                case 1: swap_bit_quad<1>(A, B, hi); break;
                 case 2: swap_bit_dpp_dword<2>(A.x, B.x, hi); swap_bit_dpp_dword<2>(A.y, B.y, hi); break;
                 default: swap_bit_dpp_dword<3>(A.x, B.x, hi); swap_bit_dpp_dword<3>(A.y, B.y, hi); break;
             }

@@ -571,6 +571,36 @@ def test_reference_shaped_back_to_back_calls(sm, n, reo):
     assert l2 < 5e-7 and mx < 1.5e-6, (n, reo, l2, mx)
 
 
+@pytest.mark.parametrize("n,wave64", [(n, 0) for n in C2C_SIZES] + [(n, 1) for n in (32, 64, 128)])
+def test_device_function_in_a_runtime_loop(sm, oracle_lib, n, wave64):
+    """do_SMFFT_CT_DIT<P>(s) called in a loop whose trip count is a kernel argument (the `multiple` kernels' pattern with a count
+    the compiler cannot unroll): four natural-order applications are N^2 * identity, three no-reorder applications are three
+    applications of the oracle.  Guards the wave's SCALAR state across the device function -- its lane transposes are inline
+    assembly that writes VCC and SCC; an undeclared SCC clobber once ended such a loop after its first iteration and only a
+    timing gave it away (round 4)."""
+    import ctypes
+    ex = _examples(sm)
+    fn = ex.smfft_example_reference_shape_ct_times
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    nffts = 3 * max(1, 256 // n) * 2
+    rng = np.random.default_rng(7000 + n + wave64)
+    x = ((rng.random((nffts, n), dtype=np.float32) - 0.5) + 1j * (rng.random((nffts, n), dtype=np.float32) - 0.5)).astype(np.complex64)
+    dx, dy = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
+    assert fn(dx.ptr, dy.ptr, n, nffts, 1, 4, wave64, None) == 0 and sm.lib.smfft_synchronize() == 0
+    got = dy.to_host(np.complex64, x.shape)
+    l2, mx = ref.fft_errors(got / np.float32(n) ** 2, x.astype(np.complex128))
+    assert l2 < 1e-6 and mx < 2e-6, (n, l2, mx)
+    assert fn(dx.ptr, dy.ptr, n, nffts, 0, 3, wave64, None) == 0 and sm.lib.smfft_synchronize() == 0
+    got = dy.to_host(np.complex64, x.shape)
+    want = x.astype(np.complex128)
+    for _ in range(3):
+        want = oa.ct_c2c(oracle_lib, want, 0, 0, "f64")
+    l2, mx = ref.fft_errors(got, want)
+    assert l2 < 5e-7 * 3 ** 0.5 and mx < 1e-6 * 3 ** 0.5, (n, l2, mx)
+    dx.free()
+    dy.free()
+
+
 @pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096])
 def test_reference_shaped_stockham_kernel(sm, oracle_lib, n):
     """FFT_GPU_external<FFT_N><<<nFFTs, N/4, N*8>>>(in, out) calling do_FFT_Stockham_mk6 on exactly N float2 of dynamic
