@@ -309,6 +309,22 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
     constexpr int kLastQuad = R::kOdd ? -1 : R::kPasses - 1;    // the pass whose results leave in natural order (none: the radix-2 pass is last)
     float2* sf = s + region_offset;
     float2 e[4];
+    // N >= 512, no reorder: the first FOUR passes (index bits 0 ... 7) never leave the wave -- thread t = lane + 64 w starts with
+    // elements 4 t + i, i.e. its wave owns the aligned block of 256 elements number w -- so they run on lanes and registers as
+    // a 256-point ladder (QuarterLanes<256>: same twiddles W_4P^k, k = lane mod P); its results, elements 256 w + lane + 64 i, go
+    // to the swizzled image, and only the passes that cross waves (P >= 256 and the radix-2 pass) run through LDS:
+    // 2 LDS round trips instead of 5 at N = 512 / 1024, 3 instead of 6 at N = 2048 / 4096 (whose eight barriers become three).
+    constexpr bool kLanesHead = (ENGINE == 2 || (ENGINE == 0 && SMFFT_QUARTER_LANES != 0)) && !REORDER && N >= 512;
+    constexpr int kFirstLdsPass = kLanesHead ? 4 : 1;
+    if constexpr (kLanesHead) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = IN_REGS ? x[i] : sf[4 * t + i];
+        QuarterLanes<256, DIR, 0>::run(e, t & 63, t & 63);
+        if constexpr (!IN_REGS) fft_sync<false>();            // the wave's own loads precede its stores into the same 256 elements
+        const int j0 = region_offset + (t & ~63) * 4 + (t & 63);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[quarter_swizzle(j0 + 64 * i)] = e[i];
+    } else {
     // ---- pass 0 (P = 1): twiddles 1, 1, -+i -----------------------------------------------------------------------
     int a;
     if constexpr (REORDER) {
@@ -332,11 +348,12 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
             s[a0] = cadd(s0, s1), s[a0 ^ 2] = csub(s0, s1), s[a0 ^ 1] = cadd(d0, jd1), s[a0 ^ 3] = csub(d0, jd1);
         }
     }
+    }
     // ---- passes 1 .. (P = 4, 16, ...) -----------------------------------------------------------------------------
-    if constexpr (R::kPasses > 1) {
-        int P = 4;
+    if constexpr (R::kPasses > kFirstLdsPass) {
+        int P = 1 << (2 * kFirstLdsPass);
 #pragma unroll
-        for (int p = 1; p < R::kPasses; ++p, P *= 4) {
+        for (int p = kFirstLdsPass; p < R::kPasses; ++p, P *= 4) {
             if (P > 64 || (REORDER && p == 1) || !kWaveLocal) fft_sync<kBarrier>();
             else fft_sync<false>();
             const int k = t & (P - 1);
