@@ -461,6 +461,61 @@ struct PlanarEngine {
             r[16 - q] = combine(16 - q, A2, B2);
         }
     }
+
+    // ---- the same split / merge PAIR-WISE (round 4) ------------------------------------------------------------------
+    // out[i] = S/2 + V*D and out[L - i] = conj(S - out[i]) come from ONE S, D and V: 16 instructions per pair instead of 28.
+    // A thread takes the pairs of its registers q = 0..7 (i = klow + T*q); the partner x[L - i] is register 15 - q of the
+    // thread with role T - klow, so the registers 8..15 of every thread are somebody else's second halves:
+    //   precondition  rows 8..15 of the image hold every thread's registers 8..15 (image_store_upper, or the loaded tile);
+    //   1  fetch the eight partners (row 15 - q at the partner's dword), combine: r[q] = out[i]; other[q] = out[L - i];
+    //   2  store other[15 - j] lane-linearly into row j (j = 8..15), sync, read row j back at the PARTNER's dword into r[j].
+    // Role 0 is its own partner: its register q pairs with its OWN register 16 - q (q = 1..7), register 0 packs DC and
+    // Nyquist and register 8 (i = L/2, its own partner) becomes its conjugate -- so that thread takes B from its registers
+    // and stores row j <- other[16 - j] (row 8 <- conj(r[8])): thirty-two selects, no second address.
+    // LDS traffic per application: 16 + 16 dword stores, 16 + 16 dword reads -- what image_store + hermitian_apply move.
+    __device__ __forceinline__ void image_store_upper(const float2 (&r)[16]) const {
+        addtid_store4<P::image_row(8), P::image_row(9), P::image_row(10), P::image_row(11), P::kPlane>(m0, r[8], r[9], r[10], r[11]);
+        addtid_store4<P::image_row(12), P::image_row(13), P::image_row(14), P::image_row(15), P::kPlane>(m0, r[12], r[13], r[14], r[15]);
+    }
+    __device__ __forceinline__ void hermitian_apply_pairs(float2 (&r)[16], const float* planes) const {
+        constexpr float c32[8] = {1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f, 0.55557023301960229f,
+                                  0.38268343236508984f, 0.19509032201612833f};
+        constexpr float s32[8] = {0.f, 0.19509032201612825f, 0.38268343236508978f, 0.55557023301960218f, 0.70710678118654746f, 0.83146961230254524f,
+                                  0.92387953251128674f, 0.98078528040323043f};
+        const float* p = planes + off_partner;
+        float2 w = herm_w;
+        asm volatile("" : "+v"(w.x), "+v"(w.y));     // the seven products W_2L^i are recomputed per application
+        float2 other[8];
+        const float2 r8 = r[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if ((q & 1) == 0) asm volatile("" ::: "memory");   // two partners in flight at a time (occupancy: see hermitian_apply)
+            const float2 fetched = make_float2(p[P::image_row(15 - q)], p[P::kPlane + P::image_row(15 - q)]);
+            const float2 own = q == 0 ? r8 : r[16 - q];
+            const float2 A = r[q], B = herm_first ? own : fetched;
+            const float2 S = make_float2(A.x + B.x, A.y - B.y);
+            const float2 D = make_float2(A.x - B.x, A.y + B.y);
+            const float2 V = (q == 0) ? w : cmul(w, make_float2(c32[q], DIR ? s32[q] : -s32[q]));
+            const float2 out = make_float2(fmaf(V.x, D.x, fmaf(-V.y, D.y, 0.5f * S.x)), fmaf(V.x, D.y, fmaf(V.y, D.x, 0.5f * S.y)));
+            other[q] = make_float2(S.x - out.x, out.y - S.y);          // conj(S - out)
+            if (q == 0) {
+                const float2 packed = DIR ? make_float2(0.5f * (A.x + A.y), 0.5f * (A.x - A.y)) : make_float2(A.x + A.y, A.x - A.y);
+                r[0] = herm_first ? packed : out;
+                other[0] = herm_first ? make_float2(r8.x, -r8.y) : other[0];
+            } else {
+                r[q] = out;
+            }
+        }
+        planar_sync<G::kMultiWave>();                // every partner is fetched before the rows are written over
+        float2 st[8];
+#pragma unroll
+        for (int j = 8; j < 16; ++j) st[j - 8] = herm_first ? other[j == 8 ? 0 : 16 - j] : other[15 - j];
+        addtid_store4<P::image_row(8), P::image_row(9), P::image_row(10), P::image_row(11), P::kPlane>(m0, st[0], st[1], st[2], st[3]);
+        addtid_store4<P::image_row(12), P::image_row(13), P::image_row(14), P::image_row(15), P::kPlane>(m0, st[4], st[5], st[6], st[7]);
+        planar_sync<G::kMultiWave>();
+#pragma unroll
+        for (int j = 8; j < 16; ++j) r[j] = make_float2(p[P::image_row(j)], p[P::kPlane + P::image_row(j)]);
+    }
 };
 
 // ------------------------------------------------------------------------------------------------

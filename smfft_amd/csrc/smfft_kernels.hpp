@@ -722,6 +722,11 @@ __device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__
 // R2C / C2R in-LDS path on the planar engine: the complex transform of length L as in c2c_multiple_body_planar (reorder
 // roles, registers forwarded from one application to the next) with the Hermitian split / merge done on the registers,
 // the partners read from the stored image.  Per application: the C2C's LDS traffic + 32 dword reads.
+#ifndef SMFFT_RC_PAIRS
+#define SMFFT_RC_PAIRS 0xf       // bit 0..3: complex length L = 256, 512, 1024, 2048 splits / merges pair-wise
+#endif
+template <int L>
+static constexpr bool kRcPairs = ((SMFFT_RC_PAIRS >> (ilog2c(L) - 8)) & 1) != 0;
 template <int L, int DIR>
 __device__ __forceinline__ void r2c_c2r_multiple_body_planar(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, MultipleSchedule sch, float* planes) {
     using G = Geometry<L>;
@@ -742,6 +747,26 @@ __device__ __forceinline__ void r2c_c2r_multiple_body_planar(const float2* __res
         planar_sync<G::kMultiWave>();
         float2 r[16];
         eng.image_load_own(r, planes);
+        if constexpr (kRcPairs<L>) {
+            // pair-wise split / merge (PlanarEngine::hermitian_apply_pairs): only the rows 8..15 go through the image
+            // (R2C: the split of application f runs at the head of iteration f + 1 and once more after the loop -- the loop is
+            //  then shaped like the C2R's, split / merge in front of the transform, which the compiler keeps at four waves per SIMD)
+            for (int f = 0; f < napps; ++f) {
+                priority.at_application(app0 + f);
+                if (DIR == 1 || f > 0) eng.hermitian_apply_pairs(r, planes);   // rows 8..15: the tile (C2R), or stored below
+                eng.natural_to_slots(r);
+                eng.transform_from_pass1_slots(r, planes);
+                planar_sync<G::kMultiWave>();
+                if (DIR == 0 || f + 1 < napps) {
+                    eng.image_store_upper(r);
+                    planar_sync<G::kMultiWave>();
+                }
+            }
+            if (DIR == 0) eng.hermitian_apply_pairs(r, planes);
+            planar_sync<G::kMultiWave>();
+            eng.image_store(r);
+            planar_sync<G::kMultiWave>();
+        } else {
         for (int f = 0; f < napps; ++f) {
             priority.at_application(app0 + f);
             if (DIR == 1) {                          // C2R: merge (partners from the image: the tile, or the previous result), then the inverse transform
@@ -761,6 +786,7 @@ __device__ __forceinline__ void r2c_c2r_multiple_body_planar(const float2* __res
         if (DIR == 0) {                              // the image holds the last transform's output: replace it by the split result
             eng.image_store(r);
             planar_sync<G::kMultiWave>();
+        }
         }
         planes_to_tile<L, DIR, 1>(d_output + first * L, planes, first, nSlots);
         if (app1 < nreuses) chain_signal_parked(sch.flags + tile, sch.epoch);
