@@ -721,7 +721,7 @@ __device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__
 
 // R2C / C2R in-LDS path on the planar engine: the complex transform of length L as in c2c_multiple_body_planar (reorder
 // roles, registers forwarded from one application to the next) with the Hermitian split / merge done on the registers,
-// the partners read from the stored image.  Per application: the C2C's LDS traffic + 32 dword reads.
+// pair-wise (PlanarEngine::hermitian_apply_pairs).  Per application: the C2C's LDS traffic + 32 dword stores + 32 dword reads.
 #ifndef SMFFT_RC_PAIRS
 #define SMFFT_RC_PAIRS 0xf       // bit 0..3: complex length L = 256, 512, 1024, 2048 splits / merges pair-wise
 #endif
@@ -767,26 +767,26 @@ __device__ __forceinline__ void r2c_c2r_multiple_body_planar(const float2* __res
             eng.image_store(r);
             planar_sync<G::kMultiWave>();
         } else {
-        for (int f = 0; f < napps; ++f) {
-            priority.at_application(app0 + f);
-            if (DIR == 1) {                          // C2R: merge (partners from the image: the tile, or the previous result), then the inverse transform
-                eng.hermitian_apply(r, planes);
-                planar_sync<G::kMultiWave>();        // every partner read precedes the exchanges' stores
+            for (int f = 0; f < napps; ++f) {
+                priority.at_application(app0 + f);
+                if (DIR == 1) {                          // C2R: merge (partners from the image: the tile, or the previous result), then the inverse transform
+                    eng.hermitian_apply(r, planes);
+                    planar_sync<G::kMultiWave>();        // every partner read precedes the exchanges' stores
+                }
+                eng.natural_to_slots(r);
+                eng.transform_from_pass1_slots(r, planes);
+                planar_sync<G::kMultiWave>();
+                eng.image_store(r);
+                planar_sync<G::kMultiWave>();
+                if (DIR == 0) {                          // R2C: the forward transform's result is in the image; split it in registers
+                    eng.hermitian_apply(r, planes);
+                    planar_sync<G::kMultiWave>();
+                }
             }
-            eng.natural_to_slots(r);
-            eng.transform_from_pass1_slots(r, planes);
-            planar_sync<G::kMultiWave>();
-            eng.image_store(r);
-            planar_sync<G::kMultiWave>();
-            if (DIR == 0) {                          // R2C: the forward transform's result is in the image; split it in registers
-                eng.hermitian_apply(r, planes);
+            if (DIR == 0) {                              // the image holds the last transform's output: replace it by the split result
+                eng.image_store(r);
                 planar_sync<G::kMultiWave>();
             }
-        }
-        if (DIR == 0) {                              // the image holds the last transform's output: replace it by the split result
-            eng.image_store(r);
-            planar_sync<G::kMultiWave>();
-        }
         }
         planes_to_tile<L, DIR, 1>(d_output + first * L, planes, first, nSlots);
         if (app1 < nreuses) chain_signal_parked(sch.flags + tile, sch.epoch);
