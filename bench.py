@@ -278,6 +278,9 @@ def compact_line(detail):
         "config3_frac_2048_4096": [_get(c3, k, o, "frac_fp32_peak") for k in ("2048", "4096") for o in ("reorder", "noreorder")],
         "config2_by_length_frac": _minmax([_get(c2, k, o, "frac") for k in c2 for o in ("forward", "inverse", "forward_noreorder", "inverse_noreorder")]),
         "config4_r2c_frac": _get(c4, "r2c", "frac"), "config4_c2r_frac": _get(c4, "c2r", "frac"),
+        # in-LDS R2C / C2R (real N = 512 ... 4096): time over the C2C of the same complex length, same slots (section 5.3)
+        "rc_in_lds_r2c_over_c2c": [_get(c4, k, "in_lds", "r2c_over_c2c") for k in ("512", "1024", "2048", "4096")],
+        "rc_in_lds_c2r_over_c2c": [_get(c4, k, "in_lds", "c2r_over_c2c") for k in ("512", "1024", "2048", "4096")],
         "contract_external_ratio_to_tiled": _minmax([_get(by_len, k, o, "external_ratio_to_tiled") for k in by_len for o in ("reorder", "noreorder")]),
         "contract_in_lds_ratio_to_compact": _minmax([_get(by_len, k, o, "in_lds_ratio_to_compact") for k in by_len for o in ("reorder", "noreorder")]),
         "contract_small_N_external_ratio": [_get(by_len, k, "reorder", "external_ratio_to_tiled") for k in ("32", "64", "128")],
@@ -559,6 +562,20 @@ def main():
         return sorted(ts)[len(ts) // 2]
 
     SETTLE = 40.0                       # ms of untimed in-LDS launches before the timed ones (see median_ms)
+
+    def launch_event_ms(fn, reps=7, settle_ms=SETTLE):
+        # the same for launch-only entry points (smfft_launch on `stream`): HIP events around each launch
+        def one():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            fn()
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            return e0.elapsed_time(e1)
+        spent = 0.0
+        while spent < settle_ms:
+            spent += one()
+        return sorted(one() for _ in range(reps))[reps // 2]
     # in-LDS `multiple` path on the same buffers (config 3's N=1024 point) on every rank: whole-job figure
     mult = {}
     for reo in (0, 1):
@@ -614,6 +631,20 @@ def main():
                 ms = median_ms(lambda t, inv=inv, src=src, dst=dst, rn=rn, rnffts=rnffts: sm.lib.smfft_rc_external_benchmark(src, dst, rn, rnffts, inv, t))
                 gbps = 2 * rbytes / (ms * 1e-3) / 1e9
                 row[name] = {"ms": ms, "TB/s": gbps / 1e3, "frac": gbps / HBM_PEAK_GBPS}
+            # in-LDS path (FFT_GPU_R2C_C2R_multiple, RC:367-384: 100 applications per load / store) next to the C2C of the same
+            # complex length on the same number of slots (the natural-order Stockham program's `multiple` kernel)
+            lds_ffts = min((1 << 30) // rn, nffts * n * 2 // rn)            # 4 GiB of reals: as many slots of complex length rn / 2 as config 3 has
+
+            def launch_ms(family, size, inv, rnffts=lds_ffts):
+                rc = []
+                ms = launch_event_ms(lambda: rc.append(sm.lib.smfft_launch(family, 1, pa.value, pb.value, size, rnffts, inv, 1, sh)))
+                if any(rc):
+                    raise RuntimeError(f"smfft_launch(family {family}, multiple, {size}) -> {set(rc)}")
+                return ms
+            lds = {"nFFTs": lds_ffts, "r2c_ms": launch_ms(2, rn, 0), "c2r_ms": launch_ms(2, rn, 1), "c2c_same_complex_length_ms": launch_ms(1, rn // 2, 1)}
+            lds["r2c_over_c2c"] = lds["r2c_ms"] / lds["c2c_same_complex_length_ms"] - 1.0
+            lds["c2r_over_c2c"] = lds["c2r_ms"] / lds["c2c_same_complex_length_ms"] - 1.0
+            row["in_lds"] = lds
             c4[str(rn)] = row
         c4.update({"real_N": 2048, "nFFTs": c4["2048"]["nFFTs"], "algorithmic_bytes_per_launch": c4["2048"]["algorithmic_bytes_per_launch"],
                    "r2c": c4["2048"]["r2c"], "c2r": c4["2048"]["c2r"]})      # BASELINE's config 4 itself, as in round 2's line

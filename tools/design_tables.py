@@ -40,3 +40,9 @@ for n in SIZES:
     if "wave64" in r:
         w, wn = r["wave64"], nr["wave64"]
         print("| %s _wave64 | %.2f / %.2f | %.2f / %.2f | %s |" % (n, w["external_ratio_to_tiled"], w["user_kernel_external_ratio_to_tiled"], w["in_lds_ratio_to_compact"], wn["in_lds_ratio_to_compact"], sci(w["in_lds_FFT/s"])))
+c4 = d["configs"]["config4_r2c_c2r_external"]
+if "in_lds" in c4.get("512", {}):
+    print("\nR2C / C2R in-LDS (4 GiB of reals, ms per 100 applications): | real N | R2C | C2R | C2C of the same complex length | R2C / C2R over it |")
+    for n in ("512", "1024", "2048", "4096"):
+        r = c4[n]["in_lds"]
+        print("| %s | %.3f | %.3f | %.3f | +%.0f / +%.0f %% |" % (n, r["r2c_ms"], r["c2r_ms"], r["c2c_same_complex_length_ms"], 100 * r["r2c_over_c2c"], 100 * r["c2r_over_c2c"]))
