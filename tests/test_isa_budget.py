@@ -1,0 +1,97 @@
+"""Compile-time budgets of the hot kernels, read from hipcc's own reports (CPU only: hipcc cross-compiles gfx950).  What they pin
+regresses silently otherwise: the in-LDS kernels live on four waves per SIMD (<= 128 VGPRs, no scratch in the application loop's
+kernels measured here), the external kernel on its register count, and the reference-shaped N = 4096 `multiple` loop on its number
+of workgroup barriers (DESIGN.md sections 2.4, 5.2-5.4)."""
+import os
+import re
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include")]
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+
+
+def _demangle(names):
+    out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+    return [re.sub(r"\(.*", "", o).replace("void ", "") for o in out]
+
+
+def _resources(n):
+    src = os.path.join(ROOT, "smfft_amd", "csrc", "smfft_inst.hip")
+    p = subprocess.run([HIPCC] + FLAGS + [f"-DSMFFT_N={n}", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rows, cur = [], None
+    for line in p.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = {"mangled": m.group(1)}
+            rows.append(cur)
+            continue
+        for key, pat in (("vgpr", r" VGPRs: (\d+)"), ("occ", r"Occupancy \[waves/SIMD\]: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)")):
+            m = re.search(pat, line)
+            if m and cur is not None:
+                cur[key] = int(m.group(1))
+    for r, name in zip(rows, _demangle([r["mangled"] for r in rows])):
+        r["name"] = name
+    return {r["name"]: r for r in rows}
+
+
+def _example_isa():
+    out = f"/tmp/smfft_test_isa_{os.getpid()}.s"
+    p = subprocess.run([HIPCC] + FLAGS + ["-S", "--cuda-device-only", os.path.join(ROOT, "examples", "reference_shape_kernel.hip"), "-o", out], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    text = open(out).read()
+    os.remove(out)
+    return text
+
+
+@pytest.fixture(scope="module")
+def built():
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        futs = {n: ex.submit(_resources, n) for n in (256, 1024, 2048)}
+        isa = ex.submit(_example_isa)
+        return {"res": {n: f.result() for n, f in futs.items()}, "isa": isa.result()}
+
+
+def test_in_lds_kernels_keep_four_waves_per_simd(built):
+    """the compact `multiple` kernels of the single-wave lengths and every R2C / C2R one: <= 128 VGPRs, nothing spilled"""
+    seen = 0
+    for n, res in built["res"].items():
+        for name, r in res.items():
+            single_wave_ct = n <= 1024 and name.startswith("SMFFT_DIT_multiple<") and "unfused" not in name
+            if single_wave_ct or name.startswith("FFT_GPU_R2C_C2R_multiple<"):
+                seen += 1
+                assert r["vgpr"] <= 128 and r["occ"] >= 4 and r["scratch"] == 0, (name, r)
+    assert seen >= 8 + 6, seen          # 4 CT variants x 2 lengths, 2 RC directions x 3 lengths
+
+
+def test_external_kernel_budget(built):
+    """the headline kernel (config 2): one 256-thread workgroup per 4096 elements, 34 KiB of LDS, no scratch, at least 3 waves per SIMD"""
+    r = built["res"][1024]["SMFFT_DIT_external<FFT_1024_forward>"]
+    assert r["scratch"] == 0 and r["occ"] >= 3 and r["lds"] <= 40 * 1024, r
+
+
+def _loop_barriers(isa, mangled_fragment, demangled_fragment):
+    """workgroup barriers inside the (only) loop of one kernel of the example file"""
+    m = re.search(r"^(_Z\w*%s\w*):[^\n]*\n(.*?)\n\s*s_endpgm" % mangled_fragment, isa, re.S | re.M)
+    assert m, mangled_fragment
+    name = _demangle([m.group(1)])[0]
+    assert demangled_fragment in name, name
+    body = m.group(2).split("\n")
+    head = next(i for i, l in enumerate(body) if "Loop Header" in l)
+    label = body[head].split(":")[0]
+    tail = max(i for i, l in enumerate(body) if re.search(r"s_cbranch\w+\s+%s\b" % re.escape(label), l))
+    return sum("s_barrier" in l for l in body[head:tail + 1])
+
+
+def test_reference_shaped_multiple_loop_barriers_at_4096(built):
+    """SMFFT_DIT_multiple<FFT_4096_*> in the reference's shape (1024 threads, NREUSES calls of do_SMFFT_CT_DIT with the loop's own
+    barrier): natural order <= 5 workgroup barriers per application (round 3: 8), no reorder <= 3 (CT:553-572)"""
+    isa = built["isa"]
+    assert _loop_barriers(isa, "SMFFT_DIT_multipleI16FFT_4096_forwardE", "SMFFT_DIT_multiple<FFT_4096_forward>") <= 5
+    assert _loop_barriers(isa, "SMFFT_DIT_multipleI26FFT_4096_forward_noreorderE", "SMFFT_DIT_multiple<FFT_4096_forward_noreorder>") <= 3
