@@ -1,11 +1,12 @@
-"""Prints the tables of DESIGN.md section 5.2 / 5.4 from profiles/<tag>_bench_detail.json (the full record behind a bench line):
-python tools/design_tables.py [r04]"""
+"""Prints the tables of DESIGN.md section 5.2 - 5.4 from profiles/<tag>_bench_detail.json (the full record behind a bench line):
+python tools/design_tables.py [r04] [--patch]      (--patch: rewrite those tables in DESIGN.md in place)"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+tag = args[0] if args else "r04"
 d = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_bench_detail.json")))
 c = d["configs"]["config3_multiple"]
 by_len = d["configs"]["reference_contract"]["by_length"]
@@ -46,3 +47,47 @@ if "in_lds" in c4.get("512", {}):
     for n in ("512", "1024", "2048", "4096"):
         r = c4[n]["in_lds"]
         print("| %s | %.3f | %.3f | %.3f | +%.0f / +%.0f %% |" % (n, r["r2c_ms"], r["c2r_ms"], r["c2c_same_complex_length_ms"], 100 * r["r2c_over_c2c"], 100 * r["c2r_over_c2c"]))
+
+
+def patch_design():
+    """the three tables of DESIGN.md 5.2 / 5.4 and the in-LDS table of 5.3, rewritten from the record (headers and prose stay)"""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), tag], capture_output=True, text=True).stdout
+    sec = [[l for l in blk.split("\n")[1:] if l.startswith("|")] for blk in out.split("\n\n")]
+    path = os.path.join(ROOT, "DESIGN.md")
+    s = open(path).read()
+
+    def replace_rows(text, header_start, end_marker, rows):
+        a = text.index(header_start)
+        hdr_end = text.index("\n", text.index("|---|", a)) + 1
+        b = text.index(end_marker, hdr_end)
+        return text[:hdr_end] + "\n".join(rows) + "\n\n" + text[b:]
+    rows = []
+    for l in sec[0]:
+        c = [x.strip() for x in l.strip("|").split("|")]
+        if c[0] == "32":
+            c[2] = "= fused (the N = 32 kernel forwards its registers in either build)"
+        if c[0] == "1024":
+            c = [c[0]] + ["**" + x + "**" for x in c[1:]]
+        rows.append("| " + " | ".join(c) + " |")
+    s = replace_rows(s, "| N | the reference's contract", "(V100 reference, README.md:84-91", rows)
+    s = replace_rows(s, "| N | reorder FFT/s | frac (round 3) | oldest-first | saturating |", "(Other runs of the round, other boxes:", sec[1])
+    rows = []
+    for l in sec[2]:
+        c = [x.strip() for x in l.strip("|").split("|")]
+        if "_wave64" in c[0]:
+            n = int(c[0].split()[0])
+            c[0] = "%d `_wave64` (64-thread blocks, %d transforms each)" % (n, 256 // n)
+        elif int(c[0]) <= 128:
+            n = int(c[0])
+            c[0] = "%d upstream shape (32-thread blocks, %d transform%s each)" % (n, 128 // n, "s" if 128 // n > 1 else "")
+        rows.append("| " + " | ".join(c) + " |")
+    s = replace_rows(s, "| N | external, two-argument kernel / user's fill-call-drain kernel (reorder), ratio to tiled |", "The `_wave64` classes (`include/smfft/SM_FFT_parameters.hpp`) change ONE number", rows)
+    if len(sec) > 3 and "| real N | R2C ms | C2R ms |" in s:
+        s = replace_rows(s, "| real N | R2C ms | C2R ms |", "(`configs.config4_r2c_c2r_external.<N>.in_lds`", sec[3])
+    open(path, "w").write(s)
+    print("DESIGN.md tables rewritten from profiles/%s_bench_detail.json" % tag)
+
+
+if "--patch" in sys.argv:
+    patch_design()
