@@ -314,8 +314,17 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
     // a 256-point ladder (QuarterLanes<256>: same twiddles W_4P^k, k = lane mod P); its results, elements 256 w + lane + 64 i, go
     // to the swizzled image, and only the passes that cross waves (P >= 256 and the radix-2 pass) run through LDS:
     // 2 LDS round trips instead of 5 at N = 512 / 1024, 3 instead of 6 at N = 2048 / 4096 (whose eight barriers become three).
-    constexpr bool kLanesHead = (ENGINE == 2 || (ENGINE == 0 && SMFFT_QUARTER_LANES != 0)) && !REORDER && N >= 512;
-    constexpr int kFirstLdsPass = kLanesHead ? 4 : 1;
+    // N >= 512, natural order: pass 0 carries the bit reversal (scattered stores into the swizzled image, across waves); after it the
+    // wave again owns the aligned block of 256 elements number w, thread t = lane + 64 w the four elements 4 t + i of it -- the
+    // state a no-reorder ladder is in after ITS pass 0 -- so the passes 1 ... 3 (P = 4, 16, 64: wave-local) run on lanes as well
+    // (QuarterLanes<256>::passes<1>): one LDS round trip instead of three, 5 -> 3 at N = 512 / 1024, 6 -> 4 at N = 2048 / 4096.
+    constexpr bool kLanes512 = (ENGINE == 2 || (ENGINE == 0 && SMFFT_QUARTER_LANES != 0)) && N >= 512;
+    constexpr bool kLanesHead = kLanes512 && !REORDER;
+#ifndef SMFFT_QUARTER_LANES_MIDDLE
+#define SMFFT_QUARTER_LANES_MIDDLE 1   // 0: the natural-order variants of N >= 512 keep every pass in LDS (A/B)
+#endif
+    constexpr bool kLanesMiddle = kLanes512 && REORDER && SMFFT_QUARTER_LANES_MIDDLE != 0;
+    constexpr int kFirstLdsPass = (kLanesHead || kLanesMiddle) ? 4 : 1;
     if constexpr (kLanesHead) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) e[i] = IN_REGS ? x[i] : sf[4 * t + i];
@@ -347,6 +356,17 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
             const int a0 = quarter_swizzle(region_offset + a);                          // a0 ^ m: the same aligned group of four
             s[a0] = cadd(s0, s1), s[a0 ^ 2] = csub(s0, s1), s[a0 ^ 1] = cadd(d0, jd1), s[a0 ^ 3] = csub(d0, jd1);
         }
+    }
+    if constexpr (kLanesMiddle) {
+        fft_sync<kBarrier>();                                      // every wave's scattered stores precede the loads
+        const int b0 = quarter_swizzle(region_offset + 4 * t);     // elements 4 t + i: one aligned group of four
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = s[b0 ^ i];
+        QuarterLanes<256, DIR, 0>::template passes<1>(e, t & 63, t & 63);
+        fft_sync<false>();                                         // the wave's own loads precede its stores into the same 256 elements
+        const int j0 = region_offset + (t & ~63) * 4 + (t & 63);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[quarter_swizzle(j0 + 64 * i)] = e[i];
     }
     }
     // ---- passes 1 .. (P = 4, 16, ...) -----------------------------------------------------------------------------
