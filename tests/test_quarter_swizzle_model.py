@@ -56,7 +56,9 @@ int main() {
 def test_lane_and_register_form_of_the_ladder_is_the_dft():
     """tools/quarter_lanes_model.py: the N <= 256 form of the reference-contract engine (exchanges between passes as lane <-> slot
     bit transposes, no LDS) computes the DFT (natural order) / the DFT of the bit-reversed input (no reorder) for N = 32 ... 256,
-    and its results end where QuarterLanes::out_offset says."""
+    and its results end where QuarterLanes::out_offset says; for N = 512 ... 4096 the lane passes inside every aligned block of 256
+    elements (all four without reorder: kLanesHead; passes 1 ... 3 after the scattered first pass in natural order: kLanesMiddle)
+    followed by the passes through LDS, and that a block's thread ends with the elements lane + 64 i the next pass expects."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))

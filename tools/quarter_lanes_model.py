@@ -2,8 +2,9 @@
 radix-2^2 decimation-in-time ladder on four elements per thread in which the exchange between two passes is a pair of one-bit
 transposes between a slot bit of the thread's four registers and a lane bit -- no LDS.  Replays lanes, slots and swaps and
 compares with numpy.fft for N = 32 ... 256, both directions, natural order and no reorder; prints where the results end up
-(slot i of thread t holds element base + (N/4) * sigma(i), base = rev(t) or t).  CPU only; tests/test_quarter_swizzle_model.py
-runs check()."""
+(slot i of thread t holds element base + (N/4) * sigma(i), base = rev(t) or t).  N = 512 ... 4096 (model_large): the same lane
+passes inside every aligned block of 256 elements -- all four of them without reorder, passes 1 ... 3 after the scattered first
+pass in natural order -- and the passes that cross waves on the image.  CPU only; tests/test_quarter_swizzle_model.py runs check()."""
 import numpy as np
 
 def rev(v, bits):
@@ -12,8 +13,9 @@ def rev(v, bits):
         r |= ((v >> b) & 1) << (bits - 1 - b)
     return r
 
-def model(N, DIR, REORDER, x):
-    """returns (result array in natural order assembled from the tracked positions, jmap[t][i])"""
+def model(N, DIR, REORDER, x, skip_pass0=False):
+    """returns (result array in natural order assembled from the tracked positions, jmap[t][i]); skip_pass0: x holds the results of
+    pass 0 already (the natural-order variants of N >= 512 enter the lane passes after their scattered first pass)"""
     n = N.bit_length() - 1
     Q = N // 4
     TB = n - 2
@@ -53,7 +55,7 @@ def model(N, DIR, REORDER, x):
                     ne[t, i] = e[p, hi]; nj[t, i] = jidx[p, hi]
         e, jidx = ne, nj
     # pass 0
-    for t in range(Q):
+    for t in range(Q if not skip_pass0 else 0):
         e0, e1, e2, e3 = e[t]
         s0, d0, s1, d1 = e0 + e1, e0 - e1, e2 + e3, e2 - e3
         jd1 = d1 * (1j * sign)
@@ -89,6 +91,52 @@ def model(N, DIR, REORDER, x):
             out[jidx[t, i]] = e[t, i]
     return out, jidx
 
+def model_large(N, DIR, REORDER, x):
+    """N >= 512 (quarter_fft, kLanesHead / kLanesMiddle): the wave-local passes of every aligned block of 256 elements on lanes
+    (the 256-point ladder above: all four passes without reorder, passes 1 ... 3 after the scattered pass 0 in natural order), the
+    passes that cross waves (P >= 256, the radix-2 pass) on the image y, indexed naturally (the swizzle is a renaming)."""
+    n = N.bit_length() - 1
+    Q, TB = N // 4, n - 2
+    sign = 1 if DIR else -1
+    W = lambda M, k: np.exp(sign * 2j * np.pi * k / M)
+    y = np.zeros(N, complex)
+    if REORDER:
+        for t in range(Q):                       # pass 0: loads x[t + m N/4], stores 4 rev(t) + i
+            e = [0] * 4
+            for m in range(4):
+                e[((m & 1) << 1) | (m >> 1)] = x[t + m * Q]
+            s0, d0, s1, d1 = e[0] + e[1], e[0] - e[1], e[2] + e[3], e[2] - e[3]
+            jd1 = d1 * (1j * sign)
+            a = 4 * rev(t, TB)
+            y[a:a + 4] = [s0 + s1, d0 + jd1, s0 - s1, d0 - jd1]
+    for w in range(N // 256):                    # the wave's block: thread (w, lane) enters with elements 256 w + 4 lane + i
+        blk = (y if REORDER else x)[256 * w:256 * w + 256]
+        out, jmap = model(256, DIR, 0, blk, skip_pass0=bool(REORDER))
+        for lane in range(64):
+            assert list(jmap[lane]) == [lane + 64 * i for i in range(4)]      # ... and leaves with 256 w + lane + 64 i
+        y[256 * w:256 * w + 256] = out
+    P = 256
+    for p in range(4, n // 2):                   # passes through LDS: k = t mod P, base = (t - k) * 4 + k
+        for t in range(Q):
+            k = t & (P - 1)
+            base = ((t - k) << 2) + k
+            w2 = W(4 * P, k); w1 = w2 * w2
+            x0, x1, x2, x3 = y[base], y[base + P], y[base + 2 * P], y[base + 3 * P]
+            t1, t3 = x1 * w1, x3 * w1
+            y0, y1, y2, y3 = x0 + t1, x0 - t1, x2 + t3, x2 - t3
+            u2, v3 = y2 * w2, y3 * w2
+            u3 = v3 * (1j * sign)
+            y[base], y[base + P], y[base + 2 * P], y[base + 3 * P] = y0 + u2, y1 + u3, y0 - u2, y1 - u3
+        P *= 4
+    if n & 1:
+        for t in range(Q):
+            w = W(N, t)
+            x0, x1, x2, x3 = y[t], y[t + N // 2], y[t + Q], y[t + 3 * Q]
+            t1, t3 = x1 * w, x3 * w * (1j * sign)
+            y[t], y[t + N // 2], y[t + Q], y[t + 3 * Q] = x0 + t1, x0 - t1, x2 + t3, x2 - t3
+    return y
+
+
 def bitrev_perm(N):
     n = N.bit_length() - 1
     return np.array([rev(i, n) for i in range(N)])
@@ -113,6 +161,17 @@ def check(verbose=False):
                     assert list(jmap[t]) == [base + Q * sigma[i] for i in range(4)], (N, REO, t)
                 if verbose:
                     print(f"N={N} dir={DIR} reorder={REO}: max error {err:.2e}; thread 1 ends with elements {list(map(int, jmap[1]))}")
+    for N in (512, 1024, 2048, 4096):
+        for DIR in (0, 1):
+            for REO in (1, 0):
+                x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+                got = model_large(N, DIR, REO, x)
+                xin = x if REO else x[bitrev_perm(N)]
+                want = (np.fft.ifft(xin) * N) if DIR else np.fft.fft(xin)
+                err = np.abs(got - want).max() / np.abs(want).max()
+                worst = max(worst, err)
+                if verbose:
+                    print(f"N={N} dir={DIR} reorder={REO}: lane passes inside every block of 256, max error {err:.2e}")
     return worst
 
 
