@@ -81,6 +81,12 @@ constexpr RowTable place_rows(int tw, int q0, int q1, int q2, int q3, int q4, in
     return t;
 }
 constexpr int bit_of(int j, int b) { return (j >> b) & 1; }
+// N = 512 natural order with exchange 1 through LDS like the longer lengths instead of sixteen v_permlane16_swap (A/B switch;
+// tools/soa_model.py 512: its reads are conflict free with the residues below; the no-reorder variant's last reads are not)
+#ifndef SMFFT_PLANAR_512_LDS_X1
+#define SMFFT_PLANAR_512_LDS_X1 0
+#endif
+constexpr bool planar_512_lds_x1(int n, int reorder) { return SMFFT_PLANAR_512_LDS_X1 != 0 && n == 512 && reorder; }
 // residue of row j as a function of (j's bits): the tables of tools/soa_model.py in closed form
 enum class RowKind { image, x1, x2 };
 template <int N, int REORDER>
@@ -89,13 +95,13 @@ constexpr int row_residue(RowKind kind, int j) {
         case RowKind::image:    // read by the bit-reversed loads of the no-reorder variants (lane linear in the reorder variants)
             return N == 32 ? 8 * bit_of(j, 3) : N == 64 ? 4 * (j >> 2) : N == 128 ? bit_of(j, 2) + 8 * bit_of(j, 3) : N == 256 ? j : N == 512 ? bit_of(j, 0) + 2 * bit_of(j, 2) + 8 * bit_of(j, 3) : N == 4096 ? 4 * bit_of(j, 3) : (j >> 2);
         case RowKind::x1:       // after pass 1 (three-pass lengths)
-            return N == 2048 ? bit_of(j, 1) : N == 4096 ? 2 * bit_of(j, 0) : 0;  // (N = 512 exchanges in registers)
+            return N == 2048 ? bit_of(j, 1) : N == 4096 ? 2 * bit_of(j, 0) : planar_512_lds_x1(N, REORDER) ? 8 * (1 - bit_of(j, 3)) : 0;  // (N = 512 exchanges in registers)
         default:                // in front of the last pass
             if (N == 32) return 8 * bit_of(j, 0);
             if (N == 64) return 4 * (j & 3);
             if (N == 128) return bit_of(j, 0) + 8 * bit_of(j, 1);
             if (N == 256) return (j & 3) + 8 * bit_of(j, 3);
-            if ((REORDER && N != 512) || N == 4096) return (j & 3) + 8 * bit_of(j, 3);   // klow = pass-1 role
+            if ((REORDER && (N != 512 || planar_512_lds_x1(N, REORDER))) || N == 4096) return (j & 3) + 8 * bit_of(j, 3);   // klow = pass-1 role
             return N == 512 ? bit_of(j, 0) + 2 * bit_of(j, 1) + 8 * bit_of(j, 2) : N == 1024 ? (j >> 2) : bit_of(j, 0) + 2 * bit_of(j, 3);
     }
 }
@@ -150,7 +156,7 @@ struct PlanarEngine {
     static constexpr bool kThreePass = RM > 1;
     // N = 512 (RM = 2): exchange 1 moves data between two threads only -- sixteen v_permlane16_swap (Engine::exchange1_registers)
     // measured faster than a third trip through LDS (profiles/r03_ab_planar_all.txt); its roles are the register engine's (t1 = v)
-    static constexpr bool kRegisterX1 = (RM == 2);
+    static constexpr bool kRegisterX1 = (RM == 2) && !planar_512_lds_x1(N, REORDER);
     // N = 4096 (RM = 16: sixteen consecutive threads share t2, so eight lanes of a ds_read_b128 group would read blocks of ONE
     // row -- 2-way conflicts no row shift can undo; round 3's first form had them on three reads, 384 of 1541 LDS cycles per FFT):
     //  * exchange 1: a lane reads the four quads of its run in an order rotated by rot = t2 >> 3.  Its registers then hold the
