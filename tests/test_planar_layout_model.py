@@ -63,3 +63,14 @@ int main() {
             assert rows[(n, 1, "x2")] == tables["x2_reorder"], (n, "x2 reorder")
     assert rows[(4096, 0, "x2")] == H[4096]["x2_reorder"]       # N = 4096 computes klow = role in both orderings
     assert rows[(512, 1, "x2")] == H[512]["x2"]                 # N = 512 keeps roles = positions in both
+
+
+def test_pairwise_hermitian_split_and_merge_bookkeeping():
+    """tools/hermitian_pairs_model.py: PlanarEngine::hermitian_apply_pairs replayed thread by thread -- who holds which element, whose
+    register the partner is, which rows the second results travel through, role 0's own pairs and the packed element 0 -- gives the
+    packed rfft (RC:269-344, S5) and, as a merge in front of the inverse transform, (N/2) x (S6), for complex lengths 256 ... 2048."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import hermitian_pairs_model
+    assert hermitian_pairs_model.check() < 1e-13
