@@ -562,6 +562,7 @@ def main():
         return sorted(ts)[len(ts) // 2]
 
     SETTLE = 40.0                       # ms of untimed in-LDS launches before the timed ones (see median_ms)
+    SETTLE_HBM = 15.0                   # ... and of untimed HBM-bound launches where those follow compute-bound ones (the reverse effect; box dependent)
 
     def launch_event_ms(fn, reps=7, settle_ms=SETTLE):
         # the same for launch-only entry points (smfft_launch on `stream`): HIP events around each launch
@@ -628,11 +629,14 @@ def main():
             for name, inv, src, dst in (("r2c", 0, pa.value, pb.value), ("c2r", 1, pa.value + half, pb.value + half)):
                 if inv:
                     sm.lib.smfft_memcpy_d2d(src, pb.value, rbytes)
-                ms = median_ms(lambda t, inv=inv, src=src, dst=dst, rn=rn, rnffts=rnffts: sm.lib.smfft_rc_external_benchmark(src, dst, rn, rnffts, inv, t))
+                ms = median_ms(lambda t, inv=inv, src=src, dst=dst, rn=rn, rnffts=rnffts: sm.lib.smfft_rc_external_benchmark(src, dst, rn, rnffts, inv, t), settle_ms=SETTLE_HBM)
                 gbps = 2 * rbytes / (ms * 1e-3) / 1e9
                 row[name] = {"ms": ms, "TB/s": gbps / 1e3, "frac": gbps / HBM_PEAK_GBPS}
-            # in-LDS path (FFT_GPU_R2C_C2R_multiple, RC:367-384: 100 applications per load / store) next to the C2C of the same
-            # complex length on the same number of slots (the natural-order Stockham program's `multiple` kernel)
+            c4[str(rn)] = row
+        # in-LDS path (FFT_GPU_R2C_C2R_multiple, RC:367-384: 100 applications per load / store) next to the C2C of the same complex
+        # length on the same number of slots (the natural-order Stockham program's `multiple` kernel) -- a loop of its own, behind
+        # the HBM-bound rows: on some boxes the memory-bound kernels run 10 % slower for a while after compute-bound launches
+        for rn in (512, 1024, 2048, 4096):
             lds_ffts = min((1 << 30) // rn, nffts * n * 2 // rn)            # 4 GiB of reals: as many slots of complex length rn / 2 as config 3 has
 
             def launch_ms(family, size, inv, rnffts=lds_ffts):
@@ -644,8 +648,7 @@ def main():
             lds = {"nFFTs": lds_ffts, "r2c_ms": launch_ms(2, rn, 0), "c2r_ms": launch_ms(2, rn, 1), "c2c_same_complex_length_ms": launch_ms(1, rn // 2, 1)}
             lds["r2c_over_c2c"] = lds["r2c_ms"] / lds["c2c_same_complex_length_ms"] - 1.0
             lds["c2r_over_c2c"] = lds["c2r_ms"] / lds["c2c_same_complex_length_ms"] - 1.0
-            row["in_lds"] = lds
-            c4[str(rn)] = row
+            c4[str(rn)]["in_lds"] = lds
         c4.update({"real_N": 2048, "nFFTs": c4["2048"]["nFFTs"], "algorithmic_bytes_per_launch": c4["2048"]["algorithmic_bytes_per_launch"],
                    "r2c": c4["2048"]["r2c"], "c2r": c4["2048"]["c2r"]})      # BASELINE's config 4 itself, as in round 2's line
         # config 2 at every length: forward / inverse x reorder / no reorder, whole 4 GiB batch
@@ -654,7 +657,7 @@ def main():
             bn = nffts * n // fn_n
             row = {"nFFTs": bn}
             for name, inv, reo in (("forward", 0, 1), ("inverse", 1, 1), ("forward_noreorder", 0, 0), ("inverse_noreorder", 1, 0)):
-                ms = median_ms(lambda t, inv=inv, reo=reo: sm.lib.smfft_ct_external_benchmark(pa.value, pb.value, fn_n, bn, inv, reo, t), reps=7)
+                ms = median_ms(lambda t, inv=inv, reo=reo: sm.lib.smfft_ct_external_benchmark(pa.value, pb.value, fn_n, bn, inv, reo, t), reps=7, settle_ms=SETTLE_HBM if name == "forward" else 0.0)
                 gbps = 2 * fn_n * bn * 8 / (ms * 1e-3) / 1e9
                 row[name] = {"ms": ms, "TB/s": gbps / 1e3, "frac": gbps / HBM_PEAK_GBPS}
             c2[str(fn_n)] = row
@@ -662,7 +665,7 @@ def main():
         cst = {}
         for fn_n in (256, 512, 1024, 2048, 4096):
             bn = nffts * n // fn_n
-            ms = median_ms(lambda t: sm.lib.smfft_st_external_benchmark(pa.value, pb.value, fn_n, bn, t), reps=7)
+            ms = median_ms(lambda t: sm.lib.smfft_st_external_benchmark(pa.value, pb.value, fn_n, bn, t), reps=7, settle_ms=SETTLE_HBM)
             gbps = 2 * fn_n * bn * 8 / (ms * 1e-3) / 1e9
             msm = median_ms(lambda t: sm.lib.smfft_st_multiple_benchmark(pa.value, pb.value, fn_n, bn, t), reps=7, settle_ms=SETTLE)
             done = bn // 100 * 100
@@ -697,7 +700,7 @@ def main():
             # user_kernel_external_*: a user's kernel around do_SMFFT_CT_DIT (fill LDS, call, drain), examples/reference_shape_kernel.hip
             for key, which_reo, which_kernel in (("ct_external_reorder", 1, 1), ("ct_external_noreorder", 0, 1),
                                                  ("user_kernel_external_reorder", 1, 0), ("user_kernel_external_noreorder", 0, 0)):
-                ms = event_ms(lambda r=which_reo, w=which_kernel: ex.smfft_example_reference_shape_ct(pa.value, pb.value, n, nffts, 0, r, w, sh))
+                ms = event_ms(lambda r=which_reo, w=which_kernel: ex.smfft_example_reference_shape_ct(pa.value, pb.value, n, nffts, 0, r, w, sh), settle_launches=8)
                 tiled = c2[str(n)]["forward" if which_reo else "forward_noreorder"]["ms"]
                 cref[key] = {"ms": ms, "TB/s": gb / ms, "frac": gb / ms * 1e3 / HBM_PEAK_GBPS, "ratio_to_tiled": tiled / ms}
             ms = event_ms(lambda: ex.smfft_example_reference_shape_st(pa.value, pb.value, n, nffts, sh))
@@ -716,7 +719,7 @@ def main():
                 blocks = (bn // 100) // per_block
                 row = {}
                 for name, reo in (("reorder", 1), ("noreorder", 0)):
-                    ms = event_ms(lambda r=reo, fn_n=fn_n, bn=bn: ex.smfft_example_reference_shape_ct(pa.value, pb.value, fn_n, bn, 0, r, 1, sh), reps=5)
+                    ms = event_ms(lambda r=reo, fn_n=fn_n, bn=bn: ex.smfft_example_reference_shape_ct(pa.value, pb.value, fn_n, bn, 0, r, 1, sh), reps=5, settle_launches=8)
                     ms_user = event_ms(lambda r=reo, fn_n=fn_n, bn=bn: ex.smfft_example_reference_shape_ct(pa.value, pb.value, fn_n, bn, 0, r, 0, sh), reps=5)
                     tiled = c2[str(fn_n)]["forward" if reo else "forward_noreorder"]["ms"]
                     msm = event_ms(lambda r=reo, fn_n=fn_n, blocks=blocks: ex.smfft_example_reference_shape_ct_multiple(pa.value, pb.value, fn_n, blocks, r, sh), reps=5, settle_launches=20)
@@ -729,7 +732,7 @@ def main():
                         # block, CT:586-595, is half of one): same contract, same kernels
                         per64 = 256 // fn_n
                         blocks64 = (bn // 100) // per64
-                        ms64 = event_ms(lambda r=reo, fn_n=fn_n, bn=bn: ex.smfft_example_reference_shape_ct(pa.value, pb.value, fn_n, bn, 0, r, 3, sh), reps=5)
+                        ms64 = event_ms(lambda r=reo, fn_n=fn_n, bn=bn: ex.smfft_example_reference_shape_ct(pa.value, pb.value, fn_n, bn, 0, r, 3, sh), reps=5, settle_launches=8)
                         ms64_user = event_ms(lambda r=reo, fn_n=fn_n, bn=bn: ex.smfft_example_reference_shape_ct(pa.value, pb.value, fn_n, bn, 0, r, 2, sh), reps=5)
                         msm64 = event_ms(lambda r=reo, fn_n=fn_n, blocks64=blocks64: ex.smfft_example_reference_shape_ct_multiple_wave64(pa.value, pb.value, fn_n, blocks64, r, sh), reps=5, settle_launches=20)
                         compact64 = c3[str(fn_n)][name]["ms"] * (blocks64 * per64 * 100) / c3[str(fn_n)]["FFTs_executed"]
@@ -740,7 +743,7 @@ def main():
             cref["by_length"] = by_len
         except (OSError, AttributeError) as e:
             cref = {"error": repr(e)}
-        configs = {"timing": "median of 11 (7 where many cases) event-timed launches after 3 warm-ups, buffers of `roofline`; the in-LDS (multiple) figures after a further 40 ms of untimed launches (clocks settled, profiles/r03_warm_ramp.txt)",
+        configs = {"timing": "median of 11 (7 where many cases) event-timed launches after 3 warm-ups, buffers of `roofline`; the in-LDS (multiple) figures after a further 40 ms of untimed launches (clocks settled, profiles/r03_warm_ramp.txt), HBM-bound figures that follow in-LDS ones after 15 ms of untimed launches",
                    "config3_schedule": "multiple path: persistent grid of the co-resident workgroups sharing the launch's applications evenly, wave priorities rotating every 2^15 clocks (DESIGN.md section 5.2); `one_chain_per_workgroup_oldest_first` = the schedule of rounds 1-3 on the same kernel",
                    "config2_external_by_length": c2, "config3_multiple": c3, "config4_r2c_c2r_external": c4,
                    "stockham_program": cst, "reference_contract": cref}
