@@ -393,7 +393,9 @@ struct PlanarEngine {
     // ---- one application: pass-1 slots in r -> natural result r[q3] = X[klow + T*q3] --------------------------------
     __device__ __forceinline__ void transform_from_pass1_slots(float2 (&r)[16], float* planes) const {
         pass1(r);
-        planar_sync<G::kMultiWave>();       // every read of the previous image is done
+        planar_sync<G::kMultiWave>();       // every read of the previous image is done -- and every STORE of it: the rows of the image and of exchange 1
+                                            // start at different residues, so near a wave boundary this wave's x1 dwords are another wave's image dwords
+                                            // (dropping this in the fused chain, where nobody reads the image, broke N = 2048: a late image store landed on x1 data)
         if constexpr (kRegisterX1) {
             Engine<N, DIR, 1>::exchange1_registers_static(r);
             middle(r);
