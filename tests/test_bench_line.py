@@ -43,6 +43,25 @@ def test_compact_line_from_recorded_detail(path):
             assert key in line["cpu_baseline"]
 
 
+def test_compact_line_from_the_rounds_full_record():
+    """the round-4 record (every config, every length: profiles/r04_bench_detail.json) gives the committed line's summary: the three
+    in-LDS figures of N = 1024 side by side, config 3 / 4 and contract ratios, the in-LDS R2C / C2R rows against their C2C"""
+    path = os.path.join(ROOT, "profiles", "r04_bench_detail.json")
+    if not os.path.exists(path):
+        pytest.skip("no round-4 record in this checkout")
+    text = bench.compact_line(json.load(open(path)))
+    assert len(text) < bench.COMPACT_LIMIT, len(text)
+    line = _strict(text)
+    s = line["summary"]
+    contract, unfused, fused = s["in_lds_1024_contract_FFTps"], s["in_lds_1024_unfused_FFTps"], s["in_lds_1024_fused_FFTps"]
+    assert 0 < contract[0] <= contract[1] < unfused < fused[1]
+    for key in ("rc_in_lds_r2c_over_c2c", "rc_in_lds_c2r_over_c2c"):
+        assert len(s[key]) == 4 and all(0.0 < v < 0.6 for v in s[key]), (key, s[key])
+    assert len(s["config3_frac_2048_4096"]) == 4 and min(s["config3_frac_2048_4096"]) > 0.4
+    assert len(s["contract_wave64_small_N_in_lds_ratio"]) == 3
+    assert 0.6 < line["roofline"]["frac"] < 1.0 and line["roofline"]["traffic"] is not None
+
+
 def test_compact_line_worst_case_is_bounded_and_strict():
     """a detail record with NaN / inf in it, eight ranks, and overlong strings still gives a strict, bounded line"""
     detail = json.load(open(RECORDED[0]))
