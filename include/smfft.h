@@ -201,6 +201,18 @@ int smfft_get_multiple_balance(void);
    hardware's oldest-wave-first order (rounds 1-3); < 0: back to the process default */
 void smfft_set_multiple_rotation(int log2_clocks);
 int smfft_get_multiple_rotation(void);
+/* The balanced schedule hands a cut chain from one workgroup to the next through the chain's slot of d_output and a word of device
+   memory.  It does not depend on the two workgroups being resident together: a workgroup that has waited `microseconds` (default 1000;
+   SMFFT_HANDOFF_WAIT_US; THIS host thread) for data nobody has committed to parking runs the whole chain itself from d_input -- same
+   bits -- and the late owner skips it.  So a launch finishes whatever else occupies the device; < 0: back to the process default. */
+void smfft_set_handoff_wait_us(int microseconds);
+/* Fault injection for the tests of that path (THIS host thread): in the next balanced launches the workgroup that parks chain `chain`
+   sleeps `milliseconds` before it commits to parking (after_commit = 0: the resumer takes the chain over) or between its commit and
+   the parked word (1: the resumer waits for the store it has been promised).  milliseconds <= 0: off. */
+void smfft_debug_delay_parking(int chain, int milliseconds, int after_commit);
+/* Introspection: buffers of hand-over words the library holds (one per balanced launch in flight, recycled by event; at most 32,
+   128 KiB each) and, in *in_flight, how many of them a launch is still using. */
+int smfft_schedule_buffers(int* in_flight);
 /* How many workgroups of a multiple kernel the device holds at once, COUNTED by a calibration launch over scratch buffers (family 0
    CT / 1 Stockham, path 1 or 2); *assumed = what the balanced schedule computes from the kernel's registers and LDS.  < 0: error. */
 int smfft_measure_multiple_residency(int family, int FFT_size, int inverse, int reorder, int path, int* assumed);

@@ -151,16 +151,7 @@ static __device__ const QuarterTwiddleRows<N> quarter_twiddle_rows = QuarterTwid
 // measured SQ_LDS_BANK_CONFLICT 0.44-0.57 -> 0.10-0.25 of the LDS cycles, in-LDS rate x 1.5-2.0).  The
 // price: the first pass must have read everything before anything is stored, and the last pass reads everything before it
 // stores in natural order -- one more synchronisation at either end (the natural-order first pass had one already).
-#ifndef SMFFT_QUARTER_SWIZZLE
-#define SMFFT_QUARTER_SWIZZLE 1
-#endif
-__host__ __device__ constexpr int quarter_swizzle(int i) {
-#if SMFFT_QUARTER_SWIZZLE
-    return i ^ ((i >> 8) & 31) ^ ((i >> 4) & 30) ^ ((i >> 2) & 24);
-#else
-    return i;
-#endif
-}
+__host__ __device__ constexpr int quarter_swizzle(int i) { return i ^ ((i >> 8) & 31) ^ ((i >> 4) & 30) ^ ((i >> 2) & 24); }
 
 // ------------------------------------------------------------------------------------------------
 // N <= 256 (round 4): the same radix-2^2 ladder with NO LDS between its passes.  The N/4 threads of a transform are 8 ... 64
@@ -300,11 +291,6 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
     // aligned groups of 32) and the elements of the first (no-reorder) and of the last pass (t + m N/4: thread and element
     // share their offset inside a group of 32): between those a wave-level fence orders everything.  What does cross waves:
     // the natural-order first pass (loads t + m N/4, stores 4 rev(t) + m), the passes with P >= 256 and the radix-2 pass.
-#ifndef SMFFT_QUARTER_WAVE_SYNC
-#define SMFFT_QUARTER_WAVE_SYNC 1
-#endif
-    constexpr bool kWaveLocal = SMFFT_QUARTER_WAVE_SYNC != 0;
-    constexpr bool kSwizzled = SMFFT_QUARTER_SWIZZLE != 0;
     constexpr int T_BITS = ilog2c(Q);
     constexpr int kLastQuad = R::kOdd ? -1 : R::kPasses - 1;    // the pass whose results leave in natural order (none: the radix-2 pass is last)
     float2* sf = s + region_offset;
@@ -320,10 +306,7 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
     // (QuarterLanes<256>::passes<1>): one LDS round trip instead of three, 5 -> 3 at N = 512 / 1024, 6 -> 4 at N = 2048 / 4096.
     constexpr bool kLanes512 = (ENGINE == 2 || (ENGINE == 0 && SMFFT_QUARTER_LANES != 0)) && N >= 512;
     constexpr bool kLanesHead = kLanes512 && !REORDER;
-#ifndef SMFFT_QUARTER_LANES_MIDDLE
-#define SMFFT_QUARTER_LANES_MIDDLE 1   // 0: the natural-order variants of N >= 512 keep every pass in LDS (A/B)
-#endif
-    constexpr bool kLanesMiddle = kLanes512 && REORDER && SMFFT_QUARTER_LANES_MIDDLE != 0;
+    constexpr bool kLanesMiddle = kLanes512 && REORDER;
     constexpr int kFirstLdsPass = (kLanesHead || kLanesMiddle) ? 4 : 1;
     if constexpr (kLanesHead) {
 #pragma unroll
@@ -345,7 +328,7 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
         a = 4 * t;
 #pragma unroll
         for (int i = 0; i < 4; ++i) e[i] = IN_REGS ? x[i] : sf[a + i];
-        if constexpr (!IN_REGS && kSwizzled && kLastQuad != 0) fft_sync<kBarrier && !kWaveLocal>();  // ... and the swizzled ones (same wave's)
+        if constexpr (!IN_REGS && kLastQuad != 0) fft_sync<false>();  // ... and the swizzled ones (same wave's)
     }
     {
         const float2 s0 = cadd(e[0], e[1]), d0 = csub(e[0], e[1]), s1 = cadd(e[2], e[3]), d1 = csub(e[2], e[3]);
@@ -374,7 +357,7 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
         int P = 1 << (2 * kFirstLdsPass);
 #pragma unroll
         for (int p = kFirstLdsPass; p < R::kPasses; ++p, P *= 4) {
-            if (P > 64 || (REORDER && p == 1) || !kWaveLocal) fft_sync<kBarrier>();
+            if (P > 64 || (REORDER && p == 1)) fft_sync<kBarrier>();
             else fft_sync<false>();
             const int k = t & (P - 1);
             const int base = ((t - k) << 2) + k;
@@ -392,7 +375,7 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
                 if constexpr (OUT_REGS) {                                                // base = t, P = N / 4
                     x[0] = cadd(y0, u2), x[2] = csub(y0, u2), x[1] = cadd(y1, u3), x[3] = csub(y1, u3);
                 } else {
-                    if constexpr (kSwizzled) fft_sync<kBarrier && !kWaveLocal>();        // every swizzled load precedes the natural stores (same wave's)
+                    fft_sync<false>();                                                   // every swizzled load precedes the natural stores (same wave's)
                     sf[base] = cadd(y0, u2), sf[base + 2 * P] = csub(y0, u2), sf[base + P] = cadd(y1, u3), sf[base + 3 * P] = csub(y1, u3);
                 }
             } else {
@@ -412,7 +395,7 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
         if constexpr (OUT_REGS) {
             x[0] = cadd(x0, t1), x[2] = csub(x0, t1), x[1] = cadd(x2, t3), x[3] = csub(x2, t3);
         } else {
-            if constexpr (kSwizzled) fft_sync<kBarrier && !kWaveLocal>();
+            fft_sync<false>();                                                           // every swizzled load precedes the natural stores (same wave's)
             sf[t] = cadd(x0, t1);
             sf[t + N / 2] = csub(x0, t1);
             sf[t + Q] = cadd(x2, t3);
@@ -564,18 +547,14 @@ __device__ void do_FFT_Stockham_R2C_C2R(float2* s_input) {
 // with 15 the in-LDS contract path measured 1-4 % SLOWER (the library's own persistent schedule gains 10-14 % from it).
 #define SMFFT_CONTRACT_ROTATE_PRIORITY 0
 #endif
-// SMFFT_CONTRACT_LANES_IO: in upstream's 32-thread blocks of N <= 128 the two-argument external kernel loads a thread's four
+// In upstream's 32-thread blocks of N <= 128 the two-argument external kernel loads a thread's four
 // elements from global memory straight into the lane-and-register ladder (QuarterLanes) and stores its four results from there:
 // no LDS at all (0.84 -> 0.91 of the tiled rate at N = 32 / 64, 0.71 -> 0.82 at N = 128).  Natural order: the lanes of a
 // transform store bit-reversed positions of a contiguous run of N/4 elements.  The 64-thread blocks of the _wave64 classes keep
 // fill / transform in LDS / drain on the LDS form of the ladder, which measured 3-6 % faster there (profiles/r04_contract_lanes.txt).
-#ifndef SMFFT_CONTRACT_LANES_IO
-#define SMFFT_CONTRACT_LANES_IO 1
-#endif
 template <class const_params>
 __global__ void SMFFT_DIT_external(float2* d_input, float2* d_output) {
-    if constexpr (SMFFT_CONTRACT_FUSED_IO && SMFFT_QUARTER_LANES != 0 &&
-                  ((SMFFT_CONTRACT_LANES_IO == 1 && const_params::fft_size <= 128 && const_params::fft_length_quarter == 32) || (SMFFT_CONTRACT_LANES_IO == 2 && const_params::fft_size <= 256))) {
+    if constexpr (SMFFT_CONTRACT_FUSED_IO && SMFFT_QUARTER_LANES != 0 && const_params::fft_size <= 128 && const_params::fft_length_quarter == 32) {
         constexpr int N = const_params::fft_size, Q = N / 4;
         using L = smfft::QuarterLanes<N, const_params::fft_direction, const_params::fft_reorder>;
         const int t = threadIdx.x % Q;
@@ -613,12 +592,9 @@ __global__ void SMFFT_DIT_external(float2* d_input, float2* d_output) {
     s_input[threadIdx.x + const_params::fft_length_half] = d_input[base + const_params::fft_length_half];
     s_input[threadIdx.x + const_params::fft_length_three_quarters] = d_input[base + const_params::fft_length_three_quarters];
     __syncthreads();
-#ifndef SMFFT_CONTRACT_WAVE64_EXTERNAL_ENGINE
-#define SMFFT_CONTRACT_WAVE64_EXTERNAL_ENGINE 1      // 1: the LDS form of the ladder between fill and drain (N <= 128); 0: do_SMFFT_CT_DIT's default
-#endif
-    if constexpr (const_params::fft_size <= 128 && SMFFT_CONTRACT_WAVE64_EXTERNAL_ENGINE != 0) {
+    if constexpr (const_params::fft_size <= 128) {     // the LDS form of the ladder between fill and drain (3-6 % faster there than do_SMFFT_CT_DIT's lane form)
         constexpr int N = const_params::fft_size;
-        smfft::quarter_fft_inplace<N, const_params::fft_direction, const_params::fft_reorder, const_params::fft_length / 4, SMFFT_CONTRACT_WAVE64_EXTERNAL_ENGINE>(s_input, threadIdx.x % (N / 4), (threadIdx.x / (N / 4)) * N);
+        smfft::quarter_fft_inplace<N, const_params::fft_direction, const_params::fft_reorder, const_params::fft_length / 4, 1>(s_input, threadIdx.x % (N / 4), (threadIdx.x / (N / 4)) * N);
     } else {
         do_SMFFT_CT_DIT<const_params>(s_input);
     }

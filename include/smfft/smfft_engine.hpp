@@ -60,18 +60,12 @@ struct Geometry {
     static constexpr bool kMultiWave = (T > 64);
     // N = 512 / 1024: exchange 1 is a transpose between the lane's row bits (lane >> 4) and the top
     // register-index bits, done in registers with v_permlane16_swap / v_permlane32_swap: no LDS.
-#ifndef SMFFT_NO_REG_X1
-#define SMFFT_NO_REG_X1 0
-#endif
-    static constexpr bool kRegExchange1 = !SMFFT_NO_REG_X1 && (RM == 2 || RM == 4);
+    static constexpr bool kRegExchange1 = (RM == 2 || RM == 4);
     // N <= 64 (two passes, an FFT is 2 or 4 lanes of one 16-lane row): the exchange between the passes -- and
     // the bit-reversal transposition of the no-reorder variants -- are transposes between the FFT's lane bits
     // and as many register-index bits, done in registers with DPP row operations: no LDS at all inside the
     // transform (measured on the in-LDS path: DESIGN.md section 5).
-#ifndef SMFFT_REG_TWOPASS_MAX_N
-#define SMFFT_REG_TWOPASS_MAX_N 64
-#endif
-    static constexpr bool kRegTwoPass = (RM == 1) && (N <= SMFFT_REG_TWOPASS_MAX_N);
+    static constexpr bool kRegTwoPass = (RM == 1) && (N <= 64);
     static constexpr int kFftsPerBlock = 4096 / N;        // tiled kernels: 256 threads own 4096 elements
     // compact kernels (the in-LDS `multiple` path): the smallest workgroup that holds whole FFTs --
     // one wave and 1024 elements for N <= 1024, N / 16 threads and one FFT above
@@ -118,20 +112,35 @@ __device__ __forceinline__ void gstore(float2* p, float2 a) {
 #endif
 }
 
+// Tile accesses of the in-LDS (`multiple`) kernels.  SHARED = the tile is handed from one workgroup of the launch to another (the
+// balanced schedule parks a cut chain in its slot of d_output): the stores are WRITE-THROUGH (`sc1`: the bytes leave the storing
+// XCD's L2, whose lines no other XCD can see) and the loads `sc1` global loads (never served by the loading CU's L1), so the
+// hand-over needs no cache-wide write-back or invalidate -- a workgroup's `buffer_wbl2` cost the README launches 10-90 us
+// (profiles/r05_handover_forms.txt).  Agent-scope relaxed atomics on global (address space 1) pointers are exactly those
+// instructions (MI355X_MICROARCH.md, inter-workgroup visibility: valid forms).
+typedef __attribute__((address_space(1))) unsigned long long global_u64;
+typedef __attribute__((address_space(1))) unsigned global_u32;
+template <bool SHARED>
+__device__ __forceinline__ float2 tile_load(const float2* p) {
+    if constexpr (SHARED) {
+        const unsigned long long x = __hip_atomic_load((const global_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_float2(__uint_as_float((unsigned)x), __uint_as_float((unsigned)(x >> 32)));
+    } else {
+        return *p;
+    }
+}
+template <bool SHARED>
+__device__ __forceinline__ void tile_store(float2* p, float2 v) {
+    if constexpr (SHARED) __hip_atomic_store((global_u64*)p, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 // W_N^m (forward sign) or its conjugate (inverse), from the fp64-rounded table.
-// SMFFT_TW_HW=1 (experiment): v_cos_f32 / v_sin_f32 on the exact fraction m/4096 (argument in
-// revolutions) instead of the table: no memory access, max error 1.2e-7 instead of 0.5 ulp.
-#ifndef SMFFT_TW_HW
-#define SMFFT_TW_HW 0
-#endif
+// (v_cos_f32 / v_sin_f32 on the exact fraction m/4096 instead of the table was tried in round 2: no memory access, but a
+//  maximum error of 1.2e-7 instead of 0.5 ulp -- profiles/HISTORY.md)
 template <int DIR>
 __device__ __forceinline__ float2 twiddle(int m_times_4096_over_N) {
-#if SMFFT_TW_HW
-    const float f = (float)(m_times_4096_over_N & 4095) * (1.0f / 4096.0f);
-    float2 w = make_float2(__builtin_amdgcn_cosf(f), -__builtin_amdgcn_sinf(f));
-#else
     float2 w = twiddle_4096[m_times_4096_over_N & 4095];
-#endif
     if (DIR) w.y = -w.y;
     return w;
 }
@@ -179,56 +188,24 @@ struct WavePriority {
     }
 };
 
-// Sixteen reads base[STRIDE * i].  SINGLE = false: plain C++, which hipcc merges pairwise into ds_read2_b64 -- half
-// the instructions, and measured faster wherever the merged accesses are conflict free (the natural-order loads and the
-// t-major last layout: N = 32, 64, 512, 1024 in-LDS path 10-20 % faster than single reads, profiles/r02_ab_mult.txt).
-// SINGLE = true: sixteen single ds_read_b64 off ONE address register with compile-time byte offsets, as one
-// inline-assembly block that ends with its own s_waitcnt (the compiler does not count inline-assembly DS operations).
-// For the layouts where a thread reads CONTIGUOUS elements of a padded row (the last pass of N = 128 / 256, the
-// bit-reversed rows of the no-reorder variants): merged into ds_read2_b64 those are served in 16-lane groups over 32
-// banks, where the 4-dword footprints of neighbouring rows overlap (2-way conflicts); single b64 reads over 64 banks
-// are conflict free (in-LDS path N = 128 / 256: +5-10 %).  SMFFT_SINGLE_READS = 0 / 2 force merged / single everywhere (A/B).
-#ifndef SMFFT_SINGLE_READS
-#define SMFFT_SINGLE_READS 1
-#endif
 // Sixteen single ds_read_b64 off ONE address register with compile-time float2 offsets OFF(k), issued in the order the
-// caller names (k = 0 .. 15 -> v[k]).  SMFFT_LDS_WAITS selects who waits for them:
-//   2 (default)  `volatile` 64-bit LDS loads: hipcc neither merges them into ds_read2_b64 nor reorders them, and -- unlike
-//                inline assembly -- COUNTS them, so it places a stepped s_waitcnt lgkmcnt(n) in front of the first use of
-//                each value: the first butterflies start while the later reads are still in flight;
-//   0            one inline-assembly block that ends in a blanket s_waitcnt lgkmcnt(0) (rounds 1-2; kept for the A/B).
-#ifndef SMFFT_LDS_WAITS
-#define SMFFT_LDS_WAITS 2
-#endif
+// caller names (k = 0 .. 15 -> v[k]).  For the layouts where a thread reads CONTIGUOUS elements of a padded row (the
+// bit-reversed rows of the no-reorder variants): merged into ds_read2_b64, as hipcc does with plain C++ loads, those are served
+// in 16-lane groups over 32 banks, where the 4-dword footprints of neighbouring rows overlap (2-way conflicts); single b64 reads
+// over 64 banks are conflict free.  They are `volatile` 64-bit LDS loads: hipcc neither merges them nor reorders them, and --
+// unlike inline assembly -- COUNTS them, so it places a stepped s_waitcnt lgkmcnt(n) in front of the first use of each value:
+// the first butterflies start while the later reads are still in flight (an inline-assembly block that ended in a blanket
+// s_waitcnt lgkmcnt(0) was rounds 1-2's form: profiles/r03_ab_step1.txt).
 template <class OFF>
 __device__ __forceinline__ void ds_read16_single(float2 (&v)[16], const float2* base) {
     typedef __attribute__((address_space(3))) const float2 lds_float2;
-#if SMFFT_LDS_WAITS == 2
     typedef __attribute__((address_space(3))) const volatile unsigned long long lds_u64;
     lds_u64* p = (lds_u64*)(lds_float2*)base;
-    unsigned long long w[16];
+    unsigned long long w[16];   // 64-bit integers, not <2 x float>: vector-typed results invite v_pk_add_f32 (half rate) downstream
 #pragma unroll
     for (int k = 0; k < 16; ++k) w[k] = p[OFF::at(k)];
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = make_float2(__uint_as_float((unsigned)w[k]), __uint_as_float((unsigned)(w[k] >> 32)));
-#else
-    const unsigned a = (unsigned)(unsigned long)(lds_float2*)base;
-    unsigned long long w[16];   // 64-bit integers, not <2 x float>: vector-typed results invite v_pk_add_f32 (half rate) downstream
-    asm volatile(
-        "ds_read_b64 %0, %16 offset:%17\n\tds_read_b64 %1, %16 offset:%18\n\tds_read_b64 %2, %16 offset:%19\n\tds_read_b64 %3, %16 offset:%20\n\t"
-        "ds_read_b64 %4, %16 offset:%21\n\tds_read_b64 %5, %16 offset:%22\n\tds_read_b64 %6, %16 offset:%23\n\tds_read_b64 %7, %16 offset:%24\n\t"
-        "ds_read_b64 %8, %16 offset:%25\n\tds_read_b64 %9, %16 offset:%26\n\tds_read_b64 %10, %16 offset:%27\n\tds_read_b64 %11, %16 offset:%28\n\t"
-        "ds_read_b64 %12, %16 offset:%29\n\tds_read_b64 %13, %16 offset:%30\n\tds_read_b64 %14, %16 offset:%31\n\tds_read_b64 %15, %16 offset:%32\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]),
-          "=&v"(w[8]), "=&v"(w[9]), "=&v"(w[10]), "=&v"(w[11]), "=&v"(w[12]), "=&v"(w[13]), "=&v"(w[14]), "=&v"(w[15])
-        : "v"(a), "n"(8 * OFF::at(0)), "n"(8 * OFF::at(1)), "n"(8 * OFF::at(2)), "n"(8 * OFF::at(3)), "n"(8 * OFF::at(4)), "n"(8 * OFF::at(5)),
-          "n"(8 * OFF::at(6)), "n"(8 * OFF::at(7)), "n"(8 * OFF::at(8)), "n"(8 * OFF::at(9)), "n"(8 * OFF::at(10)), "n"(8 * OFF::at(11)),
-          "n"(8 * OFF::at(12)), "n"(8 * OFF::at(13)), "n"(8 * OFF::at(14)), "n"(8 * OFF::at(15))
-        : "memory");
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = make_float2(__uint_as_float((unsigned)w[k]), __uint_as_float((unsigned)(w[k] >> 32)));
-#endif
 }
 
 // issue order of sixteen reads that feed B butterflies of radix R = 16 / B (decimation in time: the innermost radix-2
@@ -242,23 +219,13 @@ constexpr int dit_issue_slot(int k) {
     return b * R + rev;
 }
 
+// Sixteen reads base[STRIDE * i]: plain C++, which hipcc merges pairwise into ds_read2_b64 -- half the instructions, and
+// measured faster wherever the merged accesses are conflict free (the natural-order loads and the t-major last layout,
+// profiles/r02_ab_mult.txt).
 template <int STRIDE>
-struct StridedOffsets {
-    static constexpr int at(int k) { return STRIDE * dit_issue_slot<16>(k); }
-};
-
-template <int STRIDE, bool SINGLE>
 __device__ __forceinline__ void lds_read16(float2 (&r)[16], const float2* base) {
-  if constexpr ((SINGLE && SMFFT_SINGLE_READS != 0) || SMFFT_SINGLE_READS == 2) {
-    static_assert(8 * STRIDE * 15 < 65536, "DS offset field is 16 bits");
-    float2 v[16];
-    ds_read16_single<StridedOffsets<STRIDE>>(v, base);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) r[dit_issue_slot<16>(k)] = v[k];
-  } else {
 #pragma unroll
     for (int i = 0; i < 16; ++i) r[i] = base[STRIDE * i];
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -289,14 +256,11 @@ struct SmallDft {
         SmallDft<R / 2, 2 * STRIDE, DIR, TAN>::run(in + STRIDE, o);
         combine<0>(e, o, out);
     }
-#ifndef SMFFT_TAN_BUTTERFLY
-#define SMFFT_TAN_BUTTERFLY 1
-#endif
     template <int K>
     __device__ static __forceinline__ void combine(const float2* e, const float2* o, float2* out) {
         if constexpr (K < R / 2) {
             constexpr int IDX = K * (16 / R);
-            if constexpr (SMFFT_TAN_BUTTERFLY && TAN && (IDX & 1)) {
+            if constexpr (TAN && (IDX & 1)) {
                 // e +- W*o with W = wr * (1 + i*tn): two multiply-adds for u = o * (1 + i*tn), four for e +- wr*u -- six
                 // instructions where product, sum and difference take eight (the odd powers of W_16 only: the others are
                 // cheaper still as they are).  16 instructions fewer per N = 1024 FFT; in-LDS path N >= 256 +0.5-2.5 %,
@@ -359,16 +323,6 @@ struct Twiddles {
         return make_float2(v.x, DIR ? -v.y : v.y);
     }
     __device__ __forceinline__ void init(int u, int t2) {
-#if SMFFT_TW_HW
-#pragma unroll
-        for (int b = 0; b < G::B1; ++b)
-#pragma unroll
-            for (int q1 = 1; q1 < G::R1; ++q1) w1[b * G::R1 + q1] = twiddle<DIR>((u + G::T * b) * q1 * (4096 / N));
-        if constexpr (G::RM > 1) {
-#pragma unroll
-            for (int q2 = 1; q2 < G::RM; ++q2) wm[q2] = twiddle<DIR>(t2 * q2 * (4096 / G::T1));
-        }
-#else
 #pragma unroll
         for (int b = 0; b < G::B1; ++b)
 #pragma unroll
@@ -377,7 +331,6 @@ struct Twiddles {
 #pragma unroll
             for (int q2 = 1; q2 < G::RM; ++q2) wm[q2] = from_row(&twiddle_rows<N>.wm[q2 * 16 + t2]);
         }
-#endif
     }
 };
 
@@ -391,11 +344,8 @@ struct Engine {
     static constexpr int S1 = G::S1, S2 = G::S2, S0 = G::S0, SF = G::SF;
     static constexpr int E_BITS = ilog2c(N), T_BITS = ilog2c(T), R1_BITS = ilog2c(R1), B1_BITS = ilog2c(B1);
 
-#ifndef SMFFT_ROW_TOP_LANES
-#define SMFFT_ROW_TOP_LANES 1
-#endif
     // physical lane bit of thread bit i of a register-two-pass FFT
-    static constexpr int kLaneShift = (SMFFT_ROW_TOP_LANES && G::kRegTwoPass) ? 4 - T_BITS : 0;
+    static constexpr int kLaneShift = G::kRegTwoPass ? 4 - T_BITS : 0;
 
     int u;        // thread inside the FFT
     int fft;      // FFT inside the workgroup
@@ -406,7 +356,6 @@ struct Engine {
     __device__ __forceinline__ void init(int tid) {
         u = tid % T;
         fft = tid / T;
-#if SMFFT_ROW_TOP_LANES
         if constexpr (G::kRegTwoPass) {
             // the FFT's threads are the TOP log2(T) bits of the position inside a 16-lane row, so that the
             // DPP transposes select their lanes with the bank mask (lane bits 2, 3) wherever possible;
@@ -415,7 +364,6 @@ struct Engine {
             u = (lane >> kLaneShift) & (T - 1);
             fft = (tid >> 6) * (64 / T) + (lane >> 4) * (16 / T) + (lane & ((1 << kLaneShift) - 1));
         }
-#endif
         t2 = u & 15;
         a = u >> 4;
         // REORDER: role = lane.  No reorder: the thread with role t1 reads row rev_T(t1) of the
@@ -443,11 +391,7 @@ struct Engine {
 #pragma unroll
         for (int c = 0; c < 16; ++c) r[c] = gload(g + u + T * c);
     }
-    // SINGLE_OK: the caller is an in-LDS kernel, where single reads measured +4-10 % at the two-pass lengths N = 128 / 256
-    // (profiles/r02_ab_reads.txt); the HBM-bound external kernels keep the merged reads (their R2C form of real N = 512
-    // lost 4.6 % with single ones, profiles/r02_ab_ext_pair.txt)
-    template <bool SINGLE_OK = false>
-    __device__ __forceinline__ void load_lds(float2 (&r)[16], const float2* sf) const { lds_read16<T, SINGLE_OK && (N == 128 || N == 256)>(r, sf + u); }
+    __device__ __forceinline__ void load_lds(float2 (&r)[16], const float2* sf) const { lds_read16<T>(r, sf + u); }
 
     // ---- natural registers -> pass-1 slots r[b*R1 + r1] = x'[t1 + T1*r1], t1 = u + T*b ------------
     // REORDER: x' = x, and t1 + T1*r1 = u + T*(b + B1*r1): a compile-time renaming of registers.
@@ -590,41 +534,32 @@ struct Engine {
             for (int r2 = 0; r2 < RM; ++r2) r[c * RM + r2] = t[BM * r2 + c];
     }
 
-    // The same one-bit transpose for lane bits 0..3 (inside a 16-lane row) with DPP: lanes with the bit clear
-    // send B and receive the partner's A into B, lanes with it set send A and receive the partner's B into A.  Bits 2 and 3 select the
-    // receiving lanes with the DPP bank mask (a bank = 4 lanes of a row): two v_mov_b32_dpp per dword pair;
-    // bits 0 and 1 (partner inside the quad) need a lane predicate: select, quad_perm move, two selects.
+    // The same one-bit transpose for lane bits 2 and 3 (inside a 16-lane row) with DPP: lanes with the bit clear send B and
+    // receive the partner's A into B, lanes with it set send A and receive the partner's B into A.  The receiving lanes are
+    // selected with the DPP bank mask (a bank = 4 lanes of a row): two v_mov_b32_dpp per dword pair.
     template <int LANE_BIT>
-    __device__ static __forceinline__ void swap_bit_dpp_dword(float& A, float& B, bool hi) {
+    __device__ static __forceinline__ void swap_bit_dpp_dword(float& A, float& B, bool) {
+        static_assert(LANE_BIT == 2 || LANE_BIT == 3, "bits 0 / 1: swap_bit_quad");
         const int a = __float_as_int(A), b = __float_as_int(B);
         int na, nb;
         if constexpr (LANE_BIT == 2) {
             na = __builtin_amdgcn_update_dpp(a, b, 0x114 /* row_shr:4 */, 0xF, 0xA, false);   // banks 1,3 <- B of lane-4
             nb = __builtin_amdgcn_update_dpp(b, a, 0x104 /* row_shl:4 */, 0xF, 0x5, false);   // banks 0,2 <- A of lane+4
-        } else if constexpr (LANE_BIT == 3) {
+        } else {
             na = __builtin_amdgcn_update_dpp(a, b, 0x128 /* row_ror:8 */, 0xF, 0xC, false);   // lanes 8..15 <- B of lane^8
             nb = __builtin_amdgcn_update_dpp(b, a, 0x128, 0xF, 0x3, false);                    // lanes 0..7  <- A of lane^8
-        } else {
-            const int send = hi ? a : b;   // the partner keeps its own half and takes the other one from here
-            const int recv = __builtin_amdgcn_update_dpp(send, send, LANE_BIT == 0 ? 0xB1 /* quad_perm [1,0,3,2] */ : 0x4E /* [2,3,0,1] */, 0xF, 0xF, false);
-            na = hi ? recv : a;
-            nb = hi ? b : recv;
         }
         A = __int_as_float(na);
         B = __int_as_float(nb);
     }
-    // The same transpose for lane bits 0 / 1 on a float2 pair in FOUR instructions instead of eight: v_cndmask_b32 takes its first
+    // Lane bits 0 / 1 (partner inside the quad) on a float2 pair in FOUR instructions: v_cndmask_b32 takes its first
     // source through DPP, so "keep mine or take the partner's" is one instruction per dword and side -- hipcc does not fold the
-    // quad-perm move into the select (it emits v_mov_b32_dpp + v_cndmask_b32), hence the inline assembly.  The lane masks are
+    // quad-perm move into the select (it emits v_mov_b32_dpp + v_cndmask_b32: eight), hence the inline assembly.  The lane masks are
     // constants because every transform's lanes start at a multiple of their count.  s_nop 1: the two wait states a DPP read
     // needs after a VALU write of the same register (the assembler does not see into the block).
-#ifndef SMFFT_QUAD_SWAP_ASM
-#define SMFFT_QUAD_SWAP_ASM 1
-#endif
     template <int LANE_BIT>
     __device__ static __forceinline__ void swap_bit_quad(float2& A, float2& B, bool hi) {
         static_assert(LANE_BIT == 0 || LANE_BIT == 1, "inside a quad");
-#if SMFFT_QUAD_SWAP_ASM
         constexpr unsigned long long lo = LANE_BIT == 0 ? 0x5555555555555555ull : 0x3333333333333333ull;   // lanes with the bit clear
         float nax, nay, nbx, nby;
         if constexpr (LANE_BIT == 0) {
@@ -647,10 +582,6 @@ struct Engine {
         A = make_float2(nax, nay);     // lanes with the bit clear keep A; the others take the partner's B
         B = make_float2(nbx, nby);     // lanes with the bit set keep B; the others take the partner's A
         (void)hi;
-#else
-        swap_bit_dpp_dword<LANE_BIT>(A.x, B.x, hi);
-        swap_bit_dpp_dword<LANE_BIT>(A.y, B.y, hi);
-#endif
     }
     // all 8 register pairs (c, c | 1 << reg_bit), c with that bit clear
     __device__ __forceinline__ void swap_lane_bit_with_register_bit(float2 (&r)[16], int lane_bit, int reg_bit) const {
@@ -727,11 +658,10 @@ struct Engine {
     }
 
     // ---- last pass: one radix-16 butterfly per thread; r[q3] = X[u + T*q3] -----------------------
-    template <bool SINGLE_OK = false>
     __device__ __forceinline__ void last(float2 (&r)[16], const float2* sf) const {
         float2 x[16];
-        if constexpr (RM > 1) lds_read16<S2, false>(x, sf + u);
-        else lds_read16<1, SINGLE_OK>(x, sf + u * S0);
+        if constexpr (RM > 1) lds_read16<S2>(x, sf + u);
+        else lds_read16<1>(x, sf + u * S0);
         SmallDft<16, 1, DIR>::run(x, r);
     }
 
@@ -750,13 +680,11 @@ struct Engine {
     // registers (natural order, r[c] = x[u + T*c]) -> registers (r[q] = X[u + T*q]) through the
     // FFT's LDS region.
     // Precondition: every earlier LDS access of this FFT's region has been ordered by fft_sync.
-    template <bool SINGLE_OK = false>
     __device__ __forceinline__ void transform(float2 (&r)[16], float2* sf) const {
         to_pass1_layout(r, sf);
-        transform_from_pass1_slots<SINGLE_OK>(r, sf);
+        transform_from_pass1_slots(r, sf);
     }
     // the transform of registers that already hold the pass-1 slots (after to_pass1_layout or bitrev_read)
-    template <bool SINGLE_OK = false>
     __device__ __forceinline__ void transform_from_pass1_slots(float2 (&r)[16], float2* sf) const {
         pass1(r);
         if constexpr (G::kRegTwoPass) {
@@ -772,7 +700,7 @@ struct Engine {
             fft_sync<G::kMultiWave>();
         }
         middle(r, sf);
-        last<SINGLE_OK>(r, sf);
+        last(r, sf);
     }
 };
 

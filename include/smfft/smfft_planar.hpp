@@ -81,12 +81,6 @@ constexpr RowTable place_rows(int tw, int q0, int q1, int q2, int q3, int q4, in
     return t;
 }
 constexpr int bit_of(int j, int b) { return (j >> b) & 1; }
-// N = 512 natural order with exchange 1 through LDS like the longer lengths instead of sixteen v_permlane16_swap (A/B switch;
-// tools/soa_model.py 512: its reads are conflict free with the residues below; the no-reorder variant's last reads are not)
-#ifndef SMFFT_PLANAR_512_LDS_X1
-#define SMFFT_PLANAR_512_LDS_X1 0
-#endif
-constexpr bool planar_512_lds_x1(int n, int reorder) { return SMFFT_PLANAR_512_LDS_X1 != 0 && n == 512 && reorder; }
 // residue of row j as a function of (j's bits): the tables of tools/soa_model.py in closed form
 enum class RowKind { image, x1, x2 };
 template <int N, int REORDER>
@@ -95,13 +89,13 @@ constexpr int row_residue(RowKind kind, int j) {
         case RowKind::image:    // read by the bit-reversed loads of the no-reorder variants (lane linear in the reorder variants)
             return N == 32 ? 8 * bit_of(j, 3) : N == 64 ? 4 * (j >> 2) : N == 128 ? bit_of(j, 2) + 8 * bit_of(j, 3) : N == 256 ? j : N == 512 ? bit_of(j, 0) + 2 * bit_of(j, 2) + 8 * bit_of(j, 3) : N == 4096 ? 4 * bit_of(j, 3) : (j >> 2);
         case RowKind::x1:       // after pass 1 (three-pass lengths)
-            return N == 2048 ? bit_of(j, 1) : N == 4096 ? 2 * bit_of(j, 0) : planar_512_lds_x1(N, REORDER) ? 8 * (1 - bit_of(j, 3)) : 0;  // (N = 512 exchanges in registers)
+            return N == 2048 ? bit_of(j, 1) : N == 4096 ? 2 * bit_of(j, 0) : 0;  // (N = 512 exchanges in registers)
         default:                // in front of the last pass
             if (N == 32) return 8 * bit_of(j, 0);
             if (N == 64) return 4 * (j & 3);
             if (N == 128) return bit_of(j, 0) + 8 * bit_of(j, 1);
             if (N == 256) return (j & 3) + 8 * bit_of(j, 3);
-            if ((REORDER && (N != 512 || planar_512_lds_x1(N, REORDER))) || N == 4096) return (j & 3) + 8 * bit_of(j, 3);   // klow = pass-1 role
+            if ((REORDER && N != 512) || N == 4096) return (j & 3) + 8 * bit_of(j, 3);   // klow = pass-1 role
             return N == 512 ? bit_of(j, 0) + 2 * bit_of(j, 1) + 8 * bit_of(j, 2) : N == 1024 ? (j >> 2) : bit_of(j, 0) + 2 * bit_of(j, 3);
     }
 }
@@ -155,8 +149,9 @@ struct PlanarEngine {
     static constexpr int T_BITS = ilog2c(T), R1_BITS = ilog2c(R1), B1_BITS = ilog2c(B1), RM_BITS = ilog2c(RM);
     static constexpr bool kThreePass = RM > 1;
     // N = 512 (RM = 2): exchange 1 moves data between two threads only -- sixteen v_permlane16_swap (Engine::exchange1_registers)
-    // measured faster than a third trip through LDS (profiles/r03_ab_planar_all.txt); its roles are the register engine's (t1 = v)
-    static constexpr bool kRegisterX1 = (RM == 2) && !planar_512_lds_x1(N, REORDER);
+    // measured faster than a third trip through LDS (profiles/r03_ab_planar_all.txt, r04_ab_512_lds_x1.txt); its roles are the
+    // register engine's (t1 = v)
+    static constexpr bool kRegisterX1 = (RM == 2);
     // N = 4096 (RM = 16: sixteen consecutive threads share t2, so eight lanes of a ds_read_b128 group would read blocks of ONE
     // row -- 2-way conflicts no row shift can undo; round 3's first form had them on three reads, 384 of 1541 LDS cycles per FFT):
     //  * exchange 1: a lane reads the four quads of its run in an order rotated by rot = t2 >> 3.  Its registers then hold the
@@ -430,48 +425,8 @@ struct PlanarEngine {
         const float2 w = twiddle<DIR>(klow * (4096 / (2 * N)));
         herm_w = DIR ? make_float2(-0.5f * w.y, 0.5f * w.x) : make_float2(0.5f * w.y, -0.5f * w.x);
     }
-    __device__ __forceinline__ void hermitian_apply(float2 (&r)[16], const float* planes) const {
-        constexpr float c32[16] = {1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f, 0.55557023301960229f,
-                                   0.38268343236508984f, 0.19509032201612833f, 0.f, -0.19509032201612819f, -0.38268343236508973f, -0.55557023301960196f,
-                                   -0.70710678118654746f, -0.83146961230254535f, -0.92387953251128674f, -0.98078528040323043f};
-        constexpr float s32[16] = {0.f, 0.19509032201612825f, 0.38268343236508978f, 0.55557023301960218f, 0.70710678118654746f, 0.83146961230254524f,
-                                   0.92387953251128674f, 0.98078528040323043f, 1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254546f,
-                                   0.70710678118654757f, 0.55557023301960218f, 0.38268343236508989f, 0.19509032201612861f};
-        const float* p = planes + off_partner;
-        float2 w = herm_w;
-        asm volatile("" : "+v"(w.x), "+v"(w.y));     // the fifteen products W_2L^i are recomputed per application, not kept in 30 registers
-        auto partner = [&](int q, float2 own) {      // B = x[L - i] for register q
-            const float2 fetched = make_float2(p[P::image_row(15 - q)], p[P::kPlane + P::image_row(15 - q)]);
-            return herm_first ? own : fetched;
-        };
-        auto combine = [&](int q, float2 A, float2 B) {
-            const float2 S = make_float2(A.x + B.x, A.y - B.y);
-            const float2 D = make_float2(A.x - B.x, A.y + B.y);
-            const float2 V = (q == 0) ? w : cmul(w, make_float2(c32[q], DIR ? s32[q] : -s32[q]));
-            return make_float2(fmaf(V.x, D.x, fmaf(-V.y, D.y, 0.5f * S.x)), fmaf(V.x, D.y, fmaf(V.y, D.x, 0.5f * S.y)));
-        };
-        // In place, two partners in flight at a time (the kernels live on their occupancy: all sixteen partners fetched at
-        // once took 139-157 registers = 3 waves per SIMD).  Role 0 pairs register q with its OWN register 16 - q, so the
-        // registers are walked in the pairs (q, 16 - q), both combined from the original values.
-        {
-            const float2 A = r[0], B = partner(0, r[0]);
-            const float2 packed = DIR ? make_float2(0.5f * (A.x + A.y), 0.5f * (A.x - A.y)) : make_float2(A.x + A.y, A.x - A.y);
-            const float2 out = combine(0, A, B);
-            r[0] = herm_first ? packed : out;
-            r[8] = combine(8, r[8], partner(8, r[8]));
-        }
-#pragma unroll
-        for (int q = 1; q < 8; ++q) {
-            asm volatile("" ::: "memory");           // keeps the loads of the next pair behind the arithmetic of this one
-            const float2 A = r[q], A2 = r[16 - q];
-            const float2 B = partner(q, A2), B2 = partner(16 - q, A);
-            r[q] = combine(q, A, B);
-            r[16 - q] = combine(16 - q, A2, B2);
-        }
-    }
-
-    // ---- the same split / merge PAIR-WISE (round 4) ------------------------------------------------------------------
-    // out[i] = S/2 + V*D and out[L - i] = conj(S - out[i]) come from ONE S, D and V: 16 instructions per pair instead of 28.
+    // PAIR-WISE: out[i] = S/2 + V*D and out[L - i] = conj(S - out[i]) come from ONE S, D and V: 16 instructions per pair (two separate
+    // evaluations took 28: round 3's form, profiles/r04_ab_rc_pairs.txt).
     // A thread takes the pairs of its registers q = 0..7 (i = klow + T*q); the partner x[L - i] is register 15 - q of the
     // thread with role T - klow, so the registers 8..15 of every thread are somebody else's second halves:
     //   precondition  rows 8..15 of the image hold every thread's registers 8..15 (image_store_upper, or the loaded tile);
@@ -497,7 +452,7 @@ struct PlanarEngine {
         const float2 r8 = r[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            if ((q & 1) == 0) asm volatile("" ::: "memory");   // two partners in flight at a time (occupancy: see hermitian_apply)
+            if ((q & 1) == 0) asm volatile("" ::: "memory");   // two partners in flight at a time (the kernels live on their occupancy: all at once took 139-157 registers = 3 waves per SIMD)
             const float2 fetched = make_float2(p[P::image_row(15 - q)], p[P::kPlane + P::image_row(15 - q)]);
             const float2 own = q == 0 ? r8 : r[16 - q];
             const float2 A = r[q], B = herm_first ? own : fetched;
@@ -526,52 +481,17 @@ struct PlanarEngine {
     }
 };
 
-// ------------------------------------------------------------------------------------------------
-// TWO VIRTUAL THREADS PER LANE (round 4; the in-LDS kernels of N = 2048 / 4096).  The engine above gives a thread sixteen elements,
-// so N = 2048 / 4096 take two / four waves and pay five to six workgroup barriers per application (SQ_WAIT_ANY 21 % / 15 % of
-// the wave cycles).  Here a lane stands in for the threads tid and tid + TW/2 -- two PlanarEngine objects with their own roles,
-// offsets and pass-1 twiddles (the middle twiddles depend on t2 only and are the same) -- and runs every phase for both:
-// N = 2048 lives in ONE wave (no barrier anywhere, as N <= 1024), N = 4096 in two.  The LDS images, the store rows
-// (ds_write_addtid_b32 with the other virtual wave's base in M0) and every result are exactly the sixteen-elements-per-thread
-// engine's; the phases of the two virtual threads are independent instruction streams the scheduler interleaves.
-// MULTI_WAVE: whether the PHYSICAL workgroup has more than one wave.
-template <bool MULTI_WAVE, int N, int DIR, int REORDER>
-__device__ __forceinline__ void transform2_from_pass1_slots(const PlanarEngine<N, DIR, REORDER>& ea, float2 (&ra)[16], const PlanarEngine<N, DIR, REORDER>& eb, float2 (&rb)[16],
-                                                            float* planes) {
-    using E = PlanarEngine<N, DIR, REORDER>;
-    static_assert(E::kThreePass && !E::kRegisterX1, "N = 2048 / 4096");
-    ea.pass1(ra);
-    eb.pass1(rb);
-    planar_sync<MULTI_WAVE>();          // every read of the previous image is done
-    ea.x1_store(ra);
-    eb.x1_store(rb);
-    planar_sync<MULTI_WAVE>();
-    ea.x1_load(ra, planes);
-    eb.x1_load(rb, planes);
-    ea.middle(ra);
-    eb.middle(rb);
-    planar_sync<MULTI_WAVE>();
-    ea.x2_store(ra);
-    eb.x2_store(rb);
-    planar_sync<MULTI_WAVE>();
-    float2 xa[16], xb[16];
-    ea.x2_load(xa, planes);
-    eb.x2_load(xb, planes);
-    SmallDft<16, 1, DIR>::run(xa, ra);
-    SmallDft<16, 1, DIR>::run(xb, rb);
-}
-
 // tile <-> planar image (once per tile): element e = fft * N + n of the tile, n = u + T*c, lies in row c at dword
 // fft * T + position(u); position(u) = u, or the position of the thread whose pass-1 role is u (reorder)
-// thread = threadIdx.x, or the index of the VIRTUAL thread this lane stands in for (the two-threads-per-lane kernels of N >= 2048)
-template <int N, int DIR, int REORDER>
-__device__ __forceinline__ void tile_to_planes(const float2* __restrict__ g, float* planes, long first_fft, long limit_fft, int thread = -1) {
+// (g is not __restrict__: a resumed piece of a cut chain reads what another workgroup of the same launch stored -- SHARED, see tile_load)
+template <int N, int DIR, int REORDER, bool SHARED = false>
+__device__ __forceinline__ void tile_to_planes(const float2* g, float* planes, long first_fft, long limit_fft) {
     using E = PlanarEngine<N, DIR, REORDER>;
     using P = PlanarGeometry<N, REORDER>;
     constexpr int T = E::T, TW = E::TW;
     // (opaque copy of the thread index: the sixteen addresses below are computed where they are used, once per chain, instead
     //  of being hoisted out of the loop over chains and kept in registers across the applications)
-    int tid = thread < 0 ? (int)threadIdx.x : thread;
+    int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
     float2 val[16];
     const bool full = first_fft + P::F <= limit_fft;
@@ -579,7 +499,7 @@ __device__ __forceinline__ void tile_to_planes(const float2* __restrict__ g, flo
     for (int c = 0; c < 16; ++c) {
         const int e = tid + TW * c;
         const bool ok = full || (first_fft + e / N < limit_fft);
-        const float2 t = g[ok ? e : 0];
+        const float2 t = tile_load<SHARED>(g + (ok ? e : 0));
         val[c] = ok ? t : make_float2(0.f, 0.f);
     }
 #pragma unroll
@@ -592,12 +512,12 @@ __device__ __forceinline__ void tile_to_planes(const float2* __restrict__ g, flo
         p[P::kPlane] = val[c].y;
     }
 }
-template <int N, int DIR, int REORDER>
-__device__ __forceinline__ void planes_to_tile(float2* __restrict__ g, const float* planes, long first_fft, long limit_fft, int thread = -1) {
+template <int N, int DIR, int REORDER, bool SHARED = false>
+__device__ __forceinline__ void planes_to_tile(float2* g, const float* planes, long first_fft, long limit_fft) {
     using E = PlanarEngine<N, DIR, REORDER>;
     using P = PlanarGeometry<N, REORDER>;
     constexpr int T = E::T, TW = E::TW;
-    int tid = thread < 0 ? (int)threadIdx.x : thread;
+    int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
     const bool full = first_fft + P::F <= limit_fft;
 #pragma unroll
@@ -607,7 +527,7 @@ __device__ __forceinline__ void planes_to_tile(float2* __restrict__ g, const flo
         const int pos = E::kForward ? E::position_of_role(u) : u;
         const float* p = planes + P::image_row(row) + f * T + pos;
         const float2 t = make_float2(p[0], p[P::kPlane]);
-        if (full || first_fft + f < limit_fft) g[e] = t;
+        if (full || first_fft + f < limit_fft) tile_store<SHARED>(g + e, t);
     }
 }
 

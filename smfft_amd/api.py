@@ -55,6 +55,9 @@ _SIGS = {
     "smfft_get_multiple_balance": (_i, []),
     "smfft_set_multiple_rotation": (None, [_i]),
     "smfft_get_multiple_rotation": (_i, []),
+    "smfft_set_handoff_wait_us": (None, [_i]),
+    "smfft_debug_delay_parking": (None, [_i, _i, _i]),
+    "smfft_schedule_buffers": (_i, [ctypes.POINTER(ctypes.c_int)]),
     "smfft_va_window": (_i, [ctypes.POINTER(_ull), ctypes.POINTER(_ull)]),
     "smfft_get_nreuses": (_i, []),
     "smfft_device_count": (_i, []),

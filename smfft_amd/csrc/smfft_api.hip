@@ -26,9 +26,9 @@ namespace {
 // prototypes (GPU_smFFT_4elements and friends included); a value a thread has not set falls back to the process default
 // (environment: SMFFT_DEVICE, SMFFT_GRID_CAP, SMFFT_PACING, read once).  The lanes of smfft_host_transform inherit the
 // state of the thread that called it (smfft_state.hpp).
-smfft::LaunchState g_defaults = {0, 12288, SMFFT_NREUSES, -1, 1, 15};   // 12288 workgroups per launch: grid-stride over tiles, 12 or 16
+smfft::LaunchState g_defaults = {0, 12288, SMFFT_NREUSES, -1, 1, 15, 1000, -1, 0, 0};   // 12288 workgroups per launch: grid-stride over tiles, 12 or 16
                                                                  // rounds of the 4 or 3 resident workgroups per CU (measured sweet spot)
-thread_local smfft::LaunchState t_state = {-1, smfft::kUnsetGridCap, 0, -2, -1, -1};
+thread_local smfft::LaunchState t_state = {-1, smfft::kUnsetGridCap, 0, -2, -1, -1, -1, -1, 0, 0};
 std::once_flag g_env_once;
 
 // launches may come from several host threads (per-GPU threads of a multi-GPU driver, the lanes of
@@ -40,6 +40,7 @@ void read_env() {
         if (const char* e = getenv("SMFFT_PACING")) g_defaults.pacing = atoi(e) > 0 ? atoi(e) : 0;
         if (const char* e = getenv("SMFFT_MULT_BALANCE")) g_defaults.balance = atoi(e) > 0 ? atoi(e) : 0;
         if (const char* e = getenv("SMFFT_PRIO_ROTATE")) g_defaults.rotate = atoi(e) > 0 ? atoi(e) : 0;
+        if (const char* e = getenv("SMFFT_HANDOFF_WAIT_US")) g_defaults.handoff_wait_us = atoi(e) > 0 ? atoi(e) : 0;
     });
 }
 int cur_device() { return t_state.device >= 0 ? t_state.device : g_defaults.device; }
@@ -48,6 +49,19 @@ int cur_nreuses() { return t_state.nreuses > 0 ? t_state.nreuses : g_defaults.nr
 int cur_rotate() { return t_state.rotate >= 0 ? t_state.rotate : g_defaults.rotate; }
 int cur_balance() { return t_state.balance >= 0 ? t_state.balance : g_defaults.balance; }
 int cur_pacing() { return t_state.pacing != -2 ? t_state.pacing : g_defaults.pacing; }   // -1: chosen per launch from the output buffer
+smfft::LaunchOptions cur_options(int pace) {
+    smfft::LaunchOptions o = {};
+    o.grid_cap = cur_grid_cap();
+    o.nreuses = cur_nreuses();
+    o.pace = pace;
+    o.balance = cur_balance();
+    o.rotate = cur_rotate();
+    o.handoff_wait_us = (unsigned)(t_state.handoff_wait_us >= 0 ? t_state.handoff_wait_us : g_defaults.handoff_wait_us);
+    o.delay_chain = t_state.delay_chain;
+    o.delay_ms = (unsigned)t_state.delay_ms;
+    o.delay_after_commit = t_state.delay_after_commit;
+    return o;
+}
 
 // count of FFT slots the `multiple` path touches (CT:669-683; ST:351; RC:438)
 int ct_multiple_slots(int FFT_size, int nFFTs) {
@@ -71,41 +85,41 @@ using smfft::launch_st;
 
 // returns -1 for an unsupported length (nothing launched), else the launch status
 int dispatch_ct(const float2* in, float2* out, int N, int count, int inverse, int reorder, int path, hipStream_t st) {
-    const int pace = pacing_for(out, c2c_pacing(N).ordinary, c2c_pacing(N).mixed);
+    const smfft::LaunchOptions opt = cur_options(pacing_for(out, c2c_pacing(N).ordinary, c2c_pacing(N).mixed));
     switch (N) {
-        case 32:   return launch_ct<32>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
-        case 64:   return launch_ct<64>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
-        case 128:  return launch_ct<128>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
-        case 256:  return launch_ct<256>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
-        case 512:  return launch_ct<512>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
-        case 1024: return launch_ct<1024>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
-        case 2048: return launch_ct<2048>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
-        case 4096: return launch_ct<4096>(in, out, count, inverse, reorder, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 32:   return launch_ct<32>(in, out, count, inverse, reorder, path, opt, st);
+        case 64:   return launch_ct<64>(in, out, count, inverse, reorder, path, opt, st);
+        case 128:  return launch_ct<128>(in, out, count, inverse, reorder, path, opt, st);
+        case 256:  return launch_ct<256>(in, out, count, inverse, reorder, path, opt, st);
+        case 512:  return launch_ct<512>(in, out, count, inverse, reorder, path, opt, st);
+        case 1024: return launch_ct<1024>(in, out, count, inverse, reorder, path, opt, st);
+        case 2048: return launch_ct<2048>(in, out, count, inverse, reorder, path, opt, st);
+        case 4096: return launch_ct<4096>(in, out, count, inverse, reorder, path, opt, st);
         default:   return -1;
     }
 }
 int dispatch_st(const float2* in, float2* out, int N, int count, int path, hipStream_t st) {
-    const int pace = pacing_for(out, c2c_pacing(N).ordinary, c2c_pacing(N).mixed);
+    const smfft::LaunchOptions opt = cur_options(pacing_for(out, c2c_pacing(N).ordinary, c2c_pacing(N).mixed));
     switch (N) {
-        case 32:   return launch_st<32>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
-        case 64:   return launch_st<64>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
-        case 128:  return launch_st<128>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
-        case 256:  return launch_st<256>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
-        case 512:  return launch_st<512>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
-        case 1024: return launch_st<1024>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
-        case 2048: return launch_st<2048>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
-        case 4096: return launch_st<4096>(in, out, count, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 32:   return launch_st<32>(in, out, count, path, opt, st);
+        case 64:   return launch_st<64>(in, out, count, path, opt, st);
+        case 128:  return launch_st<128>(in, out, count, path, opt, st);
+        case 256:  return launch_st<256>(in, out, count, path, opt, st);
+        case 512:  return launch_st<512>(in, out, count, path, opt, st);
+        case 1024: return launch_st<1024>(in, out, count, path, opt, st);
+        case 2048: return launch_st<2048>(in, out, count, path, opt, st);
+        case 4096: return launch_st<4096>(in, out, count, path, opt, st);
         default:   return -1;
     }
 }
 // FFT_size is the REAL length; the kernels are instantiated on the complex length L = FFT_size/2 (RC:404-428)
 int dispatch_rc(const float2* in, float2* out, int FFT_size, int count, int inverse, int path, hipStream_t st) {
-    const int pace = pacing_for(out, rc_pacing(FFT_size / 2).ordinary, rc_pacing(FFT_size / 2).mixed);
+    const smfft::LaunchOptions opt = cur_options(pacing_for(out, rc_pacing(FFT_size / 2).ordinary, rc_pacing(FFT_size / 2).mixed));
     switch (FFT_size) {
-        case 512:  return launch_rc<256>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
-        case 1024: return launch_rc<512>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
-        case 2048: return launch_rc<1024>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
-        case 4096: return launch_rc<2048>(in, out, count, inverse, path, cur_grid_cap(), cur_nreuses(), pace, cur_balance(), cur_rotate(), st);
+        case 512:  return launch_rc<256>(in, out, count, inverse, path, opt, st);
+        case 1024: return launch_rc<512>(in, out, count, inverse, path, opt, st);
+        case 2048: return launch_rc<1024>(in, out, count, inverse, path, opt, st);
+        case 4096: return launch_rc<2048>(in, out, count, inverse, path, opt, st);
         default:   return -1;
     }
 }
@@ -163,11 +177,16 @@ LaunchState get_thread_state() { return t_state; }
 void set_thread_state(const LaunchState& s) { t_state = s; }
 
 // ---- host side of the multiple paths' balanced schedule (smfft_kernels.hpp, MultipleSchedule) -----------------------------
-// Workgroups of `kernel` that the device holds at once, from the kernel's own resources and the CU's (MI355X_MICROARCH.md):
-// 512 vector registers per SIMD lane, handed out in blocks of 8 per wave; at most 8 waves per SIMD; 160 KiB of LDS per CU.
-// (hipOccupancyMaxActiveBlocksPerMultiprocessor counts the LDS only: it answered 19 per CU for a 126-register single-wave
-//  kernel of which 16 run -- workgroup traces, profiles/r04_workgroup_trace.txt; tests/test_gpu_parity.py checks this function
-//  against smfft_measure_multiple_residency, which counts the workgroups that are alive at once, for every kernel.)
+// Workgroups of `kernel` that the device holds at once, from the kernel's own resources and the CU's: the vector registers of a
+// SIMD lane (handed out to a wave in blocks), the wave slots of a SIMD, the LDS of a CU.  The register file is not a device
+// attribute, so it is a table by architecture (MI355X_MICROARCH.md: gfx950 -- 512 registers per lane in blocks of 8, 8 wave slots
+// per SIMD); the LDS comes from the device.  On an architecture the table does not know the answer is 0 and the multiple paths run
+// one chain per workgroup (nothing is assumed about a device nobody has counted on).  hipOccupancyMaxActiveBlocksPerMultiprocessor
+// counts the LDS only -- it answered 19 per CU for a 126-register single-wave kernel of which 16 run (profiles/r04_workgroup_trace.txt)
+// -- so it serves as an upper bound here; tests/test_gpu_parity.py checks this function against smfft_measure_multiple_residency,
+// which COUNTS the workgroups that are alive at once, for every kernel.  (numRegs counts the arch VGPRs; none of the kernels uses AGPRs.)
+struct RegisterFile { const char* arch; int per_lane, granule, wave_slots; };
+static const RegisterFile kRegisterFiles[] = {{"gfx950", 512, 8, 8}, {"gfx942", 512, 8, 8}, {"gfx90a", 512, 8, 8}};
 int resident_workgroups(const void* kernel, int threads) {
     static std::mutex mutex;
     static std::map<std::pair<const void*, int>, int> known;      // (kernel, device) -> workgroups
@@ -176,23 +195,30 @@ int resident_workgroups(const void* kernel, int threads) {
     std::lock_guard<std::mutex> lock(mutex);
     auto it = known.find({kernel, device});
     if (it != known.end()) return it->second;
+    int result = 0;
     hipFuncAttributes attr = {};
-    int cus = 0, result = 0;
-    if (hipFuncGetAttributes(&attr, kernel) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && attr.numRegs > 0) {
-        const int regs = (attr.numRegs + 7) / 8 * 8;
-        int waves_per_simd = 512 / regs;
-        if (waves_per_simd > 8) waves_per_simd = 8;
+    hipDeviceProp_t prop = {};
+    const RegisterFile* rf = nullptr;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+        for (const RegisterFile& r : kRegisterFiles)
+            if (strncmp(prop.gcnArchName, r.arch, strlen(r.arch)) == 0) rf = &r;
+    int lds_per_cu = 0, by_runtime = 0;
+    if (rf && hipFuncGetAttributes(&attr, kernel) == hipSuccess && attr.numRegs > 0 && prop.multiProcessorCount > 0 &&
+        hipDeviceGetAttribute(&lds_per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) == hipSuccess && lds_per_cu > 0) {
+        const int regs = (attr.numRegs + rf->granule - 1) / rf->granule * rf->granule;
+        int waves_per_simd = rf->per_lane / regs;
+        if (waves_per_simd > rf->wave_slots) waves_per_simd = rf->wave_slots;
         const int waves_per_wg = (threads + 63) / 64;
         int per_cu = waves_per_simd * 4 / waves_per_wg;
         if (attr.sharedSizeBytes > 0) {
-            const int by_lds = (int)((160u << 10) / attr.sharedSizeBytes);
+            const int by_lds = (int)((size_t)lds_per_cu / attr.sharedSizeBytes);
             if (by_lds < per_cu) per_cu = by_lds;
         }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&by_runtime, kernel, threads, 0) == hipSuccess && by_runtime > 0 && by_runtime < per_cu) per_cu = by_runtime;
         if (per_cu > 32) per_cu = 32;
-        result = per_cu * cus;
-    } else {
-        (void)hipGetLastError();
+        result = per_cu * prop.multiProcessorCount;
     }
+    (void)hipGetLastError();
     return known[{kernel, device}] = result;
 }
 thread_local unsigned* t_residency_probe = nullptr;
@@ -200,24 +226,75 @@ thread_local int t_last_slots = 0;
 void note_resident_workgroups(int slots) { t_last_slots = slots; }
 int last_noted_slots() { return t_last_slots; }
 unsigned* residency_probe() { return t_residency_probe; }
-unsigned* schedule_flags(int nchains, hipStream_t stream, unsigned* epoch) {
-    struct Entry { unsigned* flags = nullptr; int capacity = 0; unsigned epoch = 0; };
-    static std::mutex mutex;
-    static std::map<std::pair<int, hipStream_t>, Entry> entries;
+
+// The hand-over words of the balanced launches: a pool of fixed-size buffers per device.  A launch takes one that no launch in
+// flight uses (its event has completed, or it has never been used), and gives it back by recording an event behind the kernel:
+// launches that can overlap -- other streams, hipStreamPerThread of other host threads, other host threads on the same stream --
+// never share words, nothing is keyed by a stream handle (which a destroyed stream's successor may reuse), and nothing in the
+// launch path frees memory.  The pool is bounded; when every buffer is in flight the launch runs unbalanced.
+struct ScheduleBuffer {
+    int device = -1;
+    unsigned* flags = nullptr;
+    unsigned epoch = 0;
+    hipEvent_t done = nullptr;
+    bool in_flight = false;      // an event has been recorded behind the last launch that used it
+    bool taken = false;          // between schedule_acquire and schedule_release
+};
+constexpr int kSchedulePool = 32;
+static std::mutex g_schedule_mutex;
+static ScheduleBuffer g_schedule_pool[kSchedulePool];
+unsigned* schedule_acquire(int nchains, hipStream_t stream, unsigned* base, int* ticket) {
+    *ticket = -1;
+    if (nchains > kScheduleMaxChains) return nullptr;
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    std::lock_guard<std::mutex> lock(mutex);
-    Entry& e = entries[{device, stream}];
-    if (e.capacity < nchains || e.epoch == 0xFFFFFFFFu) {
-        if (e.flags) (void)hipFree(e.flags);          // (waits for the launches that still use it)
-        e = Entry();
-        const int capacity = nchains < 8192 ? 8192 : nchains;
-        if (hipMalloc((void**)&e.flags, (size_t)capacity * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); e.flags = nullptr; return nullptr; }
-        if (hipMemsetAsync(e.flags, 0, (size_t)capacity * sizeof(unsigned), stream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(e.flags); e.flags = nullptr; return nullptr; }
-        e.capacity = capacity;
+    std::lock_guard<std::mutex> lock(g_schedule_mutex);
+    int chosen = -1, empty = -1;
+    for (int i = 0; i < kSchedulePool && chosen < 0; ++i) {
+        ScheduleBuffer& b = g_schedule_pool[i];
+        if (!b.flags) { if (empty < 0) empty = i; continue; }
+        if (b.device != device || b.taken) continue;
+        if (b.in_flight) {
+            const hipError_t q = hipEventQuery(b.done);
+            if (q == hipErrorNotReady) { (void)hipGetLastError(); continue; }
+            b.in_flight = false;                      // complete (or the event is unusable: the buffer is idle either way once the stream has drained)
+            (void)hipGetLastError();
+        }
+        chosen = i;
     }
-    *epoch = ++e.epoch;
-    return e.flags;
+    if (chosen < 0) {
+        if (empty < 0) return nullptr;
+        ScheduleBuffer& b = g_schedule_pool[empty];
+        if (hipMalloc((void**)&b.flags, (size_t)kScheduleMaxChains * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); b.flags = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess || hipMemsetAsync(b.flags, 0, (size_t)kScheduleMaxChains * sizeof(unsigned), stream) != hipSuccess) {
+            (void)hipGetLastError();
+            if (b.done) (void)hipEventDestroy(b.done);
+            (void)hipFree(b.flags);
+            b = ScheduleBuffer();
+            return nullptr;
+        }
+        b.device = device;
+        b.epoch = 0;
+        chosen = empty;
+    }
+    ScheduleBuffer& b = g_schedule_pool[chosen];
+    if (b.epoch >= (1u << 30) - 1u) {                 // 4 * epoch would wrap: start over (the buffer is idle; the memset is ordered in front of the kernel)
+        if (hipMemsetAsync(b.flags, 0, (size_t)kScheduleMaxChains * sizeof(unsigned), stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        b.epoch = 0;
+    }
+    b.taken = true;
+    *base = 4u * ++b.epoch;
+    *ticket = chosen;
+    return b.flags;
+}
+void schedule_release(int ticket, hipStream_t stream) {
+    if (ticket < 0 || ticket >= kSchedulePool) return;
+    std::lock_guard<std::mutex> lock(g_schedule_mutex);
+    ScheduleBuffer& b = g_schedule_pool[ticket];
+    // (if the event cannot be recorded the buffer counts as idle: its last launch is then ordered only by whoever synchronises the stream)
+    b.in_flight = hipEventRecord(b.done, stream) == hipSuccess;
+    if (!b.in_flight) (void)hipGetLastError();
+    b.taken = false;
 }
 }  // namespace smfft
 
@@ -461,6 +538,24 @@ void smfft_set_multiple_balance(int on) { t_state.balance = on < 0 ? -1 : on; }
 int smfft_get_multiple_balance(void) { read_env(); return cur_balance(); }
 void smfft_set_multiple_rotation(int log2_clocks) { t_state.rotate = log2_clocks < 0 ? -1 : log2_clocks; }
 int smfft_get_multiple_rotation(void) { read_env(); return cur_rotate(); }
+void smfft_set_handoff_wait_us(int microseconds) { t_state.handoff_wait_us = microseconds < 0 ? -1 : microseconds; }
+void smfft_debug_delay_parking(int chain, int milliseconds, int after_commit) {
+    t_state.delay_chain = milliseconds > 0 ? chain : -1;
+    t_state.delay_ms = milliseconds > 0 ? milliseconds : 0;
+    t_state.delay_after_commit = after_commit != 0;
+}
+int smfft_schedule_buffers(int* in_flight) {
+    std::lock_guard<std::mutex> lock(smfft::g_schedule_mutex);
+    int allocated = 0, busy = 0;
+    for (const smfft::ScheduleBuffer& b : smfft::g_schedule_pool) {
+        if (!b.flags) continue;
+        ++allocated;
+        if (b.taken || (b.in_flight && hipEventQuery(b.done) == hipErrorNotReady)) ++busy;
+    }
+    (void)hipGetLastError();
+    if (in_flight) *in_flight = busy;
+    return allocated;
+}
 // The most workgroups of the multiple kernel (family, FFT_size, inverse, reorder, path = 1 or 2) that are alive at once on the
 // current device, COUNTED: a launch of three times what any kernel's residency can be, 60 applications each, over scratch buffers,
 // with every workgroup incrementing a counter when it starts and decrementing it when it ends (workgroups of such a launch end and

@@ -22,65 +22,82 @@ namespace smfft {
 // grid cap.  Balanced (the default when the batch is more chains than the chip holds at once): a persistent grid of the
 // co-resident workgroups, each owning an equal share of the launch's ntiles * nreuses applications (MultipleSchedule).
 using CompactKernel = void (*)(const float2*, float2*, int, int, MultipleSchedule);
-static int launch_compact(CompactKernel kernel, const float2* d_input, float2* d_output, int count, int grid_cap, int nreuses, int balance, int rotate, hipStream_t stream,
-                          int threads = Geometry<SMFFT_N>::kCompactThreads) {
+static int launch_compact(CompactKernel kernel, const float2* d_input, float2* d_output, int count, const LaunchOptions& opt, hipStream_t stream) {
     using G = Geometry<SMFFT_N>;
+    constexpr int threads = G::kCompactThreads;
     const int ntiles = (count + G::kCompactFfts - 1) / G::kCompactFfts;
-    // (rotate: the waves' scheduling priority rotates every 2^15 shader clocks = 14 us by default; smfft_kernels.hpp, WavePriority;
+    const int nreuses = opt.nreuses, balance = opt.balance;
+    // (rotate: the waves' scheduling priority rotates every 2^15 shader clocks = 14 us by default; smfft_engine.hpp, WavePriority;
     //  sweep of the period: profiles/r04_priority_rotation.txt)
-    MultipleSchedule sch = {0, 0u, nullptr, rotate, nullptr, nullptr};
-    int grid = grid_for(count, G::kCompactFfts, grid_cap);
+    MultipleSchedule sch = {};
+    sch.rotate = opt.rotate;
+    sch.delay_chain = -1;
+    int grid = grid_for(count, G::kCompactFfts, opt.grid_cap);
     // Which schedule.  Up to four rounds' worth of chains: the balanced persistent grid (when there is
     // more than one round) and rotating priorities -- no tail, co-resident chains end together: +14-24 % on the README batches.
     // A long launch (more than four rounds) is in a steady state of its own: workgroups start whenever an older one ends, the
     // tail is a few percent, and there the persistent grid measured 0-7 % SLOWER (N = 2048 most): one chain per workgroup,
     // grid-strided, the arbiter's own order.  balance >= 2 (tests): that many workgroups, as if the chip held no more.
-    const int slots = balance >= 2 ? balance : resident_workgroups((const void*)kernel, threads);
+    // A caller who caps the grid below what the chip holds (to leave CUs to other work) keeps that cap: no persistent grid then.
+    const int resident = resident_workgroups((const void*)kernel, threads);
+    const int slots = balance >= 2 ? balance : resident;
     const bool short_launch = slots <= 0 || balance >= 2 || (long)ntiles <= 4l * slots;
+    const bool capped = balance < 2 && opt.grid_cap > 0 && opt.grid_cap < slots;
     if (!short_launch) sch.rotate = 0;
-    // a launch that is being CAPTURED into a graph keeps one chain per workgroup: the balanced grid's hand-off flags carry the
-    // epoch of one launch (a replayed graph would find them set), and their buffer may have to be allocated here
+    // a launch that is being CAPTURED into a graph keeps one chain per workgroup: the balanced grid's hand-over words carry the
+    // epoch of one launch (a replayed graph would find them set)
     hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
     if (stream != nullptr && hipStreamIsCapturing(stream, &capture) != hipSuccess) { (void)hipGetLastError(); capture = hipStreamCaptureStatusNone; }
-    if (balance && nreuses > 1 && short_launch && capture == hipStreamCaptureStatusNone) {
-        if (slots > 0 && ntiles > slots) {
-            const long total = (long)ntiles * nreuses;
-            const long per_wg = (total + slots - 1) / slots;            // > nreuses, so a chain straddles at most two workgroups
-            unsigned epoch = 0;
-            unsigned* flags = schedule_flags(ntiles, stream, &epoch);
-            if (flags && per_wg < (1l << 30)) {
-                sch.per_wg = (int)per_wg;
-                sch.epoch = epoch;
-                sch.flags = flags;
-                grid = (int)((total + per_wg - 1) / per_wg);
-            }
+    int ticket = -1;
+    unsigned base = 0;
+    unsigned* flags = nullptr;
+    const bool balanced = balance && nreuses > 1 && short_launch && !capped && capture == hipStreamCaptureStatusNone && slots > 0 && ntiles > slots && ntiles <= kScheduleMaxChains;
+    if (balanced) {
+        flags = schedule_acquire(ntiles, stream, &base, &ticket);
+        const long total = (long)ntiles * nreuses;
+        const long per_wg = (total + slots - 1) / slots;            // > nreuses, so a chain straddles at most two workgroups
+        if (flags && per_wg < (1l << 30)) {
+            sch.per_wg = (int)per_wg;
+            sch.base = base;
+            sch.flags = flags;
+            sch.wait_ticks = opt.handoff_wait_us * 100u;            // 100 MHz
+            sch.delay_chain = opt.delay_chain;
+            sch.delay_ticks = opt.delay_ms * 100000u;
+            sch.delay_after_commit = opt.delay_after_commit;
+            grid = (int)((total + per_wg - 1) / per_wg);
         }
     }
     sch.residency = residency_probe();
-    if (sch.residency) note_resident_workgroups(resident_workgroups((const void*)kernel, threads));          // non-null only inside smfft_measure_multiple_residency
+    if (sch.residency) note_resident_workgroups(resident);          // non-null only inside smfft_measure_multiple_residency
     static const bool debug = getenv("SMFFT_SCHEDULE_DEBUG") != nullptr;
     if (debug) printf("smfft multiple N=%d: %d chains x %d applications, %d co-resident workgroups (from the kernel's registers and LDS), grid %d, %d applications per workgroup%s\n", SMFFT_N, ntiles, nreuses,
-                      resident_workgroups((const void*)kernel, threads), grid, sch.per_wg, sch.per_wg ? "" : " (one chain at a time)");
+                      resident, grid, sch.per_wg, sch.per_wg ? "" : " (one chain at a time)");
     static const char* trace_file = getenv("SMFFT_SCHEDULE_TRACE");          // experiments: one line per workgroup of the LAST launch
-    if (trace_file && hipMalloc((void**)&sch.trace, (size_t)grid * 32) != hipSuccess) sch.trace = nullptr;
+    if (trace_file && (hipMalloc((void**)&sch.trace, (size_t)grid * kTraceWords * 8) != hipSuccess || hipMemset(sch.trace, 0, (size_t)grid * kTraceWords * 8) != hipSuccess)) sch.trace = nullptr;
     kernel<<<dim3(grid), dim3(threads), 0, stream>>>(d_input, d_output, count, nreuses, sch);
+    const int rc = (int)hipGetLastError();
+    if (ticket >= 0) schedule_release(ticket, stream);
     if (sch.trace) {
-        std::vector<unsigned long long> host((size_t)grid * 4);
+        std::vector<unsigned long long> host((size_t)grid * kTraceWords);
         (void)hipMemcpy(host.data(), sch.trace, host.size() * 8, hipMemcpyDeviceToHost);
         (void)hipFree(sch.trace);
         if (FILE* f = fopen(trace_file, "w")) {
-            fprintf(f, "# N=%d chains=%d nreuses=%d grid=%d per_wg=%d : block start end hw_id xcc_id\n", SMFFT_N, ntiles, nreuses, grid, sch.per_wg);
-            for (int i = 0; i < grid; ++i) fprintf(f, "%d %llu %llu %llx %llx\n", i, host[4 * i], host[4 * i + 1], host[4 * i + 2], host[4 * i + 3]);
+            fprintf(f, "# N=%d chains=%d nreuses=%d grid=%d per_wg=%d : block start end hw_id xcc_id start_100MHz end_100MHz first_tile_loaded_100MHz\n", SMFFT_N, ntiles, nreuses, grid, sch.per_wg);
+            for (int i = 0; i < grid; ++i) {
+                const unsigned long long* w = &host[(size_t)i * kTraceWords];
+                fprintf(f, "%d %llu %llu %llx %llx %llu %llu %llu\n", i, w[0], w[1], w[2], w[3], w[4], w[5], w[6]);
+            }
             fclose(f);
         }
     }
-    return (int)hipGetLastError();
+    return rc;
 }
 
 template <>
-int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, int grid_cap, int nreuses, int pace, int balance, int rotate, hipStream_t stream) {
+int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, const LaunchOptions& opt, hipStream_t stream) {
     if (count <= 0) return 0;
-    dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
+    dim3 grid(grid_for(count, 4096 / SMFFT_N, opt.grid_cap)), block(256);
+    const int pace = opt.pace;
     if (path == 0) {
 #if SMFFT_N == 4096
 #define SMFFT_EXTERNAL_REORDER_KERNEL SMFFT_DIT_external_occ3
@@ -94,25 +111,16 @@ int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int i
         return (int)hipGetLastError();
     }
     // in-LDS path: compact workgroups (one wave per 1024 elements for N <= 1024, one FFT per workgroup above)
-#if SMFFT_PLANAR_SIZES(SMFFT_N)
+#if SMFFT_N >= 64
     if (path == 2 && reorder) {     // no cross-application fusion (what one call of the device function costs)
-        if (!inverse) return launch_compact(SMFFT_DIT_multiple_unfused<CT_CLASS(_forward)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
-        return launch_compact(SMFFT_DIT_multiple_unfused<CT_CLASS(_inverse)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
+        if (!inverse) return launch_compact(SMFFT_DIT_multiple_unfused<CT_CLASS(_forward)>, d_input, d_output, count, opt, stream);
+        return launch_compact(SMFFT_DIT_multiple_unfused<CT_CLASS(_inverse)>, d_input, d_output, count, opt, stream);
     }
 #endif
-#if SMFFT_X2_SIZES(SMFFT_N)
-    if (path == 1) {                // two virtual threads per lane: N = 2048 in one wave, N = 4096 in two
-        constexpr int kThreads = Geometry<SMFFT_N>::kCompactThreads / 2;
-        if (!inverse && reorder)  return launch_compact(SMFFT_DIT_multiple_x2<CT_CLASS(_forward)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream, kThreads);
-        if (!inverse && !reorder) return launch_compact(SMFFT_DIT_multiple_x2<CT_CLASS(_forward_noreorder)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream, kThreads);
-        if (inverse && reorder)   return launch_compact(SMFFT_DIT_multiple_x2<CT_CLASS(_inverse)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream, kThreads);
-        return launch_compact(SMFFT_DIT_multiple_x2<CT_CLASS(_inverse_noreorder)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream, kThreads);
-    }
-#endif
-    if (!inverse && reorder)  return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_forward)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
-    if (!inverse && !reorder) return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_forward_noreorder)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
-    if (inverse && reorder)   return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_inverse)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
-    return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_inverse_noreorder)>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
+    if (!inverse && reorder)  return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_forward)>, d_input, d_output, count, opt, stream);
+    if (!inverse && !reorder) return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_forward_noreorder)>, d_input, d_output, count, opt, stream);
+    if (inverse && reorder)   return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_inverse)>, d_input, d_output, count, opt, stream);
+    return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_inverse_noreorder)>, d_input, d_output, count, opt, stream);
 }
 
 #if SMFFT_N == 1024
@@ -154,10 +162,11 @@ int launch_stream_read(const float2* d_input, long n_float2, int grid_cap, hipSt
 
 #define ST_CLASS SMFFT_PASTE3(FFT_, SMFFT_N, )
 template <>
-int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int path, int grid_cap, int nreuses, int pace, int balance, int rotate, hipStream_t stream) {
+int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int path, const LaunchOptions& opt, hipStream_t stream) {
     if (count <= 0) return 0;
-    if (path != 0) return launch_compact(FFT_GPU_multiple<ST_CLASS>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
-    dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
+    if (path != 0) return launch_compact(FFT_GPU_multiple<ST_CLASS>, d_input, d_output, count, opt, stream);
+    dim3 grid(grid_for(count, 4096 / SMFFT_N, opt.grid_cap)), block(256);
+    const int pace = opt.pace;
 #if SMFFT_N == 4096
     // same transform (Engine<4096, inverse, reorder>) through the occupancy-3 build, see SMFFT_DIT_external_occ3
     SMFFT_DIT_external_occ3<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
@@ -169,13 +178,14 @@ int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int p
 
 #if SMFFT_N >= 256 && SMFFT_N <= 2048
 template <>
-int launch_rc<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int path, int grid_cap, int nreuses, int pace, int balance, int rotate, hipStream_t stream) {
+int launch_rc<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int path, const LaunchOptions& opt, hipStream_t stream) {
     if (count <= 0) return 0;
     if (path != 0) {
-        if (!inverse) return launch_compact(FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_forward>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
-        return launch_compact(FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_inverse>, d_input, d_output, count, grid_cap, nreuses, balance, rotate, stream);
+        if (!inverse) return launch_compact(FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_forward>, d_input, d_output, count, opt, stream);
+        return launch_compact(FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_inverse>, d_input, d_output, count, opt, stream);
     }
-    dim3 grid(grid_for(count, 4096 / SMFFT_N, grid_cap)), block(256);
+    dim3 grid(grid_for(count, 4096 / SMFFT_N, opt.grid_cap)), block(256);
+    const int pace = opt.pace;
     if (!inverse) FFT_GPU_R2C_C2R_external<ST_CLASS, FFT_forward><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
     else          FFT_GPU_R2C_C2R_external<ST_CLASS, FFT_inverse><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
     return (int)hipGetLastError();

@@ -20,12 +20,10 @@
 #include "smfft/smfft_device_functions.hpp"
 #include "smfft/smfft_planar.hpp"
 
-// external kernels stage through LDS with wave-coalesced global access up to this length
-#ifndef SMFFT_STAGED_MAX_N
-#define SMFFT_STAGED_MAX_N 128
-#endif
-
 namespace smfft {
+
+// external kernels stage through LDS with wave-coalesced global access up to this length
+constexpr int kStagedMaxN = 128;
 
 // ------------------------------------------------------------------------------------------------
 // C2C, external: out[f] = FFT(in[f]) for f < nFFTs.
@@ -110,7 +108,7 @@ __device__ __forceinline__ void vmem_throttle(const float2* rows, float2 (&r)[16
 template <int N, int DIR, int REORDER>
 __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nFFTs, int pace, float2* s) {
     using G = Geometry<N>;
-    constexpr bool kStaged = (N <= SMFFT_STAGED_MAX_N);
+    constexpr bool kStaged = (N <= kStagedMaxN);
     constexpr int kFftsPerWave = (N <= 1024) ? 1024 / N : 1;
     Engine<N, DIR, REORDER> eng;
     eng.init(threadIdx.x);
@@ -171,21 +169,21 @@ constexpr int compact_lds_offset(int c) {
     const int e = G::kCompactThreads * c;
     return (e / N) * G::SF + (e % N) + (PADDED ? ((e % N) >> G::kPadShift) : 0);
 }
-template <int N, bool PADDED>
-__device__ __forceinline__ void tile_to_lds(const float2* __restrict__ g, float2* s, long first_fft, long limit_fft) {
+template <int N, bool PADDED, bool SHARED = false>
+__device__ __forceinline__ void tile_to_lds(const float2* g, float2* s, long first_fft, long limit_fft) {
     using G = Geometry<N>;
     constexpr int C = G::kCompactTile / G::kCompactThreads;
     static_assert(N >= G::kCompactThreads || G::kCompactThreads % N == 0, "see compact_lds_base");
     float2 v[C];
     if (first_fft + G::kCompactFfts <= limit_fft) {      // whole tile inside the batch: loads back to back, no predicate
 #pragma unroll
-        for (int c = 0; c < C; ++c) v[c] = g[threadIdx.x + G::kCompactThreads * c];
+        for (int c = 0; c < C; ++c) v[c] = tile_load<SHARED>(g + threadIdx.x + G::kCompactThreads * c);
     } else {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int e = threadIdx.x + G::kCompactThreads * c;
             const bool ok = first_fft + e / N < limit_fft;
-            const float2 t = g[ok ? e : 0];              // g[0] belongs to FFT first_fft, which exists
+            const float2 t = tile_load<SHARED>(g + (ok ? e : 0));   // g[0] belongs to FFT first_fft, which exists
             v[c] = ok ? t : make_float2(0.f, 0.f);
         }
     }
@@ -193,8 +191,8 @@ __device__ __forceinline__ void tile_to_lds(const float2* __restrict__ g, float2
 #pragma unroll
     for (int c = 0; c < C; ++c) base[compact_lds_offset<N, PADDED>(c)] = v[c];
 }
-template <int N, bool PADDED>
-__device__ __forceinline__ void lds_to_tile(float2* __restrict__ g, const float2* s, long first_fft, long limit_fft) {
+template <int N, bool PADDED, bool SHARED = false>
+__device__ __forceinline__ void lds_to_tile(float2* g, const float2* s, long first_fft, long limit_fft) {
     using G = Geometry<N>;
     constexpr int C = G::kCompactTile / G::kCompactThreads;
     float2 v[C];
@@ -203,12 +201,12 @@ __device__ __forceinline__ void lds_to_tile(float2* __restrict__ g, const float2
     for (int c = 0; c < C; ++c) v[c] = base[compact_lds_offset<N, PADDED>(c)];
     if (first_fft + G::kCompactFfts <= limit_fft) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) g[threadIdx.x + G::kCompactThreads * c] = v[c];
+        for (int c = 0; c < C; ++c) tile_store<SHARED>(g + threadIdx.x + G::kCompactThreads * c, v[c]);
     } else {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int e = threadIdx.x + G::kCompactThreads * c;
-            if (first_fft + e / N < limit_fft) g[e] = v[c];
+            if (first_fft + e / N < limit_fft) tile_store<SHARED>(g + e, v[c]);
         }
     }
 }
@@ -218,21 +216,30 @@ __device__ __forceinline__ void lds_to_tile(float2* __restrict__ g, const float2
 // A CHAIN = one tile's data loaded once, transformed `nreuses` times in LDS, stored once (CT:553-572).  The README batches are
 // 5242 wave-tiles at every length -- 42.9 MB of LDS images on a chip that has 41.9 MB -- so with one chain per workgroup slot the
 // launch runs one full round of resident workgroups and then a second round of a few hundred lone ones at a quarter of the
-// rate: a 14-28 % tail (profiles/r03_*).  BALANCED schedule (round 4): the launch is a persistent grid of exactly the G
-// workgroups that are co-resident, and the total of ntiles * nreuses APPLICATIONS is cut into G equal intervals (McNaughton's
-// wrap-around rule): a workgroup's interval covers the last part of one chain, whole chains, and the first part of another.
-// A chain that straddles two workgroups is cut ONCE: the workgroup with the lower index runs its first applications -- as the
-// FIRST thing it does -- and parks the data in the chain's own output slot; the next workgroup resumes it from there as the
-// LAST thing it does (both are ordinary tile stores / loads: same bits).  Because an interval is longer than a chain, the
-// first part is finished long before the second is due, so nobody waits in practice; the hand-off is a flag per chain with
-// agent-scope release / acquire (the two workgroups sit on different XCDs, whose L2s are not coherent with each other), and
-// waiting only ever points to a LOWER block index, so the lowest unfinished workgroup can always run.  Every application still
-// happens in LDS; a cut chain pays one more tile store + load.  per_wg = 0: the old schedule (one chain at a time, grid-strided).
+// rate: a 14-28 % tail (profiles/r03_*).  BALANCED schedule (round 4): the launch is a persistent grid of about as many
+// workgroups as are co-resident, and the total of ntiles * nreuses APPLICATIONS is cut into that many equal intervals
+// (McNaughton's wrap-around rule): a workgroup's interval covers the last part of one chain, whole chains, and the first part of
+// another.  A chain that straddles two workgroups is cut ONCE: the workgroup with the lower index (its OWNER) runs its first
+// applications -- as the FIRST thing it does -- and parks the data in the chain's own output slot; the next workgroup (its
+// RESUMER) continues from there as the LAST thing it does (both are ordinary tile stores / loads: same bits).  Because an interval
+// is longer than a chain, the first part is finished long before the second is due, so nobody waits in practice.
+//
+// The hand-over is a word per chain (ChainState below), agent-scope atomics (the two workgroups sit on different XCDs, whose L2s
+// are not coherent with each other).  It does NOT rely on the two workgroups being co-resident or on any dispatch order (round 5):
+// a resumer that has waited `wait_ticks` for a chain nobody has committed to parking TAKES the chain -- it runs ALL of the chain's
+// applications itself from d_input, which gives the same bits -- and an owner that finds its chain taken stores nothing.  So every
+// wait is bounded by the owner's own tile store, whatever else runs on the device (another stream's kernels, another process, a
+// balanced launch of another host thread); the price of a take-over is at most one chain's worth of repeated applications.
+// per_wg = 0: the old schedule (one chain at a time, grid-strided; no hand-overs).
 struct MultipleSchedule {
     int per_wg;              // applications per workgroup (> nreuses), or 0: grid-stride over whole chains
-    unsigned epoch;          // flags[c] == epoch: chain c has been parked in this launch
-    unsigned* flags;         // one per chain, device memory owned by the host API
+    unsigned base;           // 4 * the launch's epoch: flags[c] - base is the ChainState of chain c in THIS launch (smaller: an earlier launch's)
+    unsigned* flags;         // one per chain, device memory owned by the host API (one buffer per launch in flight)
     int rotate;              // > 0: the wave's scheduling priority rotates every 2^rotate shader clocks (see WavePriority)
+    unsigned wait_ticks;     // 100 MHz ticks a resumer waits for an uncommitted chain before it takes it over
+    int delay_chain;         // fault injection (tests; -1: none): the owner of this chain sleeps delay_ticks ...
+    unsigned delay_ticks;    //   ... before it commits to parking (delay_after_commit = 0) or between the commit and the parked flag (1)
+    int delay_after_commit;
     unsigned* residency;     // calibration launches only: [0] workgroups alive now, [1] the most that were alive at once
     unsigned long long* trace;   // experiments (SMFFT_SCHEDULE_TRACE): per workgroup {start, end} of s_memrealtime + {HW_ID, XCC_ID}; nullptr otherwise
 };
@@ -243,33 +250,101 @@ __device__ __forceinline__ void residency_enter(unsigned* r) {
 __device__ __forceinline__ void residency_leave(unsigned* r) {
     if (r && threadIdx.x == 0) atomicSub(r, 1u);
 }
+// per workgroup: [0] start, [1] end (shader clock of its XCD), [2] HW_ID, [3] XCC_ID, [4] start, [5] end, [6] first tile in LDS (100 MHz, device-wide)
+constexpr int kTraceWords = 8;
 __device__ __forceinline__ void trace_mark(unsigned long long* trace, int slot) {
     if (trace && threadIdx.x == 0) {
-        trace[4 * blockIdx.x + slot] = __builtin_readcyclecounter();
+        unsigned long long* w = trace + (size_t)kTraceWords * blockIdx.x;
         if (slot == 0) {
-            trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((4 /* HW_REG_HW_ID */) | (0 << 6) | ((32 - 1) << 11));
-            trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((32 - 1) << 11));
+            w[0] = __builtin_readcyclecounter();
+            w[2] = __builtin_amdgcn_s_getreg((4 /* HW_REG_HW_ID */) | (0 << 6) | ((32 - 1) << 11));
+            w[3] = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((32 - 1) << 11));
+            w[4] = wall_clock64();
+        } else if (slot == 1) {
+            w[1] = __builtin_readcyclecounter();
+            w[5] = wall_clock64();
+        } else {
+            w[6] = wall_clock64();
         }
     }
 }
-__device__ __forceinline__ void chain_signal_parked(unsigned* flag, unsigned epoch) {
-    __syncthreads();                                    // every wave's tile stores are issued and complete at workgroup scope
-    if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void chain_wait_parked(unsigned* flag, unsigned epoch) {
-    if (threadIdx.x == 0) {
-        // Nobody waits here in practice (the first part of a chain is finished long before its second part is due), and a wait can
-        // only point to a lower block index, which the dispatcher has started earlier (per XCD in order), so it always ends.  Should
-        // that reasoning ever fail on some device, the kernel TRAPS after three seconds instead of hanging the GPU: the launch then
-        // returns an error (SMFFT_MULT_BALANCE=0 is the schedule without hand-offs).
-        const unsigned long long t0 = wall_clock64();                   // 100 MHz
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-            __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > 300000000ull) __builtin_trap();
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // L1 and the XCD's L2 drop what they hold of other XCDs' lines
-    }
+
+// Where the hand-over of a cut chain stands: flags[chain] - base.
+//   (anything below 1: nothing yet)  ->  kChainStoring (the owner has committed: it is storing the tile)  ->  kChainParked
+//   (anything below 1: nothing yet)  ->  kChainTaken   (the resumer has waited long enough: the chain is its own from application 0)
+// Both transitions out of "nothing yet" are compare-and-swaps on the same word, so exactly one of them happens.
+// Visibility (MI355X_MICROARCH.md, inter-workgroup visibility; the XCDs' L2s are not coherent with each other): the parked tile is
+// stored WRITE-THROUGH and read with `sc1` loads (tile_store / tile_load <SHARED>), every storing wave drains its stores
+// (s_waitcnt vmcnt(0)) in front of the workgroup barrier behind which ONE lane sets the word with an agent-scope atomic; the
+// resumer polls that word relaxed with one lane, tells its workgroup through LDS, and every load of the tile is an `sc1` load.
+// No cache-wide write-back or invalidate anywhere: with `fence(release / acquire, "agent")` around plain tile accesses -- rounds
+// 4's form -- every workgroup's `buffer_wbl2` scanned its XCD's L2, 10-90 us of a README launch (profiles/r05_handover_forms.txt).
+enum ChainState : unsigned { kChainStoring = 1u, kChainParked = 2u, kChainTaken = 3u };
+
+// one word from thread 0 to every thread of the workgroup (single-wave workgroups: the barriers compile to nothing)
+__device__ __forceinline__ unsigned workgroup_broadcast(unsigned value) {
+    __shared__ unsigned word;
+    __syncthreads();                                    // the previous broadcast has been read
+    if (threadIdx.x == 0) word = value;
     __syncthreads();
+    return word;
+}
+__device__ __forceinline__ void sleep_ticks(unsigned ticks) {
+    const unsigned long long t0 = wall_clock64();       // 100 MHz
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+__device__ __forceinline__ global_u32* chain_word(const MultipleSchedule& sch, int tile) { return (global_u32*)(sch.flags + tile); }
+// OWNER, head computed: commit to parking it.  false: the resumer took the chain meanwhile -- nothing may be stored.
+__device__ __forceinline__ bool chain_park_begin(const MultipleSchedule& sch, int tile) {
+    unsigned go = 0;
+    if (threadIdx.x == 0) {
+        if (tile == sch.delay_chain && !sch.delay_after_commit) sleep_ticks(sch.delay_ticks);
+        global_u32* word = chain_word(sch, tile);
+        unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+            if (v == sch.base + kChainTaken) break;
+            if (__hip_atomic_compare_exchange_strong(word, &v, sch.base + kChainStoring, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                go = 1;
+                break;
+            }
+        }
+    }
+    return workgroup_broadcast(go) != 0;
+}
+__device__ __forceinline__ void chain_park_end(const MultipleSchedule& sch, int tile) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave: its write-through stores have arrived ...
+    __syncthreads();                                    // ... before thread 0 says so
+    if (threadIdx.x == 0) {
+        if (tile == sch.delay_chain && sch.delay_after_commit) sleep_ticks(sch.delay_ticks);
+        __hip_atomic_store(chain_word(sch, tile), sch.base + kChainParked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// RESUMER: the application its piece really starts from -- app0 when the parked data are there (to be loaded from d_output, SHARED),
+// 0 when it has taken the chain (to be loaded from d_input).  Nobody waits here in practice (the head of a chain is the first thing
+// its owner does, the tail the last thing the resumer does); when the owner has not even committed after wait_ticks -- it is not
+// resident yet, or the device is shared -- the resumer stops waiting.  An owner that HAS committed is running its tile store: that
+// wait is bounded by the store.
+__device__ __forceinline__ int chain_resume_or_take(const MultipleSchedule& sch, int tile, int app0) {
+    unsigned take = 0;
+    if (threadIdx.x == 0) {
+        global_u32* word = chain_word(sch, tile);
+        const unsigned long long t0 = wall_clock64();   // 100 MHz
+        for (;;) {
+            unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v == sch.base + kChainParked) break;
+            if (v != sch.base + kChainStoring && wall_clock64() - t0 > sch.wait_ticks) {
+                if (__hip_atomic_compare_exchange_strong(word, &v, sch.base + kChainTaken, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    take = 1;
+                    break;
+                }
+                continue;                               // the owner committed under our hands: look again
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    take = workgroup_broadcast(take);                   // (the other waves load behind this barrier)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the compiler from moving the tile loads above the poll
+    return take ? 0 : app0;
 }
 // The parts of chains this workgroup owns, in the order the schedule needs: the chain it shares with the NEXT workgroup (its
 // head) first, the one it shares with the PREVIOUS (its tail) last.  One loop for both schedules: chain = first + k * step,
@@ -303,22 +378,32 @@ struct PieceLoop {
         return __builtin_amdgcn_readfirstlane((int)((hi < c0 + nreuses ? hi : c0 + nreuses) - c0));
     }
 };
+// One piece of the loop above with its hand-overs resolved: applications [app0, app1) of `tile`, loaded from d_output when
+// app0 > 0 (parked there by the owner: `resumed`) and from d_input otherwise.
+struct Piece {
+    int tile, app0, app1;
+    bool park;               // the piece ends before the chain does -- its data are handed to the next workgroup
+    __device__ __forceinline__ Piece(const PieceLoop& pieces, const MultipleSchedule& sch, int k) : tile(pieces.tile(k)), app0(pieces.app0(k)), app1(pieces.app1(k)) {
+        park = app1 < pieces.nreuses;
+        if (!park && app0 > 0) app0 = chain_resume_or_take(sch, tile, app0);
+    }
+    __device__ __forceinline__ bool resumed() const { return app0 > 0; }
+    // a parked head may be stored only if the resumer has not taken the chain meanwhile
+    __device__ __forceinline__ bool store_begin(const MultipleSchedule& sch) const { return chain_park_begin(sch, tile); }
+    __device__ __forceinline__ void store_end(const MultipleSchedule& sch) const { chain_park_end(sch, tile); }
+};
 
-// C2C, multiple, on the float2 engine (N = 32; every length with SMFFT_PLANAR=0 -- the A/B baseline of the planar engine):
+// C2C, multiple, on the float2 engine (N = 32: its transform never leaves the registers -- two threads per FFT, one DPP
+// transposition -- and the planar engine measured 10 % slower there, profiles/r03_ab_planar_small.txt):
 // the first nSlots FFTs are loaded once, transformed nreuses (= NREUSES = 100 in the
 // benchmark; a kernel argument so the tests can run 1, 2 and 4 applications) times in LDS, stored once.
 // Every application reads its input from LDS and writes its result to LDS (the device function's contract);
 // what the kernel chooses is the IMAGE the data are kept in between applications: natural order for the reorder
 // variants, the padded image of Engine::bitrev_write for the no-reorder variants -- a result is stored straight into
-// the layout the next application's bit-reversed read wants, instead of natural order + a second write and read
-// (round 1: 64 LDS instructions per N = 1024 FFT against 32 for reorder; now 32 + 32 either way; for N <= 64, whose
-// device-function form does the bit reversal as a DPP register transposition, the read from the padded image replaces
-// that transposition too).
-#ifndef SMFFT_MULT_FORWARD
-#define SMFFT_MULT_FORWARD 1
-#endif
+// the layout the next application's bit-reversed read wants, instead of natural order + a second write and read.
+// (d_input / d_output are not __restrict__ here: a resumed piece READS the tile another workgroup of this launch parked in d_output)
 template <int N, int DIR, int REORDER>
-__device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, MultipleSchedule sch, float2* s) {
+__device__ __forceinline__ void c2c_multiple_body(const float2* d_input, float2* d_output, int nSlots, int nreuses, MultipleSchedule sch, float2* s) {
     using G = Geometry<N>;
     constexpr bool kPaddedImage = !REORDER;
     Engine<N, DIR, REORDER> eng;
@@ -330,73 +415,60 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* __restrict__ d_i
     trace_mark(sch.trace, 0);
     residency_enter(sch.residency);
     for (int k = 0; k < pieces.count; ++k) {
-        const int tile = pieces.tile(k), app0 = pieces.app0(k), app1 = pieces.app1(k);
-        const long first = (long)tile * G::kCompactFfts;
-        const int napps = app1 - app0;
-        if (app0 > 0) chain_wait_parked(sch.flags + tile, sch.epoch);
+        const Piece piece(pieces, sch, k);
+        const long first = (long)piece.tile * G::kCompactFfts;
+        const int napps = piece.app1 - piece.app0;
         fft_sync<G::kMultiWave>();
-        tile_to_lds<N, kPaddedImage>((app0 > 0 ? d_output : d_input) + first * N, s, first, nSlots);
+        if (piece.resumed()) tile_to_lds<N, kPaddedImage, true>(d_output + first * N, s, first, nSlots);
+        else tile_to_lds<N, kPaddedImage>(d_input + first * N, s, first, nSlots);
         fft_sync<G::kMultiWave>();
+        if (k == 0) trace_mark(sch.trace, 2);
         if constexpr (kPaddedImage) {
             for (int f = 0; f < napps; ++f) {
-                priority.at_application(app0 + f);
+                priority.at_application();
                 float2 r[16];
                 eng.bitrev_read(r, sf);
                 fft_sync<G::kMultiWave>();          // all inputs are in registers before the region is reused
-                eng.template transform_from_pass1_slots<true>(r, sf);
+                eng.transform_from_pass1_slots(r, sf);
                 fft_sync<G::kMultiWave>();          // all exchange reads done before the results overwrite them
                 eng.bitrev_write(r, sf);
                 fft_sync<G::kMultiWave>();          // the reference omits this (latent race, CT:563-565)
             }
-        } else if constexpr (SMFFT_MULT_FORWARD) {
+        } else {
             // Natural-order image: what a thread stores at the end of an application (r[q] -> sf[u + T*q]) is exactly what
             // it would load at the start of the next one (r[c] <- sf[u + T*c]).  Every result is still stored (the data
             // are in LDS, natural order, after every application, as the device function's contract has it); the re-load
             // of the thread's own stores is forwarded from its registers: 16 of the 64 LDS operations per application.
             float2 r[16];
-            eng.template load_lds<true>(r, sf);
+            eng.load_lds(r, sf);
             for (int f = 0; f < napps; ++f) {
-                priority.at_application(app0 + f);
+                priority.at_application();
                 fft_sync<G::kMultiWave>();
-                eng.template transform<true>(r, sf);
+                eng.transform(r, sf);
                 fft_sync<G::kMultiWave>();
                 eng.store_lds(r, sf);
                 fft_sync<G::kMultiWave>();          // the reference omits this (latent race, CT:563-565)
             }
-        } else {
-            for (int f = 0; f < napps; ++f) {
-                float2 r[16];
-                eng.template load_lds<true>(r, sf);
-                fft_sync<G::kMultiWave>();
-                eng.template transform<true>(r, sf);
-                fft_sync<G::kMultiWave>();
-                eng.store_lds(r, sf);
-                fft_sync<G::kMultiWave>();
-            }
         }
-        lds_to_tile<N, kPaddedImage>(d_output + first * N, s, first, nSlots);
-        if (app1 < nreuses) chain_signal_parked(sch.flags + tile, sch.epoch);
+        if (!piece.park) {
+            lds_to_tile<N, kPaddedImage>(d_output + first * N, s, first, nSlots);
+        } else if (piece.store_begin(sch)) {
+            lds_to_tile<N, kPaddedImage, true>(d_output + first * N, s, first, nSlots);
+            piece.store_end(sch);
+        }
     }
     trace_mark(sch.trace, 1);
     residency_leave(sch.residency);
 }
 
-// The same kernel on the planar engine (smfft_planar.hpp): every LDS image as two planes of dwords, stored with
+// The same kernel on the planar engine (smfft_planar.hpp; N >= 64): every LDS image as two planes of dwords, stored with
 // ds_write_addtid_b32 and read back in contiguous runs.  The image between applications is the natural-order image in
 // planar form (row c, dword of thread u = x[u + T*c]); the no-reorder variants read their bit-reversed rows from it,
-// the reorder variants store every result and forward their own registers into the next application.
-#ifndef SMFFT_PLANAR
-#define SMFFT_PLANAR 1          // 0: the float2-image engine for every length (A/B)
-#endif
-#ifndef SMFFT_PLANAR_MIN_N
-#define SMFFT_PLANAR_MIN_N 64   // N = 32 keeps the register engine and its float2 image (planar: -10 %, profiles/r03_ab_planar_small.txt)
-#endif
-#define SMFFT_PLANAR_SIZES(N) (SMFFT_PLANAR && (N) >= SMFFT_PLANAR_MIN_N)
-#ifndef SMFFT_MULT_FUSED
-#define SMFFT_MULT_FUSED 1      // 0: no cross-application fusion -- every application re-loads its input from the LDS image (see SMFFT_DIT_multiple_unfused)
-#endif
-template <int N, int DIR, int REORDER, bool FUSED = (SMFFT_MULT_FUSED != 0)>
-__device__ __forceinline__ void c2c_multiple_body_planar(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, MultipleSchedule sch, float* planes) {
+// the reorder variants store every result and forward their own registers into the next application (FUSED; false: every
+// application re-loads its input from the LDS image -- SMFFT_DIT_multiple_unfused).
+constexpr int kPlanarMinN = 64;
+template <int N, int DIR, int REORDER, bool FUSED = true>
+__device__ __forceinline__ void c2c_multiple_body_planar(const float2* d_input, float2* d_output, int nSlots, int nreuses, MultipleSchedule sch, float* planes) {
     using G = Geometry<N>;
     PlanarEngine<N, DIR, REORDER> eng;
     eng.init(threadIdx.x, planes);
@@ -406,18 +478,19 @@ __device__ __forceinline__ void c2c_multiple_body_planar(const float2* __restric
     trace_mark(sch.trace, 0);
     residency_enter(sch.residency);
     for (int k = 0; k < pieces.count; ++k) {
-        const int tile = pieces.tile(k), app0 = pieces.app0(k), app1 = pieces.app1(k);
-        const long first = (long)tile * G::kCompactFfts;
-        const int napps = app1 - app0;
-        if (app0 > 0) chain_wait_parked(sch.flags + tile, sch.epoch);
+        const Piece piece(pieces, sch, k);
+        const long first = (long)piece.tile * G::kCompactFfts;
+        const int napps = piece.app1 - piece.app0;
         planar_sync<G::kMultiWave>();
-        tile_to_planes<N, DIR, REORDER>((app0 > 0 ? d_output : d_input) + first * N, planes, first, nSlots);
+        if (piece.resumed()) tile_to_planes<N, DIR, REORDER, true>(d_output + first * N, planes, first, nSlots);
+        else tile_to_planes<N, DIR, REORDER>(d_input + first * N, planes, first, nSlots);
         planar_sync<G::kMultiWave>();
+        if (k == 0) trace_mark(sch.trace, 2);
         float2 r[16];
         if constexpr (REORDER && FUSED) {
             eng.image_load_own(r, planes);
             for (int f = 0; f < napps; ++f) {
-                priority.at_application(app0 + f);
+                priority.at_application();
                 eng.natural_to_slots(r);
                 eng.transform_from_pass1_slots(r, planes);
                 planar_sync<G::kMultiWave>();       // the last pass's reads are done before the result overwrites them
@@ -427,7 +500,7 @@ __device__ __forceinline__ void c2c_multiple_body_planar(const float2* __restric
             // unfused: what ONE call of the device function costs when its input is data in LDS and its output is data in
             // LDS -- the application reads its sixteen inputs back from the stored image instead of keeping them in registers
             for (int f = 0; f < napps; ++f) {
-                priority.at_application(app0 + f);
+                priority.at_application();
                 planar_sync<G::kMultiWave>();       // the image is complete (stored by the threads that computed it)
                 eng.image_load_own(r, planes);
                 eng.natural_to_slots(r);
@@ -437,7 +510,7 @@ __device__ __forceinline__ void c2c_multiple_body_planar(const float2* __restric
             }
         } else {
             for (int f = 0; f < napps; ++f) {
-                priority.at_application(app0 + f);
+                priority.at_application();
                 eng.image_load_bitrev(r, planes);
                 eng.transform_from_pass1_slots(r, planes);
                 planar_sync<G::kMultiWave>();
@@ -446,74 +519,12 @@ __device__ __forceinline__ void c2c_multiple_body_planar(const float2* __restric
             }
         }
         planar_sync<G::kMultiWave>();
-        planes_to_tile<N, DIR, REORDER>(d_output + first * N, planes, first, nSlots);
-        if (app1 < nreuses) chain_signal_parked(sch.flags + tile, sch.epoch);
-    }
-    trace_mark(sch.trace, 1);
-    residency_leave(sch.residency);
-}
-
-// The same kernel with two virtual threads per lane (smfft_planar.hpp, transform2_from_pass1_slots): N = 2048 in one wave,
-// N = 4096 in two.  Launched with Geometry<N>::kCompactThreads / 2 threads.
-// MEASURED AND NOT USED (profiles/r04_ab_two_virtual_threads.txt): 20-25 % slower than the sixteen-elements-per-thread kernels at
-// both lengths, README and saturating batch alike -- two or three waves per SIMD hide less latency than four, and the two
-// instruction streams of a lane interleave worse statically than four waves do in hardware.  Kept as an A/B build.
-#ifndef SMFFT_MULT_X2
-#define SMFFT_MULT_X2 0          // 1: N = 2048 / 4096 on two virtual threads per lane
-#endif
-#define SMFFT_X2_SIZES(N) (SMFFT_MULT_X2 && SMFFT_PLANAR && (N) >= 2048)
-template <int N, int DIR, int REORDER>
-__device__ __forceinline__ void c2c_multiple_body_planar_x2(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, MultipleSchedule sch, float* planes) {
-    using G = Geometry<N>;
-    constexpr int H = G::kCompactThreads / 2;               // physical threads; the second virtual thread of a lane is tid + H
-    constexpr bool kMW = H > 64;
-    PlanarEngine<N, DIR, REORDER> ea, eb;
-    ea.init(threadIdx.x, planes);
-    eb.init(threadIdx.x + H, planes);
-    const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
-    const PieceLoop pieces(sch, ntiles, nreuses);
-    const WavePriority priority(sch.rotate);
-    trace_mark(sch.trace, 0);
-    residency_enter(sch.residency);
-    for (int k = 0; k < pieces.count; ++k) {
-        const int tile = pieces.tile(k), app0 = pieces.app0(k), app1 = pieces.app1(k);
-        const long first = (long)tile * G::kCompactFfts;
-        const int napps = app1 - app0;
-        if (app0 > 0) chain_wait_parked(sch.flags + tile, sch.epoch);
-        planar_sync<kMW>();
-        const float2* src = (app0 > 0 ? d_output : d_input) + first * N;
-        tile_to_planes<N, DIR, REORDER>(src, planes, first, nSlots, threadIdx.x);
-        tile_to_planes<N, DIR, REORDER>(src, planes, first, nSlots, threadIdx.x + H);
-        planar_sync<kMW>();
-        float2 ra[16], rb[16];
-        if constexpr (REORDER) {
-            ea.image_load_own(ra, planes);
-            eb.image_load_own(rb, planes);
-            for (int f = 0; f < napps; ++f) {
-                priority.at_application(app0 + f);
-                ea.natural_to_slots(ra);
-                eb.natural_to_slots(rb);
-                transform2_from_pass1_slots<kMW>(ea, ra, eb, rb, planes);
-                planar_sync<kMW>();                 // the last pass's reads are done before the result overwrites them
-                ea.image_store(ra);
-                eb.image_store(rb);
-            }
-        } else {
-            for (int f = 0; f < napps; ++f) {
-                priority.at_application(app0 + f);
-                ea.image_load_bitrev(ra, planes);
-                eb.image_load_bitrev(rb, planes);
-                transform2_from_pass1_slots<kMW>(ea, ra, eb, rb, planes);
-                planar_sync<kMW>();
-                ea.image_store(ra);
-                eb.image_store(rb);
-                planar_sync<kMW>();                 // the reference omits this (latent race, CT:563-565)
-            }
+        if (!piece.park) {
+            planes_to_tile<N, DIR, REORDER>(d_output + first * N, planes, first, nSlots);
+        } else if (piece.store_begin(sch)) {
+            planes_to_tile<N, DIR, REORDER, true>(d_output + first * N, planes, first, nSlots);
+            piece.store_end(sch);
         }
-        planar_sync<kMW>();
-        planes_to_tile<N, DIR, REORDER>(d_output + first * N, planes, first, nSlots, threadIdx.x);
-        planes_to_tile<N, DIR, REORDER>(d_output + first * N, planes, first, nSlots, threadIdx.x + H);
-        if (app1 < nreuses) chain_signal_parked(sch.flags + tile, sch.epoch);
     }
     trace_mark(sch.trace, 1);
     residency_leave(sch.residency);
@@ -529,9 +540,6 @@ __device__ __forceinline__ void c2c_multiple_body_planar_x2(const float2* __rest
 // evaluates to the conjugate expression the LDS version writes there, RC:302-308).  W^i = W^u * W_32^q: one table
 // value per thread and 15 constants.  Replaces store_lds + hermitian_pass + load_lds (4 LDS passes, 3 syncs) in the
 // external kernels where that measured faster.
-#ifndef SMFFT_RC_REGISTERS
-#define SMFFT_RC_REGISTERS 1
-#endif
 template <int L, int DIR>
 struct HermitianRegisters {
     static constexpr int T = L / 16;
@@ -542,7 +550,7 @@ struct HermitianRegisters {
     // LDS write + read of the data instead of the LDS-resident merge's two (C2R +3 %; the R2C of that length measured
     // 1.3 % SLOWER this way and L = 256 unchanged, so both keep the LDS form)
     static constexpr bool kFromLds = (L == 2048 && DIR == 1);
-    static constexpr bool kEnabled = SMFFT_RC_REGISTERS && (L == 512 || L == 1024 || kFromLds);
+    static constexpr bool kEnabled = (L == 512 || L == 1024 || kFromLds);
     float2 wu;          // (-+i / 2) * W_{2L}^u (W conjugated, +i, for DIR = 1): see combine
     int partner_addr;   // byte address of the partner lane for ds_bpermute
     bool first;         // u == 0
@@ -562,9 +570,6 @@ struct HermitianRegisters {
     // price of 135-146 VGPRs (3 waves per SIMD).  An in-place form that fetched two partners at a time, software-pipelined,
     // at 93-113 VGPRs = 4 waves per SIMD measured 0.6-2 % SLOWER on the same buffers (profiles/r02_ab_rc.txt) and is gone.
     // sf: the FFT's LDS region (kFromLds only; free on entry, the caller orders its later re-use).
-    // RESIDENT = true (the in-LDS kernels): the data the registers were loaded from still lies in sf in natural order, so
-    // the partners are read from there without the store -- the split / merge fused into a load.
-    template <bool RESIDENT = false>
     __device__ __forceinline__ void apply(float2 (&r)[16], float2* sf = nullptr) const {
         constexpr float c32[16] = {1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f, 0.55557023301960229f,
                                    0.38268343236508984f, 0.19509032201612833f, 0.f, -0.19509032201612819f, -0.38268343236508973f, -0.55557023301960196f,
@@ -573,13 +578,11 @@ struct HermitianRegisters {
                                    0.92387953251128674f, 0.98078528040323043f, 1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254546f,
                                    0.70710678118654757f, 0.55557023301960218f, 0.38268343236508989f, 0.19509032201612861f};
         float2 B[16];
-        if constexpr (kFromLds || RESIDENT) {
+        if constexpr (kFromLds) {
             const int u = threadIdx.x % T;
-            if constexpr (!RESIDENT) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) sf[u + T * q] = r[q];
-                fft_sync<(T > 64)>();
-            }
+            for (int q = 0; q < 16; ++q) sf[u + T * q] = r[q];
+            fft_sync<(T > 64)>();
             // x[L - (u + T*q)] = x[(T - u) + T*(15 - q)] -- for thread 0, too (x[T*(16 - q)], q >= 1); its q = 0 reads one
             // element past the data (inside the region's padding) and is replaced by the packed DC / Nyquist value below
             const float2* partner = sf + (T - u);
@@ -595,11 +598,8 @@ struct HermitianRegisters {
                 B[q] = first ? own : make_float2(bx, by);
             }
         }
-        // the fifteen products V are the same for every tile and application: the external kernels let the compiler keep
-        // them in 30 registers across the grid-stride loop; the in-LDS kernels (RESIDENT), which live on their occupancy,
-        // recompute them -- the copy below is opaque to the compiler
-        float2 w = wu;
-        if constexpr (RESIDENT) asm volatile("" : "+v"(w.x), "+v"(w.y));
+        // the fifteen products V are the same for every tile: the compiler keeps them in 30 registers across the grid-stride loop
+        const float2 w = wu;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const float2 A = r[q];
@@ -669,66 +669,11 @@ __device__ __forceinline__ void r2c_c2r_external_body(const float2* __restrict__
     }
 }
 
-#ifndef SMFFT_RC_MULTIPLE_PLANAR
-#define SMFFT_RC_MULTIPLE_PLANAR 1      // 0: the float2-image form below (A/B)
-#endif
-template <int L, int DIR>
-__device__ __forceinline__ void r2c_c2r_multiple_body(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, MultipleSchedule sch, float2* s) {
-    using G = Geometry<L>;
-    Engine<L, DIR, 1> eng;
-    eng.init(threadIdx.x);
-    HermitianRegisters<L, DIR> herm;
-    herm.init(threadIdx.x);
-    const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
-    const PieceLoop pieces(sch, ntiles, nreuses);
-    const WavePriority priority(sch.rotate);
-    residency_enter(sch.residency);
-    for (int k = 0; k < pieces.count; ++k) {
-        const int tile = pieces.tile(k), app0 = pieces.app0(k), app1 = pieces.app1(k);
-        const long first = (long)tile * G::kCompactFfts;
-        const int napps = app1 - app0;
-        if (app0 > 0) chain_wait_parked(sch.flags + tile, sch.epoch);
-        fft_sync<G::kMultiWave>();
-        tile_to_lds<L, false>((app0 > 0 ? d_output : d_input) + first * L, s, first, nSlots);
-        fft_sync<G::kMultiWave>();
-        // The split (R2C, after the FFT) / merge (C2R, before it) of an application is fused into the LOAD of the transform
-        // that follows it: the partner x[L - i] is read from the resident data next to x[i] and the pair is combined in
-        // registers -- two LDS round trips per application instead of three (the LDS-resident pass reads and re-writes the
-        // data once more).  R2C: the first load of a piece is plain and its last split is the LDS pass.
-        float2* sf = s + eng.fft * G::SF;
-        for (int f = 0; f < napps; ++f) {
-            priority.at_application(app0 + f);
-            float2 r[16];
-            eng.load_lds(r, sf);
-            if (DIR == 1 || f > 0) herm.template apply<true>(r, sf);
-            fft_sync<G::kMultiWave>();          // every read of the region is done before the exchanges write into it
-            eng.transform(r, sf);
-            fft_sync<G::kMultiWave>();
-            eng.store_lds(r, sf);
-            fft_sync<G::kMultiWave>();
-        }
-        if (DIR == 0) {
-            int u = eng.u;
-            asm volatile("" : "+v"(u));         // keeps the pass's eight twiddle loads after the loop (16 registers less in it)
-            hermitian_pass<L, 0>(sf, u);
-            fft_sync<G::kMultiWave>();
-        }
-        lds_to_tile<L, false>(d_output + first * L, s, first, nSlots);
-        if (app1 < nreuses) chain_signal_parked(sch.flags + tile, sch.epoch);
-    }
-    residency_leave(sch.residency);
-}
-
 // R2C / C2R in-LDS path on the planar engine: the complex transform of length L as in c2c_multiple_body_planar (reorder
 // roles, registers forwarded from one application to the next) with the Hermitian split / merge done on the registers,
 // pair-wise (PlanarEngine::hermitian_apply_pairs).  Per application: the C2C's LDS traffic + 32 dword stores + 32 dword reads.
-#ifndef SMFFT_RC_PAIRS
-#define SMFFT_RC_PAIRS 0xf       // bit 0..3: complex length L = 256, 512, 1024, 2048 splits / merges pair-wise
-#endif
-template <int L>
-static constexpr bool kRcPairs = ((SMFFT_RC_PAIRS >> (ilog2c(L) - 8)) & 1) != 0;
 template <int L, int DIR>
-__device__ __forceinline__ void r2c_c2r_multiple_body_planar(const float2* __restrict__ d_input, float2* __restrict__ d_output, int nSlots, int nreuses, MultipleSchedule sch, float* planes) {
+__device__ __forceinline__ void r2c_c2r_multiple_body_planar(const float2* d_input, float2* d_output, int nSlots, int nreuses, MultipleSchedule sch, float* planes) {
     using G = Geometry<L>;
     PlanarEngine<L, DIR, 1> eng;
     eng.init(threadIdx.x, planes);
@@ -738,58 +683,39 @@ __device__ __forceinline__ void r2c_c2r_multiple_body_planar(const float2* __res
     const WavePriority priority(sch.rotate);
     residency_enter(sch.residency);
     for (int k = 0; k < pieces.count; ++k) {
-        const int tile = pieces.tile(k), app0 = pieces.app0(k), app1 = pieces.app1(k);
-        const long first = (long)tile * G::kCompactFfts;
-        const int napps = app1 - app0;
-        if (app0 > 0) chain_wait_parked(sch.flags + tile, sch.epoch);
+        const Piece piece(pieces, sch, k);
+        const long first = (long)piece.tile * G::kCompactFfts;
+        const int napps = piece.app1 - piece.app0;
         planar_sync<G::kMultiWave>();
-        tile_to_planes<L, DIR, 1>((app0 > 0 ? d_output : d_input) + first * L, planes, first, nSlots);
+        if (piece.resumed()) tile_to_planes<L, DIR, 1, true>(d_output + first * L, planes, first, nSlots);
+        else tile_to_planes<L, DIR, 1>(d_input + first * L, planes, first, nSlots);
         planar_sync<G::kMultiWave>();
         float2 r[16];
         eng.image_load_own(r, planes);
-        if constexpr (kRcPairs<L>) {
-            // pair-wise split / merge (PlanarEngine::hermitian_apply_pairs): only the rows 8..15 go through the image
-            // (R2C: the split of application f runs at the head of iteration f + 1 and once more after the loop -- the loop is
-            //  then shaped like the C2R's, split / merge in front of the transform, which the compiler keeps at four waves per SIMD)
-            for (int f = 0; f < napps; ++f) {
-                priority.at_application(app0 + f);
-                if (DIR == 1 || f > 0) eng.hermitian_apply_pairs(r, planes);   // rows 8..15: the tile (C2R), or stored below
-                eng.natural_to_slots(r);
-                eng.transform_from_pass1_slots(r, planes);
-                planar_sync<G::kMultiWave>();
-                if (DIR == 0 || f + 1 < napps) {
-                    eng.image_store_upper(r);
-                    planar_sync<G::kMultiWave>();
-                }
-            }
-            if (DIR == 0) eng.hermitian_apply_pairs(r, planes);
+        // pair-wise split / merge (PlanarEngine::hermitian_apply_pairs): only the rows 8..15 go through the image
+        // (R2C: the split of application f runs at the head of iteration f + 1 and once more after the loop -- the loop is
+        //  then shaped like the C2R's, split / merge in front of the transform, which the compiler keeps at four waves per SIMD)
+        for (int f = 0; f < napps; ++f) {
+            priority.at_application();
+            if (DIR == 1 || f > 0) eng.hermitian_apply_pairs(r, planes);   // rows 8..15: the tile (C2R), or stored below
+            eng.natural_to_slots(r);
+            eng.transform_from_pass1_slots(r, planes);
             planar_sync<G::kMultiWave>();
-            eng.image_store(r);
-            planar_sync<G::kMultiWave>();
-        } else {
-            for (int f = 0; f < napps; ++f) {
-                priority.at_application(app0 + f);
-                if (DIR == 1) {                          // C2R: merge (partners from the image: the tile, or the previous result), then the inverse transform
-                    eng.hermitian_apply(r, planes);
-                    planar_sync<G::kMultiWave>();        // every partner read precedes the exchanges' stores
-                }
-                eng.natural_to_slots(r);
-                eng.transform_from_pass1_slots(r, planes);
-                planar_sync<G::kMultiWave>();
-                eng.image_store(r);
-                planar_sync<G::kMultiWave>();
-                if (DIR == 0) {                          // R2C: the forward transform's result is in the image; split it in registers
-                    eng.hermitian_apply(r, planes);
-                    planar_sync<G::kMultiWave>();
-                }
-            }
-            if (DIR == 0) {                              // the image holds the last transform's output: replace it by the split result
-                eng.image_store(r);
+            if (DIR == 0 || f + 1 < napps) {
+                eng.image_store_upper(r);
                 planar_sync<G::kMultiWave>();
             }
         }
-        planes_to_tile<L, DIR, 1>(d_output + first * L, planes, first, nSlots);
-        if (app1 < nreuses) chain_signal_parked(sch.flags + tile, sch.epoch);
+        if (DIR == 0) eng.hermitian_apply_pairs(r, planes);
+        planar_sync<G::kMultiWave>();
+        eng.image_store(r);
+        planar_sync<G::kMultiWave>();
+        if (!piece.park) {
+            planes_to_tile<L, DIR, 1>(d_output + first * L, planes, first, nSlots);
+        } else if (piece.store_begin(sch)) {
+            planes_to_tile<L, DIR, 1, true>(d_output + first * L, planes, first, nSlots);
+            piece.store_end(sch);
+        }
     }
     residency_leave(sch.residency);
 }
@@ -869,24 +795,17 @@ SMFFT_DIT_external_occ3(const float2* d_input, float2* d_output, int nFFTs, int 
     smfft::c2c_external_body<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nFFTs, pace, s_input);
 }
 
-// SMFFT_MULT_MINWAVES (experiment switch): minimum waves per SIMD the compact kernels are compiled for
-#ifdef SMFFT_MULT_MINWAVES
-#define SMFFT_COMPACT_BOUNDS(N) __launch_bounds__(smfft::Geometry<N>::kCompactThreads, SMFFT_MULT_MINWAVES)
-#else
-// N = 2048 / 4096: compiled for 4 waves per SIMD (what their LDS allows, 8-9 / 4 workgroups per CU); left alone the planar
-// engine takes 133-170 registers = 3 or 2 waves per SIMD (profiles/r03_ab_planar_b.txt: +6 % / +3-17 % with the target stated)
-// (the single-wave kernels compiled for five waves per SIMD -- 96 registers, spills outside the application loop only -- measured
-//  3-8 % SLOWER than left alone at 100-128 registers = four waves per SIMD: profiles/r04_ab_balance_variants.txt, w5 against w1)
-#ifndef SMFFT_SINGLE_WAVE_MINWAVES
-#define SMFFT_SINGLE_WAVE_MINWAVES 1
-#endif
-#define SMFFT_COMPACT_BOUNDS(N) __launch_bounds__(smfft::Geometry<N>::kCompactThreads, (N) >= 2048 ? 4 : SMFFT_SINGLE_WAVE_MINWAVES)
-#endif
+// Launch bounds of the compact (in-LDS) kernels.  N = 2048 / 4096: compiled for 4 waves per SIMD (what their LDS allows, 8-9 / 4
+// workgroups per CU); left alone the planar engine takes 133-170 registers = 3 or 2 waves per SIMD (profiles/r03_ab_planar_b.txt:
+// +6 % / +3-17 % with the target stated).  The single-wave kernels are left alone at 100-128 registers = four waves per SIMD
+// (compiled for five -- 96 registers, spills outside the application loop only -- they measured 3-27 % SLOWER:
+// profiles/r04_ab_balance_variants.txt, r04_ab_five_waves.txt).
+#define SMFFT_COMPACT_BOUNDS(N) __launch_bounds__(smfft::Geometry<N>::kCompactThreads, (N) >= 2048 ? 4 : 1)
 
 template <class const_params>
 __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_size) SMFFT_DIT_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses, smfft::MultipleSchedule sch) {
     constexpr int N = const_params::fft_size;
-    if constexpr (SMFFT_PLANAR_SIZES(N)) {
+    if constexpr (N >= smfft::kPlanarMinN) {
         __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<N, const_params::fft_reorder>::kLdsFloats];
         smfft::c2c_multiple_body_planar<N, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nSlots, nreuses, sch, s_planes);
     } else {
@@ -901,18 +820,9 @@ __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_size) SMFFT_DIT_multiple(
 template <class const_params>
 __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_size) SMFFT_DIT_multiple_unfused(const float2* d_input, float2* d_output, int nSlots, int nreuses, smfft::MultipleSchedule sch) {
     constexpr int N = const_params::fft_size;
-    static_assert(SMFFT_PLANAR_SIZES(N) && const_params::fft_reorder, "the no-reorder variants and N = 32 are unfused as they are");
+    static_assert(N >= smfft::kPlanarMinN && const_params::fft_reorder, "the no-reorder variants and N = 32 are unfused as they are");
     __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<N, 1>::kLdsFloats];
     smfft::c2c_multiple_body_planar<N, const_params::fft_direction, 1, false>(d_input, d_output, nSlots, nreuses, sch, s_planes);
-}
-
-// N = 2048 / 4096 with two virtual threads per lane: half the threads, at most 256 registers (two waves per SIMD)
-template <class const_params>
-__global__ void __launch_bounds__(smfft::Geometry<const_params::fft_size>::kCompactThreads / 2, 2)
-SMFFT_DIT_multiple_x2(const float2* d_input, float2* d_output, int nSlots, int nreuses, smfft::MultipleSchedule sch) {
-    constexpr int N = const_params::fft_size;
-    __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<N, const_params::fft_reorder>::kLdsFloats];
-    smfft::c2c_multiple_body_planar_x2<N, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nSlots, nreuses, sch, s_planes);
 }
 
 // Stockham C2C program: un-normalised INVERSE (+i) transform, natural order (ST:76, :429).
@@ -924,7 +834,7 @@ __global__ void __launch_bounds__(256) FFT_GPU_external(const float2* d_input, f
 template <class const_params>
 __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_length) FFT_GPU_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses, smfft::MultipleSchedule sch) {
     constexpr int N = const_params::fft_length;
-    if constexpr (SMFFT_PLANAR_SIZES(N)) {
+    if constexpr (N >= smfft::kPlanarMinN) {
         __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<N, 1>::kLdsFloats];
         smfft::c2c_multiple_body_planar<N, 1, 1>(d_input, d_output, nSlots, nreuses, sch, s_planes);
     } else {
@@ -942,11 +852,6 @@ __global__ void __launch_bounds__(256) FFT_GPU_R2C_C2R_external(const float2* d_
 template <class const_params, class const_direction>
 __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_length) FFT_GPU_R2C_C2R_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses, smfft::MultipleSchedule sch) {
     constexpr int L = const_params::fft_length;
-    if constexpr (SMFFT_PLANAR_SIZES(L) && SMFFT_RC_MULTIPLE_PLANAR) {
-        __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<L, 1>::kLdsFloats];
-        smfft::r2c_c2r_multiple_body_planar<L, const_direction::fft_direction>(d_input, d_output, nSlots, nreuses, sch, s_planes);
-    } else {
-        __shared__ float2 s_input[smfft::Geometry<L>::kCompactLds];
-        smfft::r2c_c2r_multiple_body<L, const_direction::fft_direction>(d_input, d_output, nSlots, nreuses, sch, s_input);
-    }
+    __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<L, 1>::kLdsFloats];
+    smfft::r2c_c2r_multiple_body_planar<L, const_direction::fft_direction>(d_input, d_output, nSlots, nreuses, sch, s_planes);
 }

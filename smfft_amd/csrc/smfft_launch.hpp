@@ -6,22 +6,36 @@
 
 namespace smfft {
 
-// path: 0 = external (count = number of FFTs), 1 = multiple (count = number of FFT slots, each
-// transformed nreuses times in LDS; the benchmark entry points pass NREUSES = 100), 2 = multiple without cross-application
-// fusion (natural-order variants of the planar lengths; everything else runs path 1).  grid_cap <= 0: one workgroup per 4096-element tile.
-// balance != 0 (multiple paths): when the batch is more chains than fit on the chip at once, the launch is a persistent grid of the
-// co-resident workgroups with the applications spread evenly over them (smfft_kernels.hpp, MultipleSchedule); 0: one chain per workgroup, grid-strided.
-// rotate = k > 0 (multiple paths): the waves' scheduling priority rotates every 2^k shader clocks (WavePriority); 0: the arbiter's oldest-first order.
-// pace = K > 0: the external kernels run their rate limiter with K serialised loads (smfft_kernels.hpp, vmem_throttle); the host API decides it per launch.
+// What a launch takes from the host API's per-thread state (smfft_api.hip).
+//   grid_cap <= 0: one workgroup per 4096-element tile.
+//   nreuses: applications per chain of the multiple paths (the benchmark entry points pass NREUSES = 100).
+//   pace = K > 0: the external kernels run their rate limiter with K serialised loads (smfft_kernels.hpp, vmem_throttle).
+//   balance != 0 (multiple paths): when the batch is more chains than fit on the chip at once, the launch is a persistent grid of the
+//     co-resident workgroups with the applications spread evenly over them (smfft_kernels.hpp, MultipleSchedule); 0: one chain per
+//     workgroup, grid-strided; n >= 2 (tests): balanced over n workgroups.
+//   rotate = k > 0 (multiple paths): the waves' scheduling priority rotates every 2^k shader clocks (WavePriority); 0: the arbiter's own order.
+//   handoff_wait_us: balanced schedule -- how long the workgroup that resumes a cut chain waits for data nobody has committed to
+//     parking before it takes the whole chain over (MultipleSchedule).
+//   delay_*: fault injection for the tests of that path (smfft_debug_delay_parking).
+struct LaunchOptions {
+    int grid_cap, nreuses, pace, balance, rotate;
+    unsigned handoff_wait_us;
+    int delay_chain;
+    unsigned delay_ms;
+    int delay_after_commit;
+};
+
+// path: 0 = external (count = number of FFTs), 1 = multiple (count = number of FFT slots, each transformed nreuses times in LDS),
+// 2 = multiple without cross-application fusion (natural-order variants of the planar lengths; everything else runs path 1).
 // Returns hipSuccess (0) or the launch error.
 template <int N>
-int launch_ct(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, int grid_cap, int nreuses, int pace, int balance, int rotate, hipStream_t stream);
-// Stockham C2C program (inverse sign), N = 256..4096.
+int launch_ct(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, const LaunchOptions& opt, hipStream_t stream);
+// Stockham C2C program (inverse sign), N = 32..4096.
 template <int N>
-int launch_st(const float2* d_input, float2* d_output, int count, int path, int grid_cap, int nreuses, int pace, int balance, int rotate, hipStream_t stream);
+int launch_st(const float2* d_input, float2* d_output, int count, int path, const LaunchOptions& opt, hipStream_t stream);
 // R2C (inverse = 0) / C2R (inverse = 1) of real length 2L, L = 256..2048.
 template <int L>
-int launch_rc(const float2* d_input, float2* d_output, int count, int inverse, int path, int grid_cap, int nreuses, int pace, int balance, int rotate, hipStream_t stream);
+int launch_rc(const float2* d_input, float2* d_output, int count, int inverse, int path, const LaunchOptions& opt, hipStream_t stream);
 
 // calibration copy of n_float2 elements (multiple of 4096) with the external kernels' access shape
 int launch_stream_copy(const float2* d_input, float2* d_output, long n_float2, int grid_cap, int pace, hipStream_t stream);
@@ -31,14 +45,20 @@ int launch_stream_read(const float2* d_input, long n_float2, int grid_cap, hipSt
 
 // ---- the balanced schedule of the multiple paths (host side: smfft_api.hip) ----------------------------------------------
 // workgroups of `kernel` (block of `threads`, static LDS only) that are co-resident on the current device; 0 if unknown
+// (a device this library has no register-file figures for: the multiple paths then run one chain per workgroup)
 int resident_workgroups(const void* kernel, int threads);
 // device counters for the launches of the calling thread, or nullptr (the normal case): see smfft_measure_multiple_residency
 unsigned* residency_probe();
 void note_resident_workgroups(int slots);     // what the last launch_compact of this thread assumed (for the probe's caller)
 int last_noted_slots();
-// a zero-initialised flag per chain for launches on `stream` of the current device, and the launch's own epoch (flags hold the
-// epoch of the launch that set them, so nothing is reset between launches); nullptr: no memory -- launch unbalanced
-unsigned* schedule_flags(int nchains, hipStream_t stream, unsigned* epoch);
+// The hand-over words of ONE balanced launch: a buffer of at least `nchains` words that no other launch in flight uses, and the
+// launch's `base` (4 * its epoch in that buffer: words hold the state of the launch that wrote them, so nothing is reset between
+// launches).  nullptr: none to be had (no memory, or too many balanced launches in flight) -- launch unbalanced.  After the
+// kernel has been enqueued the launcher calls schedule_release(ticket, stream): the buffer goes back to the pool when the stream
+// has passed that point (an event; nothing in the launch path frees memory or waits for the device).
+unsigned* schedule_acquire(int nchains, hipStream_t stream, unsigned* base, int* ticket);
+void schedule_release(int ticket, hipStream_t stream);
+constexpr int kScheduleMaxChains = 32768;      // a balanced launch has at most 4 rounds' worth of chains of at most 32 workgroups per CU
 
 inline int grid_for(int count, int ffts_per_block, int grid_cap) {
     int ntiles = (count + ffts_per_block - 1) / ffts_per_block;

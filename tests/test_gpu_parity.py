@@ -161,6 +161,178 @@ def test_ct_multiple_balanced_schedule_is_bit_identical(sm, n, inv, reo):
         sm.lib.smfft_set_multiple_balance(-1)
 
 
+def _cut_chains(ntiles, reuses, g):
+    """chains a balanced launch over g workgroups cuts, with the application they are cut at (smfft_inst.hip, launch_compact)"""
+    total = ntiles * reuses
+    per_wg = -(-total // g)
+    return [(b // reuses, b % reuses) for b in range(per_wg, total, per_wg) if b % reuses]
+
+
+@pytest.mark.parametrize("family,n", [("ct", 32), ("ct", 256), ("ct", 1024), ("ct", 4096), ("st", 2048), ("rc", 1024)])
+@pytest.mark.parametrize("after_commit", [0, 1])
+def test_balanced_schedule_survives_a_late_owner(sm, family, n, after_commit):
+    """The hand-over of a cut chain does not depend on its two workgroups running together: the
+    workgroup that parks one chain is held back for 1.5 s -- as if it had not been dispatched yet, or shared its CU with another
+    tenant.  Before its commit (after_commit = 0) the resumer stops waiting after 2 ms, runs the whole chain itself from d_input
+    and the late owner finds the chain taken and stores nothing; between the commit and the parked word (1) the resumer waits for
+    the store it has been promised.  Either way the launch ends without a trap and with the bits of one chain per workgroup."""
+    import time
+    reuses, g, ntiles = 7, 5, 23
+    cn = n // 2 if family == "rc" else n              # complex length of the tile geometry
+    tile_ffts = max(1, 1024 // cn)
+    slots = ntiles * tile_ffts
+    nffts = slots * 100
+    rng = np.random.default_rng(5000 + n + after_commit)
+    if family == "rc":
+        x = (rng.random((nffts, n), dtype=np.float32) - 0.5).astype(np.float32)
+    else:
+        x = ((rng.random((nffts, n), dtype=np.float32) - 0.5) + 1j * (rng.random((nffts, n), dtype=np.float32) - 0.5)).astype(np.complex64)
+    cuts = _cut_chains(ntiles, reuses, g)
+    assert len(cuts) >= 3
+    din, dout = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
+
+    def run():
+        sm.lib.smfft_memset(dout.ptr, 0xFF, x.nbytes)
+        t0 = time.time()
+        sm.launch(family, "multiple", din.ptr, dout.ptr, n, nffts, None if family != "ct" else False, True)
+        assert sm.lib.smfft_synchronize() == 0
+        return dout.to_host(np.uint32, (x.nbytes // 4,)), time.time() - t0
+    try:
+        sm.lib.smfft_set_nreuses(reuses)
+        sm.lib.smfft_set_multiple_balance(0)
+        want, _ = run()
+        sm.lib.smfft_set_multiple_balance(g)
+        sm.lib.smfft_set_handoff_wait_us(2000)
+        plain, t_plain = run()
+        assert np.array_equal(plain, want)
+        sm.lib.smfft_debug_delay_parking(cuts[1][0], 1500, after_commit)
+        got, t_late = run()
+        assert np.array_equal(got, want), (family, n, after_commit)
+        assert t_late > 1.4 > t_plain, (t_late, t_plain)       # the delay really happened (the owner sleeps; the kernel ends after it)
+    finally:
+        sm.lib.smfft_debug_delay_parking(-1, 0, 0)
+        sm.lib.smfft_set_handoff_wait_us(-1)
+        sm.lib.smfft_set_nreuses(0)
+        sm.lib.smfft_set_multiple_balance(-1)
+        din.free()
+        dout.free()
+
+
+def test_balanced_schedule_five_second_delay_without_a_trap(sm):
+    """VERDICT r04 item 5 to the letter: one parking store delayed by 5 s on the README batch's shape (N = 1024, the real number of
+    co-resident workgroups, default waiting time): the launch finishes, nothing traps, the result has the bits of the plain schedule."""
+    import ctypes
+    n, nffts = 1024, 524288
+    rng = np.random.default_rng(77)
+    slots = nffts // 100             # what the multiple path touches; after 100 un-normalised applications the values have overflowed, as upstream's do: bits are compared
+    x = ((rng.random((slots, n), dtype=np.float32) - 0.5) + 1j * (rng.random((slots, n), dtype=np.float32) - 0.5)).astype(np.complex64)
+    din, dout = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
+    try:
+        sm.lib.smfft_set_multiple_balance(0)
+        sm.lib.smfft_memset(dout.ptr, 0xFF, dout.nbytes)
+        sm.launch("ct", "multiple", din.ptr, dout.ptr, n, nffts, False, True)
+        assert sm.lib.smfft_synchronize() == 0
+        want = dout.to_host(np.uint32, (slots * n * 2,))
+        sm.lib.smfft_set_multiple_balance(1)
+        assumed = ctypes.c_int(0)
+        assert sm.lib.smfft_measure_multiple_residency(0, n, 0, 1, 1, ctypes.byref(assumed)) > 0
+        cuts = _cut_chains(slots, 100, assumed.value)
+        assert len(cuts) > 1000
+        sm.lib.smfft_debug_delay_parking(cuts[len(cuts) // 2][0], 5000, 0)
+        sm.lib.smfft_memset(dout.ptr, 0xFF, dout.nbytes)
+        sm.launch("ct", "multiple", din.ptr, dout.ptr, n, nffts, False, True)
+        assert sm.lib.smfft_synchronize() == 0
+        assert np.array_equal(dout.to_host(np.uint32, (slots * n * 2,)), want)
+    finally:
+        sm.lib.smfft_debug_delay_parking(-1, 0, 0)
+        sm.lib.smfft_set_multiple_balance(-1)
+        din.free()
+        dout.free()
+
+
+@pytest.mark.parametrize("n", [64, 1024, 4096])
+def test_two_host_threads_launch_balanced_batches_on_two_streams(sm, n):
+    """Two host threads, a stream each (and, second pass, hipStreamPerThread -- ONE handle that names a different stream in every
+    thread), launching README-batch `multiple` calls concurrently: each launch has its own hand-over words (they
+    used to be keyed by the stream handle), the two persistent grids share the chip -- neither is fully co-resident -- and every
+    result has the bits of a serial launch.  Nothing is freed in the launch path: the pool of hand-over buffers only grows to
+    the number of launches in flight."""
+    import ctypes
+    import threading
+    hip = ctypes.CDLL("libamdhip64.so")
+    nffts = (1 << 29) // n
+    slots = _slots(n, nffts)
+    rng = np.random.default_rng(600 + n)
+    xs = [(((rng.random((slots, n), dtype=np.float32) - 0.5) + 1j * (rng.random((slots, n), dtype=np.float32) - 0.5)) * 0.01).astype(np.complex64) for _ in range(2)]
+    dins = [sm.DeviceBuffer.from_host(x) for x in xs]
+    douts = [sm.DeviceBuffer(x.nbytes) for x in xs]
+    wants = []
+    for k in range(2):
+        sm.lib.smfft_memset(douts[k].ptr, 0xFF, xs[k].nbytes)
+        sm.launch("ct", "multiple", dins[k].ptr, douts[k].ptr, n, nffts, False, True)
+        assert sm.lib.smfft_synchronize() == 0
+        wants.append(douts[k].to_host(np.uint32, (xs[k].nbytes // 4,)))
+    per_thread = ctypes.c_void_p(2)          # hipStreamPerThread
+    errors = []
+
+    def work(k, use_per_thread):
+        try:
+            stream = ctypes.c_void_p()
+            if use_per_thread:
+                stream = per_thread
+            else:
+                assert hip.hipStreamCreate(ctypes.byref(stream)) == 0
+            for rep in range(12):
+                assert hip.hipMemsetAsync(ctypes.c_void_p(douts[k].ptr), 0xFF, ctypes.c_size_t(xs[k].nbytes), stream) == 0
+                sm.launch("ct", "multiple", dins[k].ptr, douts[k].ptr, n, nffts, False, True, stream=stream.value)
+                sm.launch("ct", "multiple", dins[k].ptr, douts[k].ptr, n, nffts, False, True, stream=stream.value)   # two in flight per stream
+                assert hip.hipStreamSynchronize(stream) == 0
+                got = douts[k].to_host(np.uint32, (xs[k].nbytes // 4,))
+                assert np.array_equal(got, wants[k]), (k, rep, use_per_thread)
+            if not use_per_thread:
+                hip.hipStreamDestroy(stream)
+        except Exception as e:       # noqa: BLE001  (reported to the main thread)
+            errors.append(repr(e))
+    try:
+        for use_per_thread in (False, True):
+            threads = [threading.Thread(target=work, args=(k, use_per_thread)) for k in range(2)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            assert not errors, errors
+        busy = ctypes.c_int(-1)
+        allocated = sm.lib.smfft_schedule_buffers(ctypes.byref(busy))
+        assert 1 <= allocated <= 8 and busy.value == 0, (allocated, busy.value)
+    finally:
+        for b in dins + douts:
+            b.free()
+
+
+def test_grid_cap_below_the_chip_keeps_the_launch_unbalanced(sm):
+    """A caller who caps the grid under what the chip holds (to leave CUs to other work) keeps that cap: the multiple path does not
+    replace it by a persistent grid of the whole chip.  (SMFFT_SCHEDULE_DEBUG prints one line per multiple launch; it is
+    read once per process, hence the child process.)"""
+    import os
+    import subprocess
+    import sys
+    nbytes = (524288 // 100) * 1024 * 8
+    code = ("import smfft_amd as sm\n"
+            "a, b = sm.DeviceBuffer(%d), sm.DeviceBuffer(%d)\n"
+            "sm.lib.smfft_memset(a.ptr, 0, %d)\n"
+            "sm.lib.smfft_set_grid_cap(512)\n"
+            "sm.launch('ct', 'multiple', a.ptr, b.ptr, 1024, 524288, False, True); sm.lib.smfft_synchronize()\n"
+            "sm.lib.smfft_set_grid_cap(12288)\n"
+            "sm.launch('ct', 'multiple', a.ptr, b.ptr, 1024, 524288, False, True); sm.lib.smfft_synchronize()\n") % (nbytes, nbytes, nbytes)
+    env = dict(os.environ, SMFFT_SCHEDULE_DEBUG="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("smfft multiple")]
+    assert len(lines) == 2, out.stdout
+    assert "grid 512," in lines[0] and "(one chain at a time)" in lines[0], lines[0]
+    assert "(one chain at a time)" not in lines[1], lines[1]
+
+
 def test_multiple_launch_captured_into_a_graph_replays_correctly(sm):
     """smfft_launch on a stream that is being captured (callers may capture their launches): the in-LDS path then
     keeps one chain per workgroup -- the balanced grid's hand-off flags carry the epoch of ONE launch and would be found set by a

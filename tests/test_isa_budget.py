@@ -50,24 +50,65 @@ def _example_isa():
     return text
 
 
+def _inst_isa(n):
+    out = f"/tmp/smfft_test_isa_{os.getpid()}_{n}.s"
+    p = subprocess.run([HIPCC] + FLAGS + [f"-DSMFFT_N={n}", "-S", "--cuda-device-only", os.path.join(ROOT, "smfft_amd", "csrc", "smfft_inst.hip"), "-o", out], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    text = open(out).read()
+    os.remove(out)
+    return text
+
+
+def _scratch_by_loop_depth(isa, mangled):
+    """scratch instructions of one kernel by the nesting depth of the block they sit in (hipcc annotates every block label with its loop)"""
+    m = re.search(r"^%s:[^\n]*\n(.*?)\n\.Lfunc_end" % re.escape(mangled), isa, re.S | re.M)
+    assert m, mangled
+    depth, found = 0, {}
+    for line in m.group(1).split("\n"):
+        if line.startswith(".LBB"):
+            d = re.findall(r"Depth=(\d+)", line)
+            depth = max(int(x) for x in d) if d else 0
+        elif re.search(r"\bscratch_(load|store)", line):
+            found[depth] = found.get(depth, 0) + 1
+    return found
+
+
 @pytest.fixture(scope="module")
 def built():
     with ThreadPoolExecutor(max_workers=4) as ex:
         futs = {n: ex.submit(_resources, n) for n in (256, 1024, 2048)}
         isa = ex.submit(_example_isa)
-        return {"res": {n: f.result() for n, f in futs.items()}, "isa": isa.result()}
+        inst = {n: ex.submit(_inst_isa, n) for n in (2048, 4096)}
+        return {"res": {n: f.result() for n, f in futs.items()}, "isa": isa.result(), "inst": {n: f.result() for n, f in inst.items()}}
 
 
 def test_in_lds_kernels_keep_four_waves_per_simd(built):
-    """the compact `multiple` kernels of the single-wave lengths and every R2C / C2R one: <= 128 VGPRs, nothing spilled"""
+    """the compact `multiple` kernels of the single-wave lengths and every R2C / C2R one: <= 128 VGPRs, nothing spilled -- the
+    two-wave R2C / C2R kernels of L = 2048 may spill set-up values (a handful of dwords), but never inside the application loop"""
     seen = 0
     for n, res in built["res"].items():
         for name, r in res.items():
             single_wave_ct = n <= 1024 and name.startswith("SMFFT_DIT_multiple<") and "unfused" not in name
             if single_wave_ct or name.startswith("FFT_GPU_R2C_C2R_multiple<"):
                 seen += 1
-                assert r["vgpr"] <= 128 and r["occ"] >= 4 and r["scratch"] == 0, (name, r)
+                assert r["vgpr"] <= 128 and r["occ"] >= 4, (name, r)
+                if n <= 1024:
+                    assert r["scratch"] == 0, (name, r)
+                else:
+                    assert r["scratch"] <= 16, (name, r)
     assert seen >= 8 + 6, seen          # 4 CT variants x 2 lengths, 2 RC directions x 3 lengths
+
+
+def test_multi_wave_in_lds_kernels_do_not_spill_in_the_application_loop(built):
+    """N = 2048 / 4096 are compiled for four waves per SIMD (128 registers): whatever they spill, they spill outside the loop over the
+    applications (block depth 2 of the kernel: the loop over a workgroup's pieces is depth 1)"""
+    checked = 0
+    for n, isa in built["inst"].items():
+        for mangled in re.findall(r"^(_Z\w*(?:SMFFT_DIT_multiple|FFT_GPU_multiple|FFT_GPU_R2C_C2R_multiple)\w*):", isa, re.M):
+            by_depth = _scratch_by_loop_depth(isa, mangled)
+            assert all(d < 2 for d in by_depth), (n, mangled, by_depth)
+            checked += 1
+    assert checked >= 7 + 7 + 2, checked
 
 
 def test_external_kernel_budget(built):

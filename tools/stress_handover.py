@@ -1,0 +1,59 @@
+"""The balanced schedule's hand-over under load: README-batch `multiple` launches (every cut chain is parked by one workgroup and
+resumed by another, usually on another XCD) must give the bits of one chain per workgroup -- every word checked, with the chip
+full, launches back to back (the resumer's CU has just read other tiles: L1 warm), and with a competing external-path kernel on
+a second stream (uneven load; the two kernels share CUs, so owners start late and some resumers take chains over).
+    python tools/stress_handover.py [rounds]"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import smfft_amd as sm  # noqa: E402
+
+hip = ctypes.CDLL("libamdhip64.so")
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+total = 1 << 29
+rng = np.random.default_rng(7)
+side_in, side_out = sm.DeviceBuffer(1 << 28), sm.DeviceBuffer(1 << 28)      # 256 MiB each way: an external N = 1024 transform of 0.1 ms
+sm.lib.smfft_memset(side_in.ptr, 0, 1 << 28)
+stream = ctypes.c_void_p()
+assert hip.hipStreamCreate(ctypes.byref(stream)) == 0
+checked = 0
+takeovers = 0
+for n in (32, 64, 128, 256, 512, 1024, 2048, 4096):
+    nffts = total // n
+    slots = nffts // 400 * 4 if n == 32 else nffts // 200 * 2 if n == 64 else nffts // 100
+    x = ((rng.random((slots, n), dtype=np.float32) - 0.5) + 1j * (rng.random((slots, n), dtype=np.float32) - 0.5)).astype(np.complex64)
+    din, dout = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
+    for reo in (1, 0):
+        for reuses in (4, 100):
+            sm.lib.smfft_set_nreuses(reuses)
+            sm.lib.smfft_set_multiple_balance(0)
+            sm.lib.smfft_memset(dout.ptr, 0xFF, x.nbytes)
+            sm.launch("ct", "multiple", din.ptr, dout.ptr, n, nffts, False, bool(reo))
+            assert sm.lib.smfft_synchronize() == 0
+            want = dout.to_host(np.uint32, (x.nbytes // 4,))
+            sm.lib.smfft_set_multiple_balance(-1)
+            for r in range(rounds):
+                loaded = r % 2 == 1
+                if r % 4 == 3:
+                    sm.lib.smfft_set_handoff_wait_us(20)       # impatient resumers: take-overs under load
+                sm.lib.smfft_memset(dout.ptr, 0xFF, x.nbytes)
+                if loaded:
+                    for _ in range(6):
+                        sm.launch("ct", "external", side_in.ptr, side_out.ptr, 1024, (1 << 28) // 8192, False, True, stream=stream.value)
+                sm.launch("ct", "multiple", din.ptr, dout.ptr, n, nffts, False, bool(reo))
+                sm.launch("ct", "multiple", din.ptr, dout.ptr, n, nffts, False, bool(reo))      # back to back: same tiles, other workgroups' L1s warm
+                assert sm.lib.smfft_synchronize() == 0
+                got = dout.to_host(np.uint32, (x.nbytes // 4,))
+                bad = np.flatnonzero(got != want)
+                assert bad.size == 0, (n, reo, reuses, r, loaded, bad.size, int(bad[0]))
+                sm.lib.smfft_set_handoff_wait_us(-1)
+                checked += 1
+    din.free()
+    dout.free()
+    print(f"N={n}: ok", flush=True)
+sm.lib.smfft_set_nreuses(0)
+print(f"{checked} pairs of README-batch launches on the balanced schedule (idle chip / competing kernel / impatient resumers): every word has the bits of one chain per workgroup")
