@@ -75,13 +75,13 @@ def cpu_baseline(x, threads):
             for thr in cands:
                 if time.time() - t_start > 30.0:
                     break
-                t = fb.fftw_baseline_c2c_sliced(x.ctypes.data_as(fp), out.ctypes.data_as(fp), n, sample_ffts, 0, 3, thr)
+                t = fb.fftw_baseline_c2c_sliced(x.ctypes.data_as(fp), out.ctypes.data_as(fp), n, sample_ffts, 0, 5, thr)
                 if 0 < t < best_all:
                     best_all, best_thr = t, thr
         if best_all < 1e29:
             res = {"value": sample_ffts / best_all, "unit": "FFT/s", "cores": best_thr, "kind": "port",
                    "impl": fb.fftw_baseline_backend().decode() + " fftwf_plan_many_dft (FFTW_ESTIMATE) per batch slice, out of place, slices on pthreads; thread counts tried " + str(cands),
-                   "sample": f"N={n} C2C forward, {sample_ffts} FFTs ({x.nbytes >> 20} MiB): the GPU run's own input copied to the host, best of 3 passes per thread count",
+                   "sample": f"N={n} C2C forward, {sample_ffts} FFTs ({x.nbytes >> 20} MiB): the GPU run's own input copied to the host, best of 5 passes per thread count",
                    "host_cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
     except OSError:
         pass
@@ -90,13 +90,13 @@ def cpu_baseline(x, threads):
         olib.oracle_ct_c2c_f32.argtypes = [fp, fp, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int]
         part = min(sample_ffts, 131072)
         best = 1e30
-        for _ in range(3):
+        for _ in range(5):
             t0 = time.time()
             olib.oracle_ct_c2c_f32(x.ctypes.data_as(fp), out.ctypes.data_as(fp), n, part, 0, 1)
             best = min(best, time.time() - t0)
         res = {"value": part / best, "unit": "FFT/s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
                "kind": "port", "impl": "oracle/smfft_oracle.c radix-2 restatement, OpenMP over FFTs",
-               "sample": f"N={n} C2C forward, the first {part} FFTs of the GPU run's input, best of 3"}
+               "sample": f"N={n} C2C forward, the first {part} FFTs of the GPU run's input, best of 5"}
     res["GB/s"] = res["value"] * 2 * n * 8 / 1e9
     return res
 

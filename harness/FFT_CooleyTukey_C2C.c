@@ -46,7 +46,9 @@ int main(int argc, char **argv) {
 	if (reorder) {
 		GPU_cuFFT(h_input, h_output_cuFFT, FFT_size, nFFTs, inverse, nRuns, &cuFFT_execution_time);
 		GPU_smFFT_4elements(h_input, h_output_smFFT, FFT_size, nFFTs, inverse, reorder, nRuns, &smFFT_execution_time, &smFFT_multiple_execution_time);
-		print_verdict(Compare_data(h_output_cuFFT, h_output_smFFT, FFT_size, nFFTs, &cumulative_error, &mean_error));
+		const int nErrors = Compare_data(h_output_cuFFT, h_output_smFFT, FFT_size, nFFTs, &cumulative_error, &mean_error);
+		print_verdict(nErrors);
+		if (nErrors > 0) harness_attribute(h_input, h_output_cuFFT, h_output_smFFT, FFT_size, inverse ? 1 : -1, false);   // (an extension: upstream stops at the verdict)
 	}
 	else if (getenv("SMFFT_HARNESS_VERIFY_NOREORDER") == NULL) {
 		// exactly as upstream (FFT.c:150-163): the transform runs and is timed, nothing is compared
@@ -72,7 +74,9 @@ int main(int argc, char **argv) {
 		free(h_bitrev);
 		GPU_smFFT_4elements(h_input, h_output_smFFT, FFT_size, nFFTs, inverse, reorder, nRuns, &smFFT_execution_time, &smFFT_multiple_execution_time);
 		printf("  Results without reordering are checked against the vendor FFT of the bit-reversed input.\n");
-		print_verdict(Compare_data(h_output_cuFFT, h_output_smFFT, FFT_size, nFFTs, &cumulative_error, &mean_error));
+		const int nErrors = Compare_data(h_output_cuFFT, h_output_smFFT, FFT_size, nFFTs, &cumulative_error, &mean_error);
+		print_verdict(nErrors);
+		if (nErrors > 0) harness_attribute(h_input, h_output_cuFFT, h_output_smFFT, FFT_size, inverse ? 1 : -1, true);
 	}
 
 	free(h_input); free(h_output_smFFT); free(h_output_cuFFT);

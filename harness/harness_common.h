@@ -99,30 +99,81 @@ static inline float get_error(float2 A, float2 B) {
 	return get_error(A.x > A.y ? A.x : A.y, B.x > B.y ? B.x : B.y);
 }
 
-// CT/FFT.c:52-77 (same metric and counts; evaluated per chunk on all cores, partial sums added in chunk order)
+// CT/FFT.c:52-77 (same metric and counts; evaluated per chunk on all cores, partial sums added in chunk order).
+// The element with the largest error is remembered (harness_worst_pos) for harness_attribute below.
+static size_t harness_worst_pos = 0;
+static double harness_worst_error = -1;
 static inline int Compare_data(float2 *vendor_result, float2 *smFFT_result, int FFT_size, int nFFTs, double *cumulative_error, double *mean_error) {
 	static int errors[HARNESS_CHUNKS];
-	static double sums[HARNESS_CHUNKS];
-	for (int c = 0; c < HARNESS_CHUNKS; c++) { errors[c] = 0; sums[c] = 0; }
+	static double sums[HARNESS_CHUNKS], worst[HARNESS_CHUNKS];
+	static size_t worst_at[HARNESS_CHUNKS];
+	for (int c = 0; c < HARNESS_CHUNKS; c++) { errors[c] = 0; sums[c] = 0; worst[c] = -1; worst_at[c] = 0; }
 	harness_parallel_chunks((size_t) FFT_size*nFFTs, [&](size_t a, size_t b, int c) {
 		int nErrors = 0;
-		double sum = 0;
+		double sum = 0, w = -1;
+		size_t wa = a;
 		for (size_t pos = a; pos < b; pos++) {
 			float er = get_error(vendor_result[pos].x, smFFT_result[pos].x);
 			float ei = get_error(vendor_result[pos].y, smFFT_result[pos].y);
 			double e = (er >= ei ? er : ei);
 			if (e > max_error) nErrors++;
+			if (e > w) { w = e; wa = pos; }
 			sum += e;
 		}
 		errors[c] = nErrors;
 		sums[c] = sum;
+		worst[c] = w;
+		worst_at[c] = wa;
 	});
 	int nErrors = 0;
 	double sum = 0;
-	for (int c = 0; c < HARNESS_CHUNKS; c++) { nErrors += errors[c]; sum += sums[c]; }
+	harness_worst_error = -1;
+	for (int c = 0; c < HARNESS_CHUNKS; c++) {
+		nErrors += errors[c];
+		sum += sums[c];
+		if (worst[c] > harness_worst_error) { harness_worst_error = worst[c]; harness_worst_pos = worst_at[c]; }
+	}
 	*cumulative_error = sum;
 	*mean_error = sum/((double) FFT_size*nFFTs);
 	return nErrors;
+}
+
+// WHO IS OFF when the metric above reports errors?  Upstream's check is a comparison of two fp32 results under an ABSOLUTE
+// bound (max_error = 1e-4 on U[0,1) data, CT/FFT.c:12,23-49): at N >= 2048 the bins are large enough (DC ~ N/2) for the fp32
+// round-off of either side to exceed it, and the verdict says FAILED without saying whose.  This prints, for the worst element,
+// both values against the un-normalised DFT of the same input evaluated on the host in fp64 (one bin: N terms), and each
+// side's distance from it relative to the largest bin of that FFT -- the measure this library's own tests gate on (1e-6).
+// sign: -1 forward, +1 inverse; bitrev: the transform of the bit-reversed input (reorder = 0).
+static inline void harness_dft_bin(const float2 *x, int N, int k, int sign, bool bitrev, double *re, double *im) {
+	int bits = 0;
+	while ((1 << bits) < N) bits++;
+	const double w = sign*2.0*M_PI/N;
+	double sr = 0, si = 0;
+	for (int n = 0; n < N; n++) {
+		int src = n;
+		if (bitrev) { src = 0; for (int b = 0; b < bits; b++) src |= ((n >> b) & 1) << (bits - 1 - b); }
+		const double c = cos(w*(double) ((long) n*k % N)), s = sin(w*(double) ((long) n*k % N));
+		sr += x[src].x*c - x[src].y*s;
+		si += x[src].x*s + x[src].y*c;
+	}
+	*re = sr; *im = si;
+}
+static inline void harness_attribute(const float2 *h_input, const float2 *vendor, const float2 *smFFT, int FFT_size, int sign, bool bitrev) {
+	const size_t f = harness_worst_pos/FFT_size;
+	const int k = (int) (harness_worst_pos % FFT_size);
+	const float2 *x = h_input + f*FFT_size;
+	double re, im, dre, dim;
+	harness_dft_bin(x, FFT_size, k, sign, bitrev, &re, &im);
+	harness_dft_bin(x, FFT_size, 0, sign, bitrev, &dre, &dim);     // U[0,1) data: the DC bin is the largest
+	double largest = sqrt(dre*dre + dim*dim);
+	const double here = sqrt(re*re + im*im);
+	if (here > largest) largest = here;
+	const float2 a = smFFT[harness_worst_pos], b = vendor[harness_worst_pos];
+	const double ea = sqrt((a.x - re)*(a.x - re) + (a.y - im)*(a.y - im)), eb = sqrt((b.x - re)*(b.x - re) + (b.y - im)*(b.y - im));
+	printf("  Worst element (error %g by the metric above): FFT %zu, bin %d: smFFT (%.9g, %.9g), vendor FFT (%.9g, %.9g), fp64 DFT of the same input (%.12g, %.12g)\n",
+	       harness_worst_error, f, k, a.x, a.y, b.x, b.y, re, im);
+	printf("  Distance from the fp64 DFT, relative to the largest bin of that FFT (%.6g): smFFT %.3e, vendor FFT %.3e  (fp32 round-off of a %d-point transform is ~1e-7; this library's tests gate on 1e-6)\n",
+	       largest, ea/largest, eb/largest, FFT_size);
 }
 
 // positional integer arguments; prints `usage` and returns false unless exactly n are given

@@ -112,28 +112,32 @@ __device__ __forceinline__ void gstore(float2* p, float2 a) {
 #endif
 }
 
-// Tile accesses of the in-LDS (`multiple`) kernels.  SHARED = the tile is handed from one workgroup of the launch to another (the
-// balanced schedule parks a cut chain in its slot of d_output): the stores are WRITE-THROUGH (`sc1`: the bytes leave the storing
-// XCD's L2, whose lines no other XCD can see) and the loads `sc1` global loads (never served by the loading CU's L1), so the
-// hand-over needs no cache-wide write-back or invalidate -- a workgroup's `buffer_wbl2` cost the README launches 10-90 us
-// (profiles/r05_handover_forms.txt).  Agent-scope relaxed atomics on global (address space 1) pointers are exactly those
-// instructions (MI355X_MICROARCH.md, inter-workgroup visibility: valid forms).
+// Tile accesses of the in-LDS (`multiple`) kernels.  A tile that is handed from one workgroup of the launch to another (the
+// balanced schedule parks a cut chain in its slot of d_output) is stored WRITE-THROUGH (`sc1`: the bytes leave the storing XCD's
+// L2, whose lines no other XCD can see) and loaded with `sc1` loads (never served by the loading CU's L1), so the hand-over needs
+// no cache-wide write-back or invalidate -- a workgroup's `buffer_wbl2` cost the README launches 10-90 us
+// (profiles/r05_handover_forms.txt; MI355X_MICROARCH.md, inter-workgroup visibility: valid forms).
 typedef __attribute__((address_space(1))) unsigned long long global_u64;
 typedef __attribute__((address_space(1))) unsigned global_u32;
-template <bool SHARED>
-__device__ __forceinline__ float2 tile_load(const float2* p) {
-    if constexpr (SHARED) {
-        const unsigned long long x = __hip_atomic_load((const global_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return make_float2(__uint_as_float((unsigned)x), __uint_as_float((unsigned)(x >> 32)));
-    } else {
-        return *p;
+// Such a tile as a raw buffer: 16 bytes per lane and instruction with the `sc1` bit (aux = 16) -- an 8-byte sc1 store is a fabric
+// write of its own and costs 2.7 times the bytes of a 16-byte one (MI355X_MICROARCH.md).  num_records = the bytes of the tile that
+// belong to the batch: accesses beyond them are dropped (stores) or return zero (loads), which is exactly what a ragged last tile
+// needs.  `tile` must be wave-uniform.
+typedef unsigned tile_quad __attribute__((ext_vector_type(4)));
+struct SharedTile {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ SharedTile(const void* tile, long valid_bytes) : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(tile), 0, (int)valid_bytes, 0x00020000)) {}
+    // elements e, e + 1 of the tile (e even)
+    __device__ __forceinline__ void load2(int e, float2& a, float2& b) const {
+        const tile_quad w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 8 * e, 0, 16);
+        a = make_float2(__uint_as_float(w[0]), __uint_as_float(w[1]));
+        b = make_float2(__uint_as_float(w[2]), __uint_as_float(w[3]));
     }
-}
-template <bool SHARED>
-__device__ __forceinline__ void tile_store(float2* p, float2 v) {
-    if constexpr (SHARED) __hip_atomic_store((global_u64*)p, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
+    __device__ __forceinline__ void store2(int e, float2 a, float2 b) const {
+        const tile_quad w = {__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(b.x), __float_as_uint(b.y)};
+        __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, 8 * e, 0, 16);
+    }
+};
 
 // W_N^m (forward sign) or its conjugate (inverse), from the fp64-rounded table.
 // (v_cos_f32 / v_sin_f32 on the exact fraction m/4096 instead of the table was tried in round 2: no memory access, but a
@@ -344,8 +348,12 @@ struct Engine {
     static constexpr int S1 = G::S1, S2 = G::S2, S0 = G::S0, SF = G::SF;
     static constexpr int E_BITS = ilog2c(N), T_BITS = ilog2c(T), R1_BITS = ilog2c(R1), B1_BITS = ilog2c(B1);
 
-    // physical lane bit of thread bit i of a register-two-pass FFT
-    static constexpr int kLaneShift = G::kRegTwoPass ? 4 - T_BITS : 0;
+    // physical lane bit of thread bit i of a register-two-pass FFT: i + kLaneShift -- the top log2(T) bits of the position inside a
+    // 16-lane row (row-DPP transposes).  (N = 32 with its two threads in neighbouring 16-lane rows instead -- lane bit 4, one
+    // v_permlane16_swap per dword pair where the row form takes two v_mov_b32_dpp and a copy: 125 against 210 SIMD cycles by the
+    // microbenchmark of the forms, profiles/r02_valu_forms.txt -- measured 8-10 % SLOWER in the in-LDS kernel: the swaps do not
+    // overlap with the other waves' arithmetic the way the DPP moves do; profiles/r05_ab_n32_permlane.txt.  kLaneShift = 4 builds it.)
+    static constexpr int kLaneShift = !G::kRegTwoPass ? 0 : 4 - T_BITS;
 
     int u;        // thread inside the FFT
     int fft;      // FFT inside the workgroup
@@ -362,7 +370,8 @@ struct Engine {
             // every LDS instruction still touches the same set of addresses per lane group
             const int lane = tid & 63;
             u = (lane >> kLaneShift) & (T - 1);
-            fft = (tid >> 6) * (64 / T) + (lane >> 4) * (16 / T) + (lane & ((1 << kLaneShift) - 1));
+            if constexpr (kLaneShift == 4) fft = (tid >> 6) * 32 + (lane >> 5) * 16 + (lane & 15);
+            else fft = (tid >> 6) * (64 / T) + (lane >> 4) * (16 / T) + (lane & ((1 << kLaneShift) - 1));
         }
         t2 = u & 15;
         a = u >> 4;
@@ -595,7 +604,8 @@ struct Engine {
                 case 0: swap_bit_quad<0>(A, B, hi); break;
                 case 1: swap_bit_quad<1>(A, B, hi); break;
                 case 2: swap_bit_dpp_dword<2>(A.x, B.x, hi); swap_bit_dpp_dword<2>(A.y, B.y, hi); break;
-                default: swap_bit_dpp_dword<3>(A.x, B.x, hi); swap_bit_dpp_dword<3>(A.y, B.y, hi); break;
+                case 3: swap_bit_dpp_dword<3>(A.x, B.x, hi); swap_bit_dpp_dword<3>(A.y, B.y, hi); break;
+                default: swap_bit<4>(A, B); break;
             }
         }
     }

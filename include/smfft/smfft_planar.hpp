@@ -483,12 +483,20 @@ struct PlanarEngine {
 
 // tile <-> planar image (once per tile): element e = fft * N + n of the tile, n = u + T*c, lies in row c at dword
 // fft * T + position(u); position(u) = u, or the position of the thread whose pass-1 role is u (reorder)
-// (g is not __restrict__: a resumed piece of a cut chain reads what another workgroup of the same launch stored -- SHARED, see tile_load)
-template <int N, int DIR, int REORDER, bool SHARED = false>
+// (g is not __restrict__: a resumed piece of a cut chain reads what another workgroup of the same launch stored)
+template <int N, int DIR, int REORDER>
+__device__ __forceinline__ float* plane_word_of(float* planes, int e) {
+    using E = PlanarEngine<N, DIR, REORDER>;
+    using P = PlanarGeometry<N, REORDER>;
+    const int f = e / N, n = e % N, u = n % E::T, row = n / E::T;
+    const int pos = E::kForward ? E::position_of_role(u) : u;
+    return planes + P::image_row(row) + f * E::T + pos;
+}
+template <int N, int DIR, int REORDER>
 __device__ __forceinline__ void tile_to_planes(const float2* g, float* planes, long first_fft, long limit_fft) {
     using E = PlanarEngine<N, DIR, REORDER>;
     using P = PlanarGeometry<N, REORDER>;
-    constexpr int T = E::T, TW = E::TW;
+    constexpr int TW = E::TW;
     // (opaque copy of the thread index: the sixteen addresses below are computed where they are used, once per chain, instead
     //  of being hoisted out of the loop over chains and kept in registers across the applications)
     int tid = (int)threadIdx.x;
@@ -499,35 +507,68 @@ __device__ __forceinline__ void tile_to_planes(const float2* g, float* planes, l
     for (int c = 0; c < 16; ++c) {
         const int e = tid + TW * c;
         const bool ok = full || (first_fft + e / N < limit_fft);
-        const float2 t = tile_load<SHARED>(g + (ok ? e : 0));
+        const float2 t = g[ok ? e : 0];
         val[c] = ok ? t : make_float2(0.f, 0.f);
     }
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        const int e = tid + TW * c;
-        const int f = e / N, n = e % N, u = n % T, row = n / T;
-        const int pos = E::kForward ? E::position_of_role(u) : u;
-        float* p = planes + P::image_row(row) + f * T + pos;
+        float* p = plane_word_of<N, DIR, REORDER>(planes, tid + TW * c);
         p[0] = val[c].x;
         p[P::kPlane] = val[c].y;
     }
 }
-template <int N, int DIR, int REORDER, bool SHARED = false>
+template <int N, int DIR, int REORDER>
 __device__ __forceinline__ void planes_to_tile(float2* g, const float* planes, long first_fft, long limit_fft) {
     using E = PlanarEngine<N, DIR, REORDER>;
     using P = PlanarGeometry<N, REORDER>;
-    constexpr int T = E::T, TW = E::TW;
+    constexpr int TW = E::TW;
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
     const bool full = first_fft + P::F <= limit_fft;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         const int e = tid + TW * c;
-        const int f = e / N, n = e % N, u = n % T, row = n / T;
-        const int pos = E::kForward ? E::position_of_role(u) : u;
-        const float* p = planes + P::image_row(row) + f * T + pos;
+        const float* p = plane_word_of<N, DIR, REORDER>(const_cast<float*>(planes), e);
         const float2 t = make_float2(p[0], p[P::kPlane]);
-        if (full || first_fft + f < limit_fft) tile_store<SHARED>(g + e, t);
+        if (full || first_fft + e / N < limit_fft) g[e] = t;
+    }
+}
+// The same two copies for a tile that changes hands inside the launch (SharedTile: write-through stores, sc1 loads, 16 bytes per
+// lane: elements 2 * tid, 2 * tid + 1 of every 2 * TW)
+template <int N, int DIR, int REORDER>
+__device__ __forceinline__ void shared_tile_to_planes(const float2* g, float* planes, long first_fft, long limit_fft) {
+    using E = PlanarEngine<N, DIR, REORDER>;
+    using P = PlanarGeometry<N, REORDER>;
+    constexpr int TW = E::TW;
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const long ffts = limit_fft - first_fft < P::F ? limit_fft - first_fft : P::F;
+    const SharedTile tile(g, ffts * N * 8);
+    float2 val[16];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) tile.load2(2 * tid + 2 * TW * c, val[2 * c], val[2 * c + 1]);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float* p = plane_word_of<N, DIR, REORDER>(planes, 2 * tid + (c & 1) + 2 * TW * (c >> 1));
+        p[0] = val[c].x;
+        p[P::kPlane] = val[c].y;
+    }
+}
+template <int N, int DIR, int REORDER>
+__device__ __forceinline__ void planes_to_shared_tile(float2* g, const float* planes, long first_fft, long limit_fft) {
+    using E = PlanarEngine<N, DIR, REORDER>;
+    using P = PlanarGeometry<N, REORDER>;
+    constexpr int TW = E::TW;
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const long ffts = limit_fft - first_fft < P::F ? limit_fft - first_fft : P::F;
+    const SharedTile tile(g, ffts * N * 8);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int e = 2 * tid + 2 * TW * c;
+        const float* p = plane_word_of<N, DIR, REORDER>(const_cast<float*>(planes), e);
+        const float* q = plane_word_of<N, DIR, REORDER>(const_cast<float*>(planes), e + 1);
+        tile.store2(e, make_float2(p[0], p[P::kPlane]), make_float2(q[0], q[P::kPlane]));
     }
 }
 

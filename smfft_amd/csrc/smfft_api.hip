@@ -162,6 +162,22 @@ bool wrapper_memory_ok(size_t pair_bytes_each, size_t needed, size_t free_mem) {
 }
 
 
+// The L3 wrappers time nRuns launches right after a multi-GiB upload, i.e. on a device whose shader clock has fallen back: the
+// first tens of milliseconds of in-LDS launches then run 20-40 % under the settled rate (clocks follow the load on MI355X;
+// profiles/r03_warm_ramp.txt), and with upstream's nRuns = 20 the reported mean is mostly ramp.  The wrappers therefore run the
+// SAME launch untimed until it has accumulated SMFFT_WRAPPER_WARMUP_MS (default 40; 0 = upstream's behaviour) of kernel time,
+// then time nRuns launches exactly as upstream does (CT:862-871).  The results are the same launches' results.
+template <class F>
+void wrapper_warm_up(F&& timed_launch) {
+    static const double budget = [] { const char* e = getenv("SMFFT_WRAPPER_WARMUP_MS"); return e ? atof(e) : 40.0; }();
+    double spent = 0;
+    for (int i = 0; i < 4096 && spent < budget; ++i) {
+        const double before = spent;
+        timed_launch(&spent);
+        if (!(spent > before)) break;            // nothing ran (unsupported length, batch too small): nothing to warm up
+    }
+}
+
 int select_device() {
     read_env();
     int devCount = 0;
@@ -400,6 +416,7 @@ int smfft_gpu_ct(const void* h_input, void* h_output, int FFT_size, int nFFTs, i
         if (DEBUG) printf("  Running shared memory FFT (Cooley-Tukey) 100 times per GPU kernel (eliminates device memory)... ");
         smfft_init();
         double total = 0;
+        wrapper_warm_up([&](double* t) { smfft_ct_multiple_benchmark(d_input, d_output, FFT_size, nFFTs, inverse, reorder, t); });
         for (int f = 0; f < nRuns; f++) {
             smfft_ct_multiple_benchmark(d_input, d_output, FFT_size, nFFTs, inverse, reorder, &total);
         }
@@ -444,6 +461,7 @@ int smfft_gpu_st(const void* h_input, void* h_output, int FFT_size, int nFFTs, i
     if (MULTIPLE) {
         smfft_init();
         double total = 0;
+        wrapper_warm_up([&](double* t) { smfft_st_multiple_benchmark(d_input, d_output, FFT_size, nFFTs, t); });
         for (int f = 0; f < nRuns; f++) {
             smfft_st_multiple_benchmark(d_input, d_output, FFT_size, nFFTs, &total);
         }
@@ -482,6 +500,7 @@ int smfft_gpu_r2c(void* h_output, const float* h_input, int FFT_size, int nFFTs,
     if (alloc_pair_for_wrapper(input_size_bytes, (void**)&d_input, (void**)&d_output)) checkHipErrors(hipErrorOutOfMemory);   // both sides are N*nFFTs*4 bytes
     checkHipErrors(hipMemcpy(d_input, h_input, input_size_bytes, hipMemcpyHostToDevice));
     if (MULTIPLE) {
+        wrapper_warm_up([&](double* t) { smfft_rc_multiple_benchmark(d_input, (float*)d_output, FFT_size, nFFTs, t); });
         for (int r = 0; r < nRuns; r++) {
             smfft_init();
             smfft_rc_multiple_benchmark(d_input, (float*)d_output, FFT_size, nFFTs, &FFT_multiple_time);

@@ -82,10 +82,12 @@ static int launch_compact(CompactKernel kernel, const float2* d_input, float2* d
         (void)hipMemcpy(host.data(), sch.trace, host.size() * 8, hipMemcpyDeviceToHost);
         (void)hipFree(sch.trace);
         if (FILE* f = fopen(trace_file, "w")) {
-            fprintf(f, "# N=%d chains=%d nreuses=%d grid=%d per_wg=%d : block start end hw_id xcc_id start_100MHz end_100MHz first_tile_loaded_100MHz\n", SMFFT_N, ntiles, nreuses, grid, sch.per_wg);
+            fprintf(f, "# N=%d chains=%d nreuses=%d grid=%d per_wg=%d : block start end hw_id xcc_id start_100MHz end_100MHz, then per piece (up to four): tile_in_LDS applications_done tile_stored (100 MHz)\n", SMFFT_N, ntiles, nreuses, grid, sch.per_wg);
             for (int i = 0; i < grid; ++i) {
                 const unsigned long long* w = &host[(size_t)i * kTraceWords];
-                fprintf(f, "%d %llu %llu %llx %llx %llu %llu %llu\n", i, w[0], w[1], w[2], w[3], w[4], w[5], w[6]);
+                fprintf(f, "%d %llu %llu %llx %llx %llu %llu", i, w[0], w[1], w[2], w[3], w[4], w[5]);
+                for (int k = 6; k < kTraceWords; ++k) fprintf(f, " %llu", w[k]);
+                fprintf(f, "\n");
             }
             fclose(f);
         }

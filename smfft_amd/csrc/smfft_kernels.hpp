@@ -169,7 +169,7 @@ constexpr int compact_lds_offset(int c) {
     const int e = G::kCompactThreads * c;
     return (e / N) * G::SF + (e % N) + (PADDED ? ((e % N) >> G::kPadShift) : 0);
 }
-template <int N, bool PADDED, bool SHARED = false>
+template <int N, bool PADDED>
 __device__ __forceinline__ void tile_to_lds(const float2* g, float2* s, long first_fft, long limit_fft) {
     using G = Geometry<N>;
     constexpr int C = G::kCompactTile / G::kCompactThreads;
@@ -177,13 +177,13 @@ __device__ __forceinline__ void tile_to_lds(const float2* g, float2* s, long fir
     float2 v[C];
     if (first_fft + G::kCompactFfts <= limit_fft) {      // whole tile inside the batch: loads back to back, no predicate
 #pragma unroll
-        for (int c = 0; c < C; ++c) v[c] = tile_load<SHARED>(g + threadIdx.x + G::kCompactThreads * c);
+        for (int c = 0; c < C; ++c) v[c] = g[threadIdx.x + G::kCompactThreads * c];
     } else {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int e = threadIdx.x + G::kCompactThreads * c;
             const bool ok = first_fft + e / N < limit_fft;
-            const float2 t = tile_load<SHARED>(g + (ok ? e : 0));   // g[0] belongs to FFT first_fft, which exists
+            const float2 t = g[ok ? e : 0];              // g[0] belongs to FFT first_fft, which exists
             v[c] = ok ? t : make_float2(0.f, 0.f);
         }
     }
@@ -191,7 +191,7 @@ __device__ __forceinline__ void tile_to_lds(const float2* g, float2* s, long fir
 #pragma unroll
     for (int c = 0; c < C; ++c) base[compact_lds_offset<N, PADDED>(c)] = v[c];
 }
-template <int N, bool PADDED, bool SHARED = false>
+template <int N, bool PADDED>
 __device__ __forceinline__ void lds_to_tile(float2* g, const float2* s, long first_fft, long limit_fft) {
     using G = Geometry<N>;
     constexpr int C = G::kCompactTile / G::kCompactThreads;
@@ -201,13 +201,46 @@ __device__ __forceinline__ void lds_to_tile(float2* g, const float2* s, long fir
     for (int c = 0; c < C; ++c) v[c] = base[compact_lds_offset<N, PADDED>(c)];
     if (first_fft + G::kCompactFfts <= limit_fft) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) tile_store<SHARED>(g + threadIdx.x + G::kCompactThreads * c, v[c]);
+        for (int c = 0; c < C; ++c) g[threadIdx.x + G::kCompactThreads * c] = v[c];
     } else {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int e = threadIdx.x + G::kCompactThreads * c;
-            if (first_fft + e / N < limit_fft) tile_store<SHARED>(g + e, v[c]);
+            if (first_fft + e / N < limit_fft) g[e] = v[c];
         }
+    }
+}
+
+// The same two copies for a tile that changes hands inside the launch (SharedTile: write-through stores, sc1 loads, 16 bytes per
+// lane: elements 2 * tid, 2 * tid + 1 of every 2 * kCompactThreads)
+template <int N, bool PADDED>
+__device__ __forceinline__ int compact_lds_index(int e) {
+    using G = Geometry<N>;
+    const int n = e % N;
+    return (e / N) * G::SF + n + (PADDED ? (n >> G::kPadShift) : 0);
+}
+template <int N, bool PADDED>
+__device__ __forceinline__ void shared_tile_to_lds(const float2* g, float2* s, long first_fft, long limit_fft) {
+    using G = Geometry<N>;
+    constexpr int C = G::kCompactTile / G::kCompactThreads / 2;
+    const long ffts = limit_fft - first_fft < G::kCompactFfts ? limit_fft - first_fft : G::kCompactFfts;
+    const SharedTile tile(g, ffts * N * 8);
+    float2 v[2 * C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) tile.load2(2 * (int)threadIdx.x + 2 * G::kCompactThreads * c, v[2 * c], v[2 * c + 1]);
+#pragma unroll
+    for (int c = 0; c < 2 * C; ++c) s[compact_lds_index<N, PADDED>(2 * (int)threadIdx.x + (c & 1) + 2 * G::kCompactThreads * (c >> 1))] = v[c];
+}
+template <int N, bool PADDED>
+__device__ __forceinline__ void lds_to_shared_tile(float2* g, const float2* s, long first_fft, long limit_fft) {
+    using G = Geometry<N>;
+    constexpr int C = G::kCompactTile / G::kCompactThreads / 2;
+    const long ffts = limit_fft - first_fft < G::kCompactFfts ? limit_fft - first_fft : G::kCompactFfts;
+    const SharedTile tile(g, ffts * N * 8);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int e = 2 * (int)threadIdx.x + 2 * G::kCompactThreads * c;
+        tile.store2(e, s[compact_lds_index<N, PADDED>(e)], s[compact_lds_index<N, PADDED>(e + 1)]);
     }
 }
 
@@ -227,18 +260,18 @@ __device__ __forceinline__ void lds_to_tile(float2* g, const float2* s, long fir
 // The hand-over is a word per chain (ChainState below), agent-scope atomics (the two workgroups sit on different XCDs, whose L2s
 // are not coherent with each other).  It does NOT rely on the two workgroups being co-resident or on any dispatch order (round 5):
 // a resumer that has waited `wait_ticks` for a chain nobody has committed to parking TAKES the chain -- it runs ALL of the chain's
-// applications itself from d_input, which gives the same bits -- and an owner that finds its chain taken stores nothing.  So every
-// wait is bounded by the owner's own tile store, whatever else runs on the device (another stream's kernels, another process, a
-// balanced launch of another host thread); the price of a take-over is at most one chain's worth of repeated applications.
+// applications itself from d_input, which gives the same bits -- and an owner that finds its chain taken when it starts leaves it
+// alone.  So every wait is for a workgroup that is running, whatever else occupies the device (another stream's kernels, another
+// process, a balanced launch of another host thread); nothing is computed twice.
 // per_wg = 0: the old schedule (one chain at a time, grid-strided; no hand-overs).
 struct MultipleSchedule {
     int per_wg;              // applications per workgroup (> nreuses), or 0: grid-stride over whole chains
     unsigned base;           // 4 * the launch's epoch: flags[c] - base is the ChainState of chain c in THIS launch (smaller: an earlier launch's)
     unsigned* flags;         // one per chain, device memory owned by the host API (one buffer per launch in flight)
     int rotate;              // > 0: the wave's scheduling priority rotates every 2^rotate shader clocks (see WavePriority)
-    unsigned wait_ticks;     // 100 MHz ticks a resumer waits for an uncommitted chain before it takes it over
+    unsigned wait_ticks;     // 100 MHz ticks a resumer waits for a chain whose owner has not started before it takes it over
     int delay_chain;         // fault injection (tests; -1: none): the owner of this chain sleeps delay_ticks ...
-    unsigned delay_ticks;    //   ... before it commits to parking (delay_after_commit = 0) or between the commit and the parked flag (1)
+    unsigned delay_ticks;    //   ... before it commits to the chain (delay_after_commit = 0) or between its tile store and the parked word (1)
     int delay_after_commit;
     unsigned* residency;     // calibration launches only: [0] workgroups alive now, [1] the most that were alive at once
     unsigned long long* trace;   // experiments (SMFFT_SCHEDULE_TRACE): per workgroup {start, end} of s_memrealtime + {HW_ID, XCC_ID}; nullptr otherwise
@@ -250,8 +283,9 @@ __device__ __forceinline__ void residency_enter(unsigned* r) {
 __device__ __forceinline__ void residency_leave(unsigned* r) {
     if (r && threadIdx.x == 0) atomicSub(r, 1u);
 }
-// per workgroup: [0] start, [1] end (shader clock of its XCD), [2] HW_ID, [3] XCC_ID, [4] start, [5] end, [6] first tile in LDS (100 MHz, device-wide)
-constexpr int kTraceWords = 8;
+// per workgroup: [0] start, [1] end (shader clock of its XCD), [2] HW_ID, [3] XCC_ID, [4] start, [5] end (100 MHz, device-wide),
+// then for each of its first four pieces: [6 + 3k] tile in LDS, [7 + 3k] applications done, [8 + 3k] tile stored (100 MHz)
+constexpr int kTraceWords = 18;
 __device__ __forceinline__ void trace_mark(unsigned long long* trace, int slot) {
     if (trace && threadIdx.x == 0) {
         unsigned long long* w = trace + (size_t)kTraceWords * blockIdx.x;
@@ -263,23 +297,28 @@ __device__ __forceinline__ void trace_mark(unsigned long long* trace, int slot) 
         } else if (slot == 1) {
             w[1] = __builtin_readcyclecounter();
             w[5] = wall_clock64();
-        } else {
-            w[6] = wall_clock64();
+        } else if (slot < kTraceWords) {
+            w[slot] = wall_clock64();
         }
     }
 }
+__device__ __forceinline__ void trace_piece(unsigned long long* trace, int k, int what) {
+    if (trace && k < 4) trace_mark(trace, 6 + 3 * k + what);
+}
 
 // Where the hand-over of a cut chain stands: flags[chain] - base.
-//   (anything below 1: nothing yet)  ->  kChainStoring (the owner has committed: it is storing the tile)  ->  kChainParked
-//   (anything below 1: nothing yet)  ->  kChainTaken   (the resumer has waited long enough: the chain is its own from application 0)
-// Both transitions out of "nothing yet" are compare-and-swaps on the same word, so exactly one of them happens.
+//   (anything below 1: nothing yet)  ->  kChainOwned (the owner is at work on the chain's head: it WILL park it)  ->  kChainParked
+//   (anything below 1: nothing yet)  ->  kChainTaken (the resumer has waited long enough for an owner that has not even started:
+//                                                     the chain is its own from application 0)
+// Both transitions out of "nothing yet" are atomics on the same word (the owner's a max, the resumer's a compare-and-swap of the
+// stale value it polled), so exactly one of them happens.
 // Visibility (MI355X_MICROARCH.md, inter-workgroup visibility; the XCDs' L2s are not coherent with each other): the parked tile is
-// stored WRITE-THROUGH and read with `sc1` loads (tile_store / tile_load <SHARED>), every storing wave drains its stores
+// stored WRITE-THROUGH and read with `sc1` loads (SharedTile, smfft_engine.hpp), every storing wave drains its stores
 // (s_waitcnt vmcnt(0)) in front of the workgroup barrier behind which ONE lane sets the word with an agent-scope atomic; the
 // resumer polls that word relaxed with one lane, tells its workgroup through LDS, and every load of the tile is an `sc1` load.
 // No cache-wide write-back or invalidate anywhere: with `fence(release / acquire, "agent")` around plain tile accesses -- rounds
 // 4's form -- every workgroup's `buffer_wbl2` scanned its XCD's L2, 10-90 us of a README launch (profiles/r05_handover_forms.txt).
-enum ChainState : unsigned { kChainStoring = 1u, kChainParked = 2u, kChainTaken = 3u };
+enum ChainState : unsigned { kChainOwned = 1u, kChainParked = 2u, kChainTaken = 3u };
 
 // one word from thread 0 to every thread of the workgroup (single-wave workgroups: the barriers compile to nothing)
 __device__ __forceinline__ unsigned workgroup_broadcast(unsigned value) {
@@ -294,24 +333,18 @@ __device__ __forceinline__ void sleep_ticks(unsigned ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 __device__ __forceinline__ global_u32* chain_word(const MultipleSchedule& sch, int tile) { return (global_u32*)(sch.flags + tile); }
-// OWNER, head computed: commit to parking it.  false: the resumer took the chain meanwhile -- nothing may be stored.
-__device__ __forceinline__ bool chain_park_begin(const MultipleSchedule& sch, int tile) {
+// OWNER, the first thing it does with a chain's head: commit to it -- ONE atomic max (the states are ordered and anything an
+// earlier launch left in the word is smaller than this launch's kChainOwned).  0: the resumer has taken the chain (this workgroup
+// started that late): the head is not computed and nothing is stored.
+__device__ __forceinline__ unsigned chain_own(const MultipleSchedule& sch, int tile) {
     unsigned go = 0;
     if (threadIdx.x == 0) {
         if (tile == sch.delay_chain && !sch.delay_after_commit) sleep_ticks(sch.delay_ticks);
-        global_u32* word = chain_word(sch, tile);
-        unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (;;) {
-            if (v == sch.base + kChainTaken) break;
-            if (__hip_atomic_compare_exchange_strong(word, &v, sch.base + kChainStoring, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                go = 1;
-                break;
-            }
-        }
+        go = __hip_atomic_fetch_max(chain_word(sch, tile), sch.base + kChainOwned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sch.base + kChainTaken;
     }
-    return workgroup_broadcast(go) != 0;
+    return go;
 }
-__device__ __forceinline__ void chain_park_end(const MultipleSchedule& sch, int tile) {
+__device__ __forceinline__ void chain_park(const MultipleSchedule& sch, int tile) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave: its write-through stores have arrived ...
     __syncthreads();                                    // ... before thread 0 says so
     if (threadIdx.x == 0) {
@@ -321,9 +354,9 @@ __device__ __forceinline__ void chain_park_end(const MultipleSchedule& sch, int 
 }
 // RESUMER: the application its piece really starts from -- app0 when the parked data are there (to be loaded from d_output, SHARED),
 // 0 when it has taken the chain (to be loaded from d_input).  Nobody waits here in practice (the head of a chain is the first thing
-// its owner does, the tail the last thing the resumer does); when the owner has not even committed after wait_ticks -- it is not
-// resident yet, or the device is shared -- the resumer stops waiting.  An owner that HAS committed is running its tile store: that
-// wait is bounded by the store.
+// its owner does, the tail the last thing the resumer does); when the owner has not even started after wait_ticks -- it is not
+// resident yet, or the device is shared -- the resumer stops waiting.  An owner that HAS started is running: that wait is bounded
+// by the head's applications.
 __device__ __forceinline__ int chain_resume_or_take(const MultipleSchedule& sch, int tile, int app0) {
     unsigned take = 0;
     if (threadIdx.x == 0) {
@@ -332,12 +365,12 @@ __device__ __forceinline__ int chain_resume_or_take(const MultipleSchedule& sch,
         for (;;) {
             unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (v == sch.base + kChainParked) break;
-            if (v != sch.base + kChainStoring && wall_clock64() - t0 > sch.wait_ticks) {
+            if (v != sch.base + kChainOwned && wall_clock64() - t0 > sch.wait_ticks) {
                 if (__hip_atomic_compare_exchange_strong(word, &v, sch.base + kChainTaken, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     take = 1;
                     break;
                 }
-                continue;                               // the owner committed under our hands: look again
+                continue;                               // the owner started under our hands: look again
             }
             __builtin_amdgcn_s_sleep(8);
         }
@@ -378,19 +411,19 @@ struct PieceLoop {
         return __builtin_amdgcn_readfirstlane((int)((hi < c0 + nreuses ? hi : c0 + nreuses) - c0));
     }
 };
-// One piece of the loop above with its hand-overs resolved: applications [app0, app1) of `tile`, loaded from d_output when
-// app0 > 0 (parked there by the owner: `resumed`) and from d_input otherwise.
+// One piece of the loop above with its hand-overs resolved: `skip` (an owner whose chain was taken before it started), else
+// applications [app0, app1) of `tile`, loaded from d_output when app0 > 0 (parked there by the owner: `resumed`) and from d_input
+// otherwise.
 struct Piece {
     int tile, app0, app1;
     bool park;               // the piece ends before the chain does -- its data are handed to the next workgroup
-    __device__ __forceinline__ Piece(const PieceLoop& pieces, const MultipleSchedule& sch, int k) : tile(pieces.tile(k)), app0(pieces.app0(k)), app1(pieces.app1(k)) {
+    bool skip;
+    __device__ __forceinline__ Piece(const PieceLoop& pieces, const MultipleSchedule& sch, int k) : tile(pieces.tile(k)), app0(pieces.app0(k)), app1(pieces.app1(k)), skip(false) {
         park = app1 < pieces.nreuses;
-        if (!park && app0 > 0) app0 = chain_resume_or_take(sch, tile, app0);
+        if (park) skip = workgroup_broadcast(chain_own(sch, tile)) == 0;
+        else if (app0 > 0) app0 = chain_resume_or_take(sch, tile, app0);
     }
     __device__ __forceinline__ bool resumed() const { return app0 > 0; }
-    // a parked head may be stored only if the resumer has not taken the chain meanwhile
-    __device__ __forceinline__ bool store_begin(const MultipleSchedule& sch) const { return chain_park_begin(sch, tile); }
-    __device__ __forceinline__ void store_end(const MultipleSchedule& sch) const { chain_park_end(sch, tile); }
 };
 
 // C2C, multiple, on the float2 engine (N = 32: its transform never leaves the registers -- two threads per FFT, one DPP
@@ -416,13 +449,14 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* d_input, float2*
     residency_enter(sch.residency);
     for (int k = 0; k < pieces.count; ++k) {
         const Piece piece(pieces, sch, k);
+        if (piece.skip) continue;
         const long first = (long)piece.tile * G::kCompactFfts;
         const int napps = piece.app1 - piece.app0;
         fft_sync<G::kMultiWave>();
-        if (piece.resumed()) tile_to_lds<N, kPaddedImage, true>(d_output + first * N, s, first, nSlots);
+        if (piece.resumed()) shared_tile_to_lds<N, kPaddedImage>(d_output + first * N, s, first, nSlots);
         else tile_to_lds<N, kPaddedImage>(d_input + first * N, s, first, nSlots);
         fft_sync<G::kMultiWave>();
-        if (k == 0) trace_mark(sch.trace, 2);
+        trace_piece(sch.trace, k, 0);
         if constexpr (kPaddedImage) {
             for (int f = 0; f < napps; ++f) {
                 priority.at_application();
@@ -450,12 +484,14 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* d_input, float2*
                 fft_sync<G::kMultiWave>();          // the reference omits this (latent race, CT:563-565)
             }
         }
+        trace_piece(sch.trace, k, 1);
         if (!piece.park) {
             lds_to_tile<N, kPaddedImage>(d_output + first * N, s, first, nSlots);
-        } else if (piece.store_begin(sch)) {
-            lds_to_tile<N, kPaddedImage, true>(d_output + first * N, s, first, nSlots);
-            piece.store_end(sch);
+        } else {
+            lds_to_shared_tile<N, kPaddedImage>(d_output + first * N, s, first, nSlots);
+            chain_park(sch, piece.tile);
         }
+        trace_piece(sch.trace, k, 2);
     }
     trace_mark(sch.trace, 1);
     residency_leave(sch.residency);
@@ -479,13 +515,14 @@ __device__ __forceinline__ void c2c_multiple_body_planar(const float2* d_input, 
     residency_enter(sch.residency);
     for (int k = 0; k < pieces.count; ++k) {
         const Piece piece(pieces, sch, k);
+        if (piece.skip) continue;
         const long first = (long)piece.tile * G::kCompactFfts;
         const int napps = piece.app1 - piece.app0;
         planar_sync<G::kMultiWave>();
-        if (piece.resumed()) tile_to_planes<N, DIR, REORDER, true>(d_output + first * N, planes, first, nSlots);
+        if (piece.resumed()) shared_tile_to_planes<N, DIR, REORDER>(d_output + first * N, planes, first, nSlots);
         else tile_to_planes<N, DIR, REORDER>(d_input + first * N, planes, first, nSlots);
         planar_sync<G::kMultiWave>();
-        if (k == 0) trace_mark(sch.trace, 2);
+        trace_piece(sch.trace, k, 0);
         float2 r[16];
         if constexpr (REORDER && FUSED) {
             eng.image_load_own(r, planes);
@@ -519,12 +556,14 @@ __device__ __forceinline__ void c2c_multiple_body_planar(const float2* d_input, 
             }
         }
         planar_sync<G::kMultiWave>();
+        trace_piece(sch.trace, k, 1);
         if (!piece.park) {
             planes_to_tile<N, DIR, REORDER>(d_output + first * N, planes, first, nSlots);
-        } else if (piece.store_begin(sch)) {
-            planes_to_tile<N, DIR, REORDER, true>(d_output + first * N, planes, first, nSlots);
-            piece.store_end(sch);
+        } else {
+            planes_to_shared_tile<N, DIR, REORDER>(d_output + first * N, planes, first, nSlots);
+            chain_park(sch, piece.tile);
         }
+        trace_piece(sch.trace, k, 2);
     }
     trace_mark(sch.trace, 1);
     residency_leave(sch.residency);
@@ -684,10 +723,11 @@ __device__ __forceinline__ void r2c_c2r_multiple_body_planar(const float2* d_inp
     residency_enter(sch.residency);
     for (int k = 0; k < pieces.count; ++k) {
         const Piece piece(pieces, sch, k);
+        if (piece.skip) continue;
         const long first = (long)piece.tile * G::kCompactFfts;
         const int napps = piece.app1 - piece.app0;
         planar_sync<G::kMultiWave>();
-        if (piece.resumed()) tile_to_planes<L, DIR, 1, true>(d_output + first * L, planes, first, nSlots);
+        if (piece.resumed()) shared_tile_to_planes<L, DIR, 1>(d_output + first * L, planes, first, nSlots);
         else tile_to_planes<L, DIR, 1>(d_input + first * L, planes, first, nSlots);
         planar_sync<G::kMultiWave>();
         float2 r[16];
@@ -712,9 +752,9 @@ __device__ __forceinline__ void r2c_c2r_multiple_body_planar(const float2* d_inp
         planar_sync<G::kMultiWave>();
         if (!piece.park) {
             planes_to_tile<L, DIR, 1>(d_output + first * L, planes, first, nSlots);
-        } else if (piece.store_begin(sch)) {
-            planes_to_tile<L, DIR, 1, true>(d_output + first * L, planes, first, nSlots);
-            piece.store_end(sch);
+        } else {
+            planes_to_shared_tile<L, DIR, 1>(d_output + first * L, planes, first, nSlots);
+            chain_park(sch, piece.tile);
         }
     }
     residency_leave(sch.residency);
@@ -795,21 +835,29 @@ SMFFT_DIT_external_occ3(const float2* d_input, float2* d_output, int nFFTs, int 
     smfft::c2c_external_body<const_params::fft_size, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nFFTs, pace, s_input);
 }
 
-// Launch bounds of the compact (in-LDS) kernels.  N = 2048 / 4096: compiled for 4 waves per SIMD (what their LDS allows, 8-9 / 4
-// workgroups per CU); left alone the planar engine takes 133-170 registers = 3 or 2 waves per SIMD (profiles/r03_ab_planar_b.txt:
-// +6 % / +3-17 % with the target stated).  The single-wave kernels are left alone at 100-128 registers = four waves per SIMD
-// (compiled for five -- 96 registers, spills outside the application loop only -- they measured 3-27 % SLOWER:
-// profiles/r04_ab_balance_variants.txt, r04_ab_five_waves.txt).
-#define SMFFT_COMPACT_BOUNDS(N) __launch_bounds__(smfft::Geometry<N>::kCompactThreads, (N) >= 2048 ? 4 : 1)
+// Launch bounds of the compact (in-LDS) kernels: every one is compiled for FOUR waves per SIMD -- what the schedule is built on
+// (the rotation of the wave priorities has four ranks; five waves per SIMD at 96 registers measured 3-27 % slower:
+// profiles/r04_ab_balance_variants.txt, r04_ab_five_waves.txt).  N = 2048 / 4096: at least four (what their LDS allows, 8-9 / 4
+// workgroups per CU; left alone the planar engine takes 133-170 registers = 3 or 2 waves per SIMD, profiles/r03_ab_planar_b.txt).
+// The single-wave kernels: exactly four -- left alone most of them take 100-128 registers anyway, but the allocator is free to
+// land on 92 (N = 64 did, after an unrelated change of the kernel's prologue: a fifth wave, 19 workgroups per CU, -35 %).
+// And so that the residency does not hang on the allocator's mood, a single-wave kernel's LDS is padded to what lets exactly
+// sixteen workgroups share a CU's 160 KiB (their images are 8.3-8.7 KiB: nineteen would fit).
+#define SMFFT_COMPACT_BOUNDS(N) __launch_bounds__(smfft::Geometry<N>::kCompactThreads, (N) >= 2048 ? 4 : 1) __attribute__((amdgpu_waves_per_eu(4, (N) >= 2048 ? 8 : 4)))
+namespace smfft {
+constexpr int kSingleWaveLdsBytes = 9728;      // 160 KiB / 9728 = 16.8
+template <int N>
+constexpr int compact_lds_floats(int needed) { return (N <= 1024 && needed * 4 < kSingleWaveLdsBytes) ? kSingleWaveLdsBytes / 4 : needed; }
+}  // namespace smfft
 
 template <class const_params>
 __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_size) SMFFT_DIT_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses, smfft::MultipleSchedule sch) {
     constexpr int N = const_params::fft_size;
     if constexpr (N >= smfft::kPlanarMinN) {
-        __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<N, const_params::fft_reorder>::kLdsFloats];
+        __shared__ __attribute__((aligned(16))) float s_planes[smfft::compact_lds_floats<N>(smfft::PlanarGeometry<N, const_params::fft_reorder>::kLdsFloats)];
         smfft::c2c_multiple_body_planar<N, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nSlots, nreuses, sch, s_planes);
     } else {
-        __shared__ float2 s_input[smfft::Geometry<N>::kCompactLds];
+        __shared__ float2 s_input[smfft::compact_lds_floats<N>(2 * smfft::Geometry<N>::kCompactLds) / 2];
         smfft::c2c_multiple_body<N, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nSlots, nreuses, sch, s_input);
     }
 }
@@ -821,7 +869,7 @@ template <class const_params>
 __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_size) SMFFT_DIT_multiple_unfused(const float2* d_input, float2* d_output, int nSlots, int nreuses, smfft::MultipleSchedule sch) {
     constexpr int N = const_params::fft_size;
     static_assert(N >= smfft::kPlanarMinN && const_params::fft_reorder, "the no-reorder variants and N = 32 are unfused as they are");
-    __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<N, 1>::kLdsFloats];
+    __shared__ __attribute__((aligned(16))) float s_planes[smfft::compact_lds_floats<N>(smfft::PlanarGeometry<N, 1>::kLdsFloats)];
     smfft::c2c_multiple_body_planar<N, const_params::fft_direction, 1, false>(d_input, d_output, nSlots, nreuses, sch, s_planes);
 }
 
@@ -835,10 +883,10 @@ template <class const_params>
 __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_length) FFT_GPU_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses, smfft::MultipleSchedule sch) {
     constexpr int N = const_params::fft_length;
     if constexpr (N >= smfft::kPlanarMinN) {
-        __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<N, 1>::kLdsFloats];
+        __shared__ __attribute__((aligned(16))) float s_planes[smfft::compact_lds_floats<N>(smfft::PlanarGeometry<N, 1>::kLdsFloats)];
         smfft::c2c_multiple_body_planar<N, 1, 1>(d_input, d_output, nSlots, nreuses, sch, s_planes);
     } else {
-        __shared__ float2 s_input[smfft::Geometry<N>::kCompactLds];
+        __shared__ float2 s_input[smfft::compact_lds_floats<N>(2 * smfft::Geometry<N>::kCompactLds) / 2];
         smfft::c2c_multiple_body<N, 1, 1>(d_input, d_output, nSlots, nreuses, sch, s_input);
     }
 }
@@ -852,6 +900,6 @@ __global__ void __launch_bounds__(256) FFT_GPU_R2C_C2R_external(const float2* d_
 template <class const_params, class const_direction>
 __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_length) FFT_GPU_R2C_C2R_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses, smfft::MultipleSchedule sch) {
     constexpr int L = const_params::fft_length;
-    __shared__ __attribute__((aligned(16))) float s_planes[smfft::PlanarGeometry<L, 1>::kLdsFloats];
+    __shared__ __attribute__((aligned(16))) float s_planes[smfft::compact_lds_floats<L>(smfft::PlanarGeometry<L, 1>::kLdsFloats)];
     smfft::r2c_c2r_multiple_body_planar<L, const_direction::fft_direction>(d_input, d_output, nSlots, nreuses, sch, s_planes);
 }
