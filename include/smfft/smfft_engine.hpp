@@ -178,6 +178,16 @@ struct WavePriority {
     __device__ __forceinline__ explicit WavePriority(int rotate = 15) : shift(rotate) {
         slot = (int)(__builtin_amdgcn_s_getreg((4 /* HW_REG_HW_ID */) | (0 << 6) | ((4 - 1) << 11)) & 3u);   // wave slot in the SIMD
     }
+    // Outside the applications -- a wave that is copying a tile between device memory and LDS, or handing a chain over -- the wave
+    // takes the TOP rank: those phases are short and mostly waiting, and a wave that runs them at whatever rank it happens to hold
+    // (a newly started one: the lowest) is starved by the three that are computing: per-workgroup traces of round 5 showed the
+    // fourth wave of every SIMD taking 15-35 us over its first tile (the others: 6), and it is the one the launch then ends with.
+    __device__ __forceinline__ void between_applications() const {
+        if (shift > 0) __builtin_amdgcn_s_setprio(3);
+    }
+    __device__ __forceinline__ void leaving() const {
+        if (shift > 0) __builtin_amdgcn_s_setprio(0);
+    }
     // called once per application: the rank follows the CU's clock, so at any moment the waves of a SIMD hold a permutation of
     // the ranks (their slots differ) and every wave holds every rank for the same share of the time
     __device__ __forceinline__ void at_application(int = 0) const {
@@ -354,6 +364,9 @@ struct Engine {
     // microbenchmark of the forms, profiles/r02_valu_forms.txt -- measured 8-10 % SLOWER in the in-LDS kernel: the swaps do not
     // overlap with the other waves' arithmetic the way the DPP moves do; profiles/r05_ab_n32_permlane.txt.  kLaneShift = 4 builds it.)
     static constexpr int kLaneShift = !G::kRegTwoPass ? 0 : 4 - T_BITS;
+    // (N = 32's one exchange through the LDS crossbar instead -- ds_swizzle lane ^ 8 of both registers of a pair and a select per
+    //  dword, 32 selects where the row-DPP form spends 32 moves at 5.4 cycles and 17 copies -- measured 20 % SLOWER in the in-LDS
+    //  kernel with the swizzles consumed four at a time, and with all of them in flight the kernel spills: profiles/r05_ab_n32_swizzle.txt)
 
     int u;        // thread inside the FFT
     int fft;      // FFT inside the workgroup
@@ -604,8 +617,7 @@ struct Engine {
                 case 0: swap_bit_quad<0>(A, B, hi); break;
                 case 1: swap_bit_quad<1>(A, B, hi); break;
                 case 2: swap_bit_dpp_dword<2>(A.x, B.x, hi); swap_bit_dpp_dword<2>(A.y, B.y, hi); break;
-                case 3: swap_bit_dpp_dword<3>(A.x, B.x, hi); swap_bit_dpp_dword<3>(A.y, B.y, hi); break;
-                default: swap_bit<4>(A, B); break;
+                default: swap_bit_dpp_dword<3>(A.x, B.x, hi); swap_bit_dpp_dword<3>(A.y, B.y, hi); break;
             }
         }
     }

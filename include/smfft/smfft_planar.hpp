@@ -132,6 +132,30 @@ struct PlanarGeometry {
     static constexpr int F = TW / T;
     static constexpr RowTable kImage = make_rows<N, REORDER>(RowKind::image), kX1 = make_rows<N, REORDER>(RowKind::x1), kX2 = make_rows<N, REORDER>(RowKind::x2);
     static constexpr int image_row(int j) { return kImage.base[j]; }
+    // image_row for a row that is known at run time only (the tile copies), without a table in memory -- sixteen dependent
+    // constant-memory loads per copy were 2-3 of the 3.5 us a tile copy took (round 5 traces): a row's base is TW * rank + 4 * residue
+    // (place_rows), and the sixteen ranks and residues are four bits each: two 64-bit constants, one shift and mask per look-up.
+    static constexpr unsigned long long pack_image(bool ranks) {
+        unsigned long long packed = 0;
+        for (int j = 0; j < 16; ++j) {
+            const int q = row_residue<N, REORDER>(RowKind::image, j);
+            const int rank = (kImage.base[j] - 4 * q) / TW;
+            packed |= (unsigned long long)((ranks ? rank : q) & 15) << (4 * j);
+        }
+        return packed;
+    }
+    static constexpr bool image_packing_is_exact() {
+        for (int j = 0; j < 16; ++j) {
+            const int q = row_residue<N, REORDER>(RowKind::image, j);
+            if (q < 0 || q > 15 || (kImage.base[j] - 4 * q) % TW != 0 || (kImage.base[j] - 4 * q) / TW > 15) return false;
+        }
+        return true;
+    }
+    __device__ static __forceinline__ int image_row_at(int j) {
+        static_assert(image_packing_is_exact(), "a row's base is TW * rank + 4 * residue with both below 16");
+        constexpr unsigned long long ranks = pack_image(true), residues = pack_image(false);
+        return TW * (int)((ranks >> (4 * j)) & 15) + 4 * (int)((residues >> (4 * j)) & 15);
+    }
     static constexpr int x1_row(int j) { return kX1.base[j]; }
     static constexpr int x2_row(int j) { return kX2.base[j]; }
     static constexpr int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
@@ -490,7 +514,7 @@ __device__ __forceinline__ float* plane_word_of(float* planes, int e) {
     using P = PlanarGeometry<N, REORDER>;
     const int f = e / N, n = e % N, u = n % E::T, row = n / E::T;
     const int pos = E::kForward ? E::position_of_role(u) : u;
-    return planes + P::image_row(row) + f * E::T + pos;
+    return planes + P::image_row_at(row) + f * E::T + pos;
 }
 template <int N, int DIR, int REORDER>
 __device__ __forceinline__ void tile_to_planes(const float2* g, float* planes, long first_fft, long limit_fft) {

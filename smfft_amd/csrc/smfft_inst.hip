@@ -33,15 +33,16 @@ static int launch_compact(CompactKernel kernel, const float2* d_input, float2* d
     sch.rotate = opt.rotate;
     sch.delay_chain = -1;
     int grid = grid_for(count, G::kCompactFfts, opt.grid_cap);
-    // Which schedule.  Up to four rounds' worth of chains: the balanced persistent grid (when there is
-    // more than one round) and rotating priorities -- no tail, co-resident chains end together: +14-24 % on the README batches.
-    // A long launch (more than four rounds) is in a steady state of its own: workgroups start whenever an older one ends, the
-    // tail is a few percent, and there the persistent grid measured 0-7 % SLOWER (N = 2048 most): one chain per workgroup,
-    // grid-strided, the arbiter's own order.  balance >= 2 (tests): that many workgroups, as if the chip held no more.
+    // Which schedule.  More chains than the chip holds workgroups: the balanced persistent grid and
+    // rotating priorities -- no tail, co-resident chains end together: +12-24 % on the README batches (1.28 rounds' worth of
+    // chains), still +2-5 % at 8.4 rounds (profiles/r05_schedule_crossover.txt; with round 4's hand-over, whose cache write-backs
+    // grew with the launch, it lost beyond four rounds).  At most one round: one chain per workgroup, priorities rotating.
+    // Beyond what a buffer of hand-over words holds (kScheduleMaxChains chains): one chain per workgroup, grid-strided, the
+    // arbiter's own order.  balance >= 2 (tests): that many workgroups, as if the chip held no more.
     // A caller who caps the grid below what the chip holds (to leave CUs to other work) keeps that cap: no persistent grid then.
     const int resident = resident_workgroups((const void*)kernel, threads);
     const int slots = balance >= 2 ? balance : resident;
-    const bool short_launch = slots <= 0 || balance >= 2 || (long)ntiles <= 4l * slots;
+    const bool short_launch = slots <= 0 || balance >= 2 || ntiles <= kScheduleMaxChains;
     const bool capped = balance < 2 && opt.grid_cap > 0 && opt.grid_cap < slots;
     if (!short_launch) sch.rotate = 0;
     // a launch that is being CAPTURED into a graph keeps one chain per workgroup: the balanced grid's hand-over words carry the

@@ -445,6 +445,7 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* d_input, float2*
     const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
     const PieceLoop pieces(sch, ntiles, nreuses);
     const WavePriority priority(sch.rotate);
+    priority.between_applications();
     trace_mark(sch.trace, 0);
     residency_enter(sch.residency);
     for (int k = 0; k < pieces.count; ++k) {
@@ -484,6 +485,7 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* d_input, float2*
                 fft_sync<G::kMultiWave>();          // the reference omits this (latent race, CT:563-565)
             }
         }
+        priority.between_applications();
         trace_piece(sch.trace, k, 1);
         if (!piece.park) {
             lds_to_tile<N, kPaddedImage>(d_output + first * N, s, first, nSlots);
@@ -511,6 +513,7 @@ __device__ __forceinline__ void c2c_multiple_body_planar(const float2* d_input, 
     const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
     const PieceLoop pieces(sch, ntiles, nreuses);
     const WavePriority priority(sch.rotate);
+    priority.between_applications();
     trace_mark(sch.trace, 0);
     residency_enter(sch.residency);
     for (int k = 0; k < pieces.count; ++k) {
@@ -556,6 +559,7 @@ __device__ __forceinline__ void c2c_multiple_body_planar(const float2* d_input, 
             }
         }
         planar_sync<G::kMultiWave>();
+        priority.between_applications();
         trace_piece(sch.trace, k, 1);
         if (!piece.park) {
             planes_to_tile<N, DIR, REORDER>(d_output + first * N, planes, first, nSlots);
@@ -720,6 +724,7 @@ __device__ __forceinline__ void r2c_c2r_multiple_body_planar(const float2* d_inp
     const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
     const PieceLoop pieces(sch, ntiles, nreuses);
     const WavePriority priority(sch.rotate);
+    priority.between_applications();
     residency_enter(sch.residency);
     for (int k = 0; k < pieces.count; ++k) {
         const Piece piece(pieces, sch, k);
@@ -750,6 +755,7 @@ __device__ __forceinline__ void r2c_c2r_multiple_body_planar(const float2* d_inp
         planar_sync<G::kMultiWave>();
         eng.image_store(r);
         planar_sync<G::kMultiWave>();
+        priority.between_applications();
         if (!piece.park) {
             planes_to_tile<L, DIR, 1>(d_output + first * L, planes, first, nSlots);
         } else {
@@ -843,7 +849,7 @@ SMFFT_DIT_external_occ3(const float2* d_input, float2* d_output, int nFFTs, int 
 // land on 92 (N = 64 did, after an unrelated change of the kernel's prologue: a fifth wave, 19 workgroups per CU, -35 %).
 // And so that the residency does not hang on the allocator's mood, a single-wave kernel's LDS is padded to what lets exactly
 // sixteen workgroups share a CU's 160 KiB (their images are 8.3-8.7 KiB: nineteen would fit).
-#define SMFFT_COMPACT_BOUNDS(N) __launch_bounds__(smfft::Geometry<N>::kCompactThreads, (N) >= 2048 ? 4 : 1) __attribute__((amdgpu_waves_per_eu(4, (N) >= 2048 ? 8 : 4)))
+#define SMFFT_COMPACT_BOUNDS(N) __launch_bounds__(smfft::Geometry<N>::kCompactThreads, 4)
 namespace smfft {
 constexpr int kSingleWaveLdsBytes = 9728;      // 160 KiB / 9728 = 16.8
 template <int N>

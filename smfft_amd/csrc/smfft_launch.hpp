@@ -58,7 +58,7 @@ int last_noted_slots();
 // has passed that point (an event; nothing in the launch path frees memory or waits for the device).
 unsigned* schedule_acquire(int nchains, hipStream_t stream, unsigned* base, int* ticket);
 void schedule_release(int ticket, hipStream_t stream);
-constexpr int kScheduleMaxChains = 32768;      // a balanced launch has at most 4 rounds' worth of chains of at most 32 workgroups per CU
+constexpr int kScheduleMaxChains = 65536;      // words per buffer (256 KiB): the most chains a launch may have to be balanced
 
 inline int grid_for(int count, int ffts_per_block, int grid_cap) {
     int ntiles = (count + ffts_per_block - 1) / ffts_per_block;

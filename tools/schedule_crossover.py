@@ -27,20 +27,22 @@ def med(fn, reps=7):
     return sorted(ts)[len(ts) // 2]
 
 
-for n in (256, 1024, 2048, 4096):
+sizes = [int(v) for v in sys.argv[1:]] or [32, 64, 256, 1024, 4096]
+for n in sizes:
+  for reo in (1, 0):
     slots = ctypes.c_int(0)
-    sm.lib.smfft_measure_multiple_residency(0, n, 0, 1, 1, ctypes.byref(slots))
+    sm.lib.smfft_measure_multiple_residency(0, n, 0, reo, 1, ctypes.byref(slots))
     slots = slots.value
     tile = max(1, 1024 // n)
-    for rounds in (1.28, 2.3, 3.3, 4.3, 5.3, 6.3, 8.37):
+    for rounds in (1.28, 2.3, 4.3, 6.3, 8.37):
         ntiles = int(rounds * slots)
         nffts = ntiles * tile * 100
         sm.lib.smfft_set_multiple_balance(slots)
         sm.lib.smfft_set_multiple_rotation(15)
-        bal = med(lambda t: sm.lib.smfft_ct_multiple_benchmark(a.ptr, b.ptr, n, nffts, 0, 1, t))
+        bal = med(lambda t: sm.lib.smfft_ct_multiple_benchmark(a.ptr, b.ptr, n, nffts, 0, reo, t))
         sm.lib.smfft_set_multiple_balance(0)
         sm.lib.smfft_set_multiple_rotation(0)
-        old = med(lambda t: sm.lib.smfft_ct_multiple_benchmark(a.ptr, b.ptr, n, nffts, 0, 1, t))
-        print(f"N={n} {slots} slots, {rounds:5.2f} rounds ({ntiles} chains): balanced + rotation {bal:.4f} ms | one chain per workgroup, oldest first {old:.4f} ms | ratio {old / bal:.3f}", flush=True)
+        old = med(lambda t: sm.lib.smfft_ct_multiple_benchmark(a.ptr, b.ptr, n, nffts, 0, reo, t))
+        print(f"N={n} reorder={reo} {slots} slots, {rounds:5.2f} rounds ({ntiles} chains): balanced + rotation {bal:.4f} ms | one chain per workgroup, oldest first {old:.4f} ms | ratio {old / bal:.3f}", flush=True)
 sm.lib.smfft_set_multiple_balance(-1)
 sm.lib.smfft_set_multiple_rotation(-1)
