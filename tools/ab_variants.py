@@ -4,7 +4,7 @@
            [--sizes 1024,4096] [--paths multiple,external,rc] [--mult 1,10] [--plain]
 
 Build a variant with
-    make -C smfft_amd/csrc LIB=../libsmfft_amd_v1.so OBJDIR=build_v1 EXTRA_HIPFLAGS="-DSMFFT_SINGLE_READS=0" ../libsmfft_amd_v1.so
+    make -C smfft_amd/csrc LIB=../libsmfft_amd_v1.so OBJDIR=build_v1 EXTRA_HIPFLAGS="-DSMFFT_NT=0" ../libsmfft_amd_v1.so      (or any other build: another commit's library, tools/build_variant.sh)
 multiple: FFT_multiple_benchmark (README batch 2^29/N FFTs, x the batch multipliers), reorder and no-reorder.
 external: FFT_external_benchmark forward, reorder and no-reorder, 4 GiB in + 4 GiB out.
 rc:       R2C and C2R external at real N = 2 * size (2 GiB each way).
