@@ -107,15 +107,6 @@ constexpr RowTable make_rows(RowKind k) {
                       row_residue<N, REORDER>(k, 8), row_residue<N, REORDER>(k, 9), row_residue<N, REORDER>(k, 10), row_residue<N, REORDER>(k, 11),
                       row_residue<N, REORDER>(k, 12), row_residue<N, REORDER>(k, 13), row_residue<N, REORDER>(k, 14), row_residue<N, REORDER>(k, 15));
 }
-// the same tables in device memory, for the rows a thread picks at run time (once, at set-up)
-template <int N, int REORDER>
-struct PlanarRows {
-    RowTable image, x1, x2;
-    constexpr PlanarRows() : image(make_rows<N, REORDER>(RowKind::image)), x1(make_rows<N, REORDER>(RowKind::x1)), x2(make_rows<N, REORDER>(RowKind::x2)) {}
-};
-template <int N, int REORDER>
-static __device__ const PlanarRows<N, REORDER> planar_rows = PlanarRows<N, REORDER>();
-
 // Synchronisation between the threads of an FFT.  The compiler does not count the stores issued from inline assembly, so a
 // multi-wave FFT drains them itself in front of the workgroup barrier; inside one wave DS operations execute in order.
 template <bool MULTI_WAVE>
@@ -132,30 +123,33 @@ struct PlanarGeometry {
     static constexpr int F = TW / T;
     static constexpr RowTable kImage = make_rows<N, REORDER>(RowKind::image), kX1 = make_rows<N, REORDER>(RowKind::x1), kX2 = make_rows<N, REORDER>(RowKind::x2);
     static constexpr int image_row(int j) { return kImage.base[j]; }
-    // image_row for a row that is known at run time only (the tile copies), without a table in memory -- sixteen dependent
+    // A row's base for a row that is known at run time only (the tile copies; a thread's offsets at set-up), without a table in memory -- sixteen dependent
     // constant-memory loads per copy were 2-3 of the 3.5 us a tile copy took (round 5 traces): a row's base is TW * rank + 4 * residue
     // (place_rows), and the sixteen ranks and residues are four bits each: two 64-bit constants, one shift and mask per look-up.
-    static constexpr unsigned long long pack_image(bool ranks) {
+    static constexpr const RowTable& table_of(RowKind kind) { return kind == RowKind::image ? kImage : kind == RowKind::x1 ? kX1 : kX2; }
+    static constexpr unsigned long long pack_rows(RowKind kind, bool ranks) {
         unsigned long long packed = 0;
         for (int j = 0; j < 16; ++j) {
-            const int q = row_residue<N, REORDER>(RowKind::image, j);
-            const int rank = (kImage.base[j] - 4 * q) / TW;
+            const int q = row_residue<N, REORDER>(kind, j);
+            const int rank = (table_of(kind).base[j] - 4 * q) / TW;
             packed |= (unsigned long long)((ranks ? rank : q) & 15) << (4 * j);
         }
         return packed;
     }
-    static constexpr bool image_packing_is_exact() {
+    static constexpr bool packing_is_exact(RowKind kind) {
         for (int j = 0; j < 16; ++j) {
-            const int q = row_residue<N, REORDER>(RowKind::image, j);
-            if (q < 0 || q > 15 || (kImage.base[j] - 4 * q) % TW != 0 || (kImage.base[j] - 4 * q) / TW > 15) return false;
+            const int q = row_residue<N, REORDER>(kind, j);
+            if (q < 0 || q > 15 || (table_of(kind).base[j] - 4 * q) % TW != 0 || (table_of(kind).base[j] - 4 * q) / TW > 15) return false;
         }
         return true;
     }
-    __device__ static __forceinline__ int image_row_at(int j) {
-        static_assert(image_packing_is_exact(), "a row's base is TW * rank + 4 * residue with both below 16");
-        constexpr unsigned long long ranks = pack_image(true), residues = pack_image(false);
+    template <RowKind KIND>
+    __device__ static __forceinline__ int row_at(int j) {
+        static_assert(packing_is_exact(KIND), "a row's base is TW * rank + 4 * residue with both below 16");
+        constexpr unsigned long long ranks = pack_rows(KIND, true), residues = pack_rows(KIND, false);
         return TW * (int)((ranks >> (4 * j)) & 15) + 4 * (int)((residues >> (4 * j)) & 15);
     }
+    __device__ static __forceinline__ int image_row_at(int j) { return row_at<RowKind::image>(j); }
     static constexpr int x1_row(int j) { return kX1.base[j]; }
     static constexpr int x2_row(int j) { return kX2.base[j]; }
     static constexpr int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
@@ -242,27 +236,26 @@ struct PlanarEngine {
                 tw.wm[q2] = rot ? turned : w;
             }
         }
-        const PlanarRows<N, REORDER>& rows = planar_rows<N, REORDER>;
         // bit-reversed load: the sixteen contiguous elements p = 16 * rho + i of the natural image, rho = rev_T(t1):
         // element p is dword fft * T + p % T of row p / T
         const int rho = (int)(__brev((unsigned)t1) >> (32 - T_BITS));
         if constexpr (kRotatedX1) {
-            off_image[0] = rows.image.base[rho / 16] + fft * T + (rho % 16);   // element 16 * (rho % 16) + i sits at the dword of role ... + i: 16 * i + rho % 16
+            off_image[0] = P::image_row_at(rho / 16) + fft * T + (rho % 16);   // element 16 * (rho % 16) + i sits at the dword of role ... + i: 16 * i + rho % 16
         } else if constexpr (T >= 16) {
-            off_image[0] = rows.image.base[rho / (T / 16)] + fft * T + 16 * (rho % (T / 16));
+            off_image[0] = P::image_row_at(rho / (T / 16)) + fft * T + 16 * (rho % (T / 16));
         } else {
 #pragma unroll
-            for (int h = 0; h < kImageRuns; ++h) off_image[h] = rows.image.base[kImageRuns * rho + h] + fft * T;   // T dwords of each row
+            for (int h = 0; h < kImageRuns; ++h) off_image[h] = P::image_row_at(kImageRuns * rho + h) + fft * T;   // T dwords of each row
         }
         if constexpr (kThreePass) {
             static_assert(x1_rows_regular(), "x1_load takes the rows a*BM + c at compile-time distances from row a*BM");
-            off_x1 = kRegisterX1 ? 0 : rows.x1.base[a * BM] + fft * T + RM * t2;
+            off_x1 = kRegisterX1 ? 0 : P::template row_at<RowKind::x1>(a * BM) + fft * T + RM * t2;
             const int c = klow % BM, aa = (klow % 16) / BM, q2 = klow / 16;
-            off_x2[0] = rows.x2.base[c * RM + q2] + fft * T + 16 * aa;
+            off_x2[0] = P::template row_at<RowKind::x2>(c * RM + q2) + fft * T + 16 * aa;
         } else {
             off_x1 = 0;
 #pragma unroll
-            for (int b = 0; b < B1; ++b) off_x2[b] = rows.x2.base[b * R1 + v] + fft * T;
+            for (int b = 0; b < B1; ++b) off_x2[b] = P::template row_at<RowKind::x2>(b * R1 + v) + fft * T;
         }
     }
 
