@@ -140,6 +140,77 @@ struct QuarterTwiddleRows {
 template <int N>
 static __device__ const QuarterTwiddleRows<N> quarter_twiddle_rows = QuarterTwiddleRows<N>();
 
+// Every twiddle of a thread's transform, fetched FIRST -- in front of the first synchronisation -- and kept: the index of a pass's
+// twiddle depends on the thread only, so in a caller's loop around the device function (the `multiple` kernels: the reference's
+// own benchmark shape, CT:553-572) the loads and the two products below are loop invariant, and at the top of the function the
+// compiler may hoist them (behind a barrier or an asm statement it may not: a load is not speculated).  A fused radix-2^2 pass
+// then costs three complex products and eight complex sums, b1 = w1 x1, b2 = w2 x2, b3 = w3 x3:
+//     (x0 + b1) +- (b2 + b3),   (x0 - b1) +- (-+i)(b2 - b3)
+// -- 28 instructions instead of the 36 of two radix-2 stages with w1 = w2^2 recomputed (N = 1024: 208 -> 176 vector instructions
+// per thread and application, and no global load left in the loop).  A single call pays the same 36 as the two-stage form.
+// The kept values cost registers -- six per pass -- and the blocks of N = 2048 / 4096 are 8 / 16 waves that must fit a CU several
+// times over: with everything kept those kernels need 66 / 73 registers (measured: N = 4096 one block per CU instead of two,
+// -20 %), so their last passes (quarter_late_passes) fetch at the pass as before ("late" passes: the load stays behind the pass's
+// synchronisation, nothing of it is kept).  N <= 128 does the same in every pass: in upstream's 32-thread blocks the kept form
+// measured 2-3 % slower, in the 64-thread blocks of the _wave64 classes within +-2 % (profiles/r05_contract_twiddles.txt).
+struct QuadTwiddle { float2 w1, w2, w3; };      // W_2P^k, W_4P^k, W_4P^3k
+// (measured, in-LDS loop of 100 calls at the README batch against fetching in every pass: N = 256 ... 1024 +7 ... +13 %, N = 2048 +9 %
+//  natural order / +4 % no reorder, N = 4096 no reorder +3 %; N = 4096 natural order -2 % with one pass kept: all late there)
+constexpr int quarter_late_passes(int n, bool reorder) {
+    const int passes = ilog2c(n) / 2;
+    return n >= 4096 ? (reorder ? passes : 4) : n >= 2048 ? 1 : n <= 128 ? passes : 0;
+}
+template <int N, int DIR, int REORDER>
+struct QuarterTwiddles {
+    using R = QuarterTwiddleRows<N>;
+    static constexpr int kLatePasses = quarter_late_passes(N, REORDER != 0);
+    static constexpr bool late(int p) { return p >= R::kPasses - kLatePasses; }
+    QuadTwiddle q[R::kPasses > 1 ? R::kPasses : 1];    // q[p], p = 1 .. kPasses - 1 (P = 4^p)
+    float2 wr;                                         // the radix-2 pass of an odd log2 N
+    int kbase;
+    __device__ static __forceinline__ QuadTwiddle fetch(int p, int k) {
+        const TwiddleValue tv = quarter_twiddle_rows<N>.w[R::row_start(p) + k];
+        QuadTwiddle t;
+        t.w2 = make_float2(tv.x, DIR ? -tv.y : tv.y);
+        t.w1 = make_float2(t.w2.x * t.w2.x - t.w2.y * t.w2.y, 2.f * t.w2.x * t.w2.y);
+        t.w3 = late(p) ? t.w2 : cmul(t.w1, t.w2);      // (a late pass takes the two-stage butterfly: no third product)
+        return t;
+    }
+    // kb: the thread's butterfly index (k = kb mod P in every pass); r: its index in the radix-2 row
+    __device__ __forceinline__ void load(int kb, int r) {
+        kbase = kb;
+#pragma unroll
+        for (int p = 1; p < R::kPasses; ++p)
+            if (!late(p)) q[p] = fetch(p, kb & ((1 << (2 * p)) - 1));
+        if constexpr (R::kOdd) {
+            const TwiddleValue tv = quarter_twiddle_rows<N>.w[R::row_start(R::kPasses) + r];
+            wr = make_float2(tv.x, DIR ? -tv.y : tv.y);
+        }
+    }
+    // the twiddles of pass `pass`, at the pass (pass: a constant where this is called -- a template argument or the counter of an unrolled loop)
+    __device__ __forceinline__ QuadTwiddle of(int pass) const {
+        return late(pass) ? fetch(pass, kbase & ((1 << (2 * pass)) - 1)) : q[pass];
+    }
+};
+// the fused radix-2^2 butterfly on (x0, x1, x2, x3) = elements k, k + P, k + 2P, k + 3P; results in place
+// (two_stage: the form for a twiddle fetched at the pass -- w2 (x2 +- w1 x3): four products, none of them behind w3 = w1 w2, whose
+//  place in the dependency chain load -> w1 -> w3 -> b3 cost the 16-wave blocks of N = 4096 2 %)
+template <int DIR>
+__device__ __forceinline__ void quad_butterfly(float2& x0, float2& x1, float2& x2, float2& x3, const QuadTwiddle& w, bool two_stage) {
+    const float2 b1 = cmul(x1, w.w1);
+    const float2 y0 = cadd(x0, b1), y1 = csub(x0, b1);
+    float2 y2, v3;
+    if (two_stage) {
+        const float2 t3 = cmul(x3, w.w1);
+        y2 = cmul(cadd(x2, t3), w.w2), v3 = cmul(csub(x2, t3), w.w2);
+    } else {
+        const float2 b2 = cmul(x2, w.w2), b3 = cmul(x3, w.w3);
+        y2 = cadd(b2, b3), v3 = csub(b2, b3);
+    }
+    const float2 u3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);   // (-+i) v3
+    x0 = cadd(y0, y2), x1 = cadd(y1, u3), x2 = csub(y0, y2), x3 = csub(y1, u3);
+}
+
 // Inside the function the data lives in a SWIZZLED image of the same LDS words: element i (index within the block's region:
 // the FFT's offset included, N <= 128 keeps 128 / N transforms per 32 threads) sits at
 //     i ^ ((i >> 8) & 31) ^ ((i >> 4) & 30) ^ ((i >> 2) & 24)
@@ -213,36 +284,35 @@ struct QuarterLanes {
     static constexpr int out_offset(int i) { return Q * (R::kOdd ? (((i & 1) << 1) | (i >> 1)) : i); }
     __device__ static __forceinline__ int base_of(int t) { return REORDER ? (int)(__brev((unsigned)t) >> (32 - T_BITS)) : t; }
 
-    template <int P_INDEX>
-    __device__ static __forceinline__ void passes(float2 (&e)[4], int base, int lane) {
+    // (TW: the QuarterTwiddles of this length or of a longer one -- the rows W_4P^k depend on P only)
+    template <int P_INDEX, class TW>
+    __device__ static __forceinline__ void passes(float2 (&e)[4], const TW& tw, int lane) {
         if constexpr (P_INDEX < R::kPasses) {
-            constexpr int P = 1 << (2 * P_INDEX);
             slots_swap<0, lane_bit_of(2 * P_INDEX - 2)>(e, lane);
             slots_swap<1, lane_bit_of(2 * P_INDEX - 1)>(e, lane);
-            const TwiddleValue tv = quarter_twiddle_rows<N>.w[R::row_start(P_INDEX) + (base & (P - 1))];
-            const float2 w2 = make_float2(tv.x, DIR ? -tv.y : tv.y);
-            const float2 w1 = make_float2(w2.x * w2.x - w2.y * w2.y, 2.f * w2.x * w2.y);
-            const float2 t1 = cmul(e[1], w1), t3 = cmul(e[3], w1);
-            const float2 y0 = cadd(e[0], t1), y1 = csub(e[0], t1), y2 = cadd(e[2], t3), y3 = csub(e[2], t3);
-            const float2 u2 = cmul(y2, w2), v3 = cmul(y3, w2);
-            const float2 u3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);   // y3 * w2 * (-+i)
-            e[0] = cadd(y0, u2), e[1] = cadd(y1, u3), e[2] = csub(y0, u2), e[3] = csub(y1, u3);
-            passes<P_INDEX + 1>(e, base, lane);
+            // slots: e[1] = element k + 2P, e[2] = element k + P of the two-stage form (t1 = w1 e[1], u2 = w2 (e[2] + w1 e[3]))
+            quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(P_INDEX), TW::late(P_INDEX));
+            passes<P_INDEX + 1>(e, tw, lane);
         }
     }
+    // the thread's twiddles: k = base mod P in every pass
+    __device__ static __forceinline__ QuarterTwiddles<N, DIR, REORDER> twiddles_of(int t) {
+        QuarterTwiddles<N, DIR, REORDER> tw;
+        tw.load(base_of(t), base_of(t));
+        return tw;
+    }
     // e[slot]: natural order e[rev2(m)] = x[t + m N/4], no reorder e[i] = x[4 t + i]; on return e[i] = result element base + out_offset(i)
-    __device__ static __forceinline__ void run(float2 (&e)[4], int t, int lane) {
-        const int base = base_of(t);
+    template <class TW>
+    __device__ static __forceinline__ void run(float2 (&e)[4], const TW& tw, int lane) {
         {   // pass 0: twiddles 1, 1, -+i
             const float2 s0 = cadd(e[0], e[1]), d0 = csub(e[0], e[1]), s1 = cadd(e[2], e[3]), d1 = csub(e[2], e[3]);
             const float2 jd1 = DIR ? make_float2(-d1.y, d1.x) : make_float2(d1.y, -d1.x);
             e[0] = cadd(s0, s1), e[1] = cadd(d0, jd1), e[2] = csub(s0, s1), e[3] = csub(d0, jd1);
         }
-        passes<1>(e, base, lane);
+        passes<1>(e, tw, lane);
         if constexpr (R::kOdd) {
             slots_swap<0, lane_bit_of(N_BITS - 3)>(e, lane);
-            const TwiddleValue tv = quarter_twiddle_rows<N>.w[R::row_start(R::kPasses) + base];
-            const float2 w = make_float2(tv.x, DIR ? -tv.y : tv.y);
+            const float2 w = tw.wr;
             const float2 t1 = cmul(e[1], w), v3 = cmul(e[3], w);
             const float2 t3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);
             const float2 x0 = e[0], x2 = e[2];
@@ -252,6 +322,7 @@ struct QuarterLanes {
     // the contract's form: data in s[region_offset .. + N) natural order in and out (IN_REGS: the inputs come in x[] instead)
     template <bool IN_REGS>
     __device__ static __forceinline__ void lds_to_lds(float2 (&x)[4], float2* s, int t, int region_offset) {
+        const QuarterTwiddles<N, DIR, REORDER> tw = twiddles_of(t);
         float2* sf = s + region_offset;
         float2 e[4];
         if constexpr (REORDER) {
@@ -261,7 +332,7 @@ struct QuarterLanes {
 #pragma unroll
             for (int i = 0; i < 4; ++i) e[i] = IN_REGS ? x[i] : sf[4 * t + i];
         }
-        run(e, t, (int)(threadIdx.x & 63));
+        run(e, tw, (int)(threadIdx.x & 63));
         if constexpr (!IN_REGS) fft_sync<false>();                  // every load of the transform's lanes precedes the stores (one wave)
         const int base = base_of(t);
 #pragma unroll
@@ -293,6 +364,10 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
     // the natural-order first pass (loads t + m N/4, stores 4 rev(t) + m), the passes with P >= 256 and the radix-2 pass.
     constexpr int T_BITS = ilog2c(Q);
     constexpr int kLastQuad = R::kOdd ? -1 : R::kPasses - 1;    // the pass whose results leave in natural order (none: the radix-2 pass is last)
+    // the twiddles first (QuarterTwiddles): k = t mod P in every pass of this form -- and in the wave-local ladder below, whose
+    // butterfly index is the lane = t mod 64 with P <= 64
+    QuarterTwiddles<N, DIR, REORDER> tw;
+    tw.load(t, t);
     float2* sf = s + region_offset;
     float2 e[4];
     // N >= 512, no reorder: the first FOUR passes (index bits 0 ... 7) never leave the wave -- thread t = lane + 64 w starts with
@@ -311,7 +386,7 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
     if constexpr (kLanesHead) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) e[i] = IN_REGS ? x[i] : sf[4 * t + i];
-        QuarterLanes<256, DIR, 0>::run(e, t & 63, t & 63);
+        QuarterLanes<256, DIR, 0>::run(e, tw, t & 63);
         if constexpr (!IN_REGS) fft_sync<false>();            // the wave's own loads precede its stores into the same 256 elements
         const int j0 = region_offset + (t & ~63) * 4 + (t & 63);
 #pragma unroll
@@ -345,7 +420,7 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
         const int b0 = quarter_swizzle(region_offset + 4 * t);     // elements 4 t + i: one aligned group of four
 #pragma unroll
         for (int i = 0; i < 4; ++i) e[i] = s[b0 ^ i];
-        QuarterLanes<256, DIR, 0>::template passes<1>(e, t & 63, t & 63);
+        QuarterLanes<256, DIR, 0>::template passes<1>(e, tw, t & 63);
         fft_sync<false>();                                         // the wave's own loads precede its stores into the same 256 elements
         const int j0 = region_offset + (t & ~63) * 4 + (t & 63);
 #pragma unroll
@@ -361,33 +436,27 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
             else fft_sync<false>();
             const int k = t & (P - 1);
             const int base = ((t - k) << 2) + k;
-            const TwiddleValue tv = quarter_twiddle_rows<N>.w[R::row_start(p) + k];
-            const float2 w2 = make_float2(tv.x, DIR ? -tv.y : tv.y);
-            const float2 w1 = make_float2(w2.x * w2.x - w2.y * w2.y, 2.f * w2.x * w2.y);
             const int a0 = quarter_swizzle(region_offset + base);
             const int a1 = a0 ^ quarter_swizzle(P), a2 = a0 ^ quarter_swizzle(2 * P), a3 = a0 ^ quarter_swizzle(3 * P);
+            // elements base, base + P, base + 2P, base + 3P; in the butterfly's order (w1 on the second, w2 on the third): x0, x1, x2, x3
             float2 x0 = s[a0], x1 = s[a1], x2 = s[a2], x3 = s[a3];
-            const float2 t1 = cmul(x1, w1), t3 = cmul(x3, w1);
-            const float2 y0 = cadd(x0, t1), y1 = csub(x0, t1), y2 = cadd(x2, t3), y3 = csub(x2, t3);
-            const float2 u2 = cmul(y2, w2), v3 = cmul(y3, w2);
-            const float2 u3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);  // y3 * w2 * (-+i)
+            quad_butterfly<DIR>(x0, x1, x2, x3, tw.of(p), tw.late(p));             // results: x0 -> base, x1 -> base + P, x2 -> base + 2P, x3 -> base + 3P
             if (p == kLastQuad) {
                 if constexpr (OUT_REGS) {                                                // base = t, P = N / 4
-                    x[0] = cadd(y0, u2), x[2] = csub(y0, u2), x[1] = cadd(y1, u3), x[3] = csub(y1, u3);
+                    x[0] = x0, x[2] = x2, x[1] = x1, x[3] = x3;
                 } else {
                     fft_sync<false>();                                                   // every swizzled load precedes the natural stores (same wave's)
-                    sf[base] = cadd(y0, u2), sf[base + 2 * P] = csub(y0, u2), sf[base + P] = cadd(y1, u3), sf[base + 3 * P] = csub(y1, u3);
+                    sf[base] = x0, sf[base + 2 * P] = x2, sf[base + P] = x1, sf[base + 3 * P] = x3;
                 }
             } else {
-                s[a0] = cadd(y0, u2), s[a2] = csub(y0, u2), s[a1] = cadd(y1, u3), s[a3] = csub(y1, u3);
+                s[a0] = x0, s[a2] = x2, s[a1] = x1, s[a3] = x3;
             }
         }
     }
     // ---- odd log2 N: the last radix-2 stage (span N/2), two butterflies per thread ----------------------------------
     if constexpr (R::kOdd) {
         fft_sync<kBarrier>();
-        const TwiddleValue tv = quarter_twiddle_rows<N>.w[R::row_start(R::kPasses) + t];
-        const float2 w = make_float2(tv.x, DIR ? -tv.y : tv.y);
+        const float2 w = tw.wr;
         const int a0 = quarter_swizzle(region_offset + t);
         const float2 x0 = s[a0], x1 = s[a0 ^ quarter_swizzle(N / 2)], x2 = s[a0 ^ quarter_swizzle(Q)], x3 = s[a0 ^ quarter_swizzle(3 * Q)];
         const float2 t1 = cmul(x1, w), v3 = cmul(x3, w);
@@ -411,9 +480,22 @@ __device__ __forceinline__ void quarter_fft_inplace(float2* s, int t, int region
 }
 
 // Hermitian split / merge on the reference's thread shape (L/4 threads, two pairs each: i = t + 1 and t + 1 + L/4, RC:289-328)
+// (w: hermitian_twiddles_quarter(t), fetched by the caller in front of everything else for the reason QuarterTwiddles gives)
 template <int L, int DIR>
-__device__ __forceinline__ void hermitian_pass_quarter(float2* sf, int t) {
+struct HermitianTwiddles { float2 w[2]; };
+template <int L, int DIR>
+__device__ __forceinline__ HermitianTwiddles<L, DIR> hermitian_twiddles_quarter(int t) {
     constexpr float ohx = DIR ? -0.5f : 0.5f;
+    HermitianTwiddles<L, DIR> h;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float2 W = twiddle<DIR>((1 + t + k * (L / 4)) * (4096 / (2 * L)));
+        h.w[k] = make_float2(ohx * W.x, ohx * W.y);
+    }
+    return h;
+}
+template <int L, int DIR>
+__device__ __forceinline__ void hermitian_pass_quarter(float2* sf, int t, const HermitianTwiddles<L, DIR>& tw) {
     if (DIR && t == 0) {
         const float2 z = sf[0];
         sf[0] = make_float2(0.5f * (z.x + z.y), 0.5f * (z.x - z.y));
@@ -422,8 +504,7 @@ __device__ __forceinline__ void hermitian_pass_quarter(float2* sf, int t) {
     for (int h = 0; h < 2; ++h) {
         const int i = 1 + t + h * (L / 4);
         const float2 A = sf[i], B = sf[L - i];
-        const float2 W = twiddle<DIR>(i * (4096 / (2 * L)));
-        const float2 Wh = make_float2(ohx * W.x, ohx * W.y);
+        const float2 Wh = tw.w[h];
         const float2 S = make_float2(A.x + B.x, A.y - B.y);
         const float2 D = make_float2(A.y + B.y, A.x - B.x);
         const float2 WH = make_float2(fmaf(Wh.x, D.x, Wh.y * D.y), fmaf(Wh.y, D.x, -Wh.x * D.y));
@@ -522,12 +603,13 @@ template <class const_params, class const_direction>
 __device__ void do_FFT_Stockham_R2C_C2R(float2* s_input) {
     constexpr int L = const_params::fft_length;
     constexpr int D = const_direction::fft_direction;
-    if (D == 0) {
+    const auto herm = smfft::hermitian_twiddles_quarter<L, D>(threadIdx.x);
+    if constexpr (D == 0) {
         smfft::quarter_fft_inplace<L, 0, 1, L / 4>(s_input, threadIdx.x);
         __syncthreads();
-        smfft::hermitian_pass_quarter<L, 0>(s_input, threadIdx.x);
+        smfft::hermitian_pass_quarter<L, 0>(s_input, threadIdx.x, herm);
     } else {
-        smfft::hermitian_pass_quarter<L, 1>(s_input, threadIdx.x);
+        smfft::hermitian_pass_quarter<L, 1>(s_input, threadIdx.x, herm);
         __syncthreads();
         smfft::quarter_fft_inplace<L, 1, 1, L / 4>(s_input, threadIdx.x);
     }
@@ -560,6 +642,7 @@ __global__ void SMFFT_DIT_external(float2* d_input, float2* d_output) {
         const int t = threadIdx.x % Q;
         const float2* in = d_input + (size_t)blockIdx.x * const_params::fft_length + (threadIdx.x / Q) * N;
         float2* out = d_output + (size_t)blockIdx.x * const_params::fft_length + (threadIdx.x / Q) * N;
+        const auto tw = L::twiddles_of(t);
         float2 e[4];
         if constexpr (const_params::fft_reorder) {
 #pragma unroll
@@ -568,7 +651,7 @@ __global__ void SMFFT_DIT_external(float2* d_input, float2* d_output) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) e[i] = in[4 * t + i];
         }
-        L::run(e, t, (int)(threadIdx.x & 63));
+        L::run(e, tw, (int)(threadIdx.x & 63));
         const int base = L::base_of(t);
 #pragma unroll
         for (int i = 0; i < 4; ++i) out[base + L::out_offset(i)] = e[i];
@@ -682,17 +765,19 @@ __global__ void FFT_GPU_R2C_C2R_external(float2* d_input, float2* d_output) {
         if constexpr (const_direction::fft_direction == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) x[k] = d_input[base + k * const_params::fft_quarter];
+            const auto herm = smfft::hermitian_twiddles_quarter<L, 0>(threadIdx.x);
             smfft::quarter_fft<L, 0, 1, L / 4, true, false>(x, s_input, threadIdx.x);
             __syncthreads();
-            smfft::hermitian_pass_quarter<L, 0>(s_input, threadIdx.x);
+            smfft::hermitian_pass_quarter<L, 0>(s_input, threadIdx.x, herm);
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 4; ++k) d_output[base + k * const_params::fft_quarter] = s_input[threadIdx.x + k * const_params::fft_quarter];
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) s_input[threadIdx.x + k * const_params::fft_quarter] = d_input[base + k * const_params::fft_quarter];
+            const auto herm = smfft::hermitian_twiddles_quarter<L, 1>(threadIdx.x);
             __syncthreads();
-            smfft::hermitian_pass_quarter<L, 1>(s_input, threadIdx.x);
+            smfft::hermitian_pass_quarter<L, 1>(s_input, threadIdx.x, herm);
             __syncthreads();
             smfft::quarter_fft<L, 1, 1, L / 4, false, true>(x, s_input, threadIdx.x);
 #pragma unroll
