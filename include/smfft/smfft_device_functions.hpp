@@ -164,6 +164,7 @@ template <int N, int DIR, int REORDER>
 struct QuarterTwiddles {
     using R = QuarterTwiddleRows<N>;
     static constexpr int kLatePasses = quarter_late_passes(N, REORDER != 0);
+    static constexpr bool kRowSelects = N < 1024;      // how the wave-local ladder of THIS length swaps lane bits 2 / 3 (slots_swap)
     static constexpr bool late(int p) { return p >= R::kPasses - kLatePasses; }
     QuadTwiddle q[R::kPasses > 1 ? R::kPasses : 1];    // q[p], p = 1 .. kPasses - 1 (P = 4^p)
     float2 wr;                                         // the radix-2 pass of an odd log2 N
@@ -249,28 +250,28 @@ __host__ __device__ constexpr int quarter_swizzle(int i) { return i ^ ((i >> 8) 
 #define SMFFT_QUARTER_LANES 1          // 0: every length through LDS (A/B)
 #endif
 constexpr bool quarter_lanes_default(int n) { return SMFFT_QUARTER_LANES != 0 && n <= 256; }
-template <int LANE_BIT>
-__device__ __forceinline__ void lane_slot_swap(float2& A, float2& B, int lane) {
+// slot bit SLOT_BIT of the thread's four elements <-> lane bit LANE_BIT (ROW_SELECTS: lane bits 2 / 3 through the selects of
+// swap_bit_select instead of the bank-masked moves of swap_bit_dpp_dword -- faster except in the blocks of N >= 1024)
+template <int LANE_BIT, bool ROW_SELECTS>
+__device__ __forceinline__ void lane_slot_swap(float2& A, float2& B) {
     using X = Engine<1024, 0, 1>;                // (the transposes are static members; the length is immaterial)
     if constexpr (LANE_BIT >= 4) {
         X::template swap_bit<LANE_BIT>(A, B);
-    } else if constexpr (LANE_BIT <= 1) {
-        X::template swap_bit_quad<LANE_BIT>(A, B, (lane >> LANE_BIT) & 1);
+    } else if constexpr (LANE_BIT <= 1 || ROW_SELECTS) {
+        X::template swap_bit_select<LANE_BIT>(A, B);
     } else {
-        const bool hi = (lane >> LANE_BIT) & 1;
-        X::template swap_bit_dpp_dword<LANE_BIT>(A.x, B.x, hi);
-        X::template swap_bit_dpp_dword<LANE_BIT>(A.y, B.y, hi);
+        X::template swap_bit_dpp_dword<LANE_BIT>(A.x, B.x);
+        X::template swap_bit_dpp_dword<LANE_BIT>(A.y, B.y);
     }
 }
-// slot bit SLOT_BIT of the thread's four elements <-> lane bit LANE_BIT
-template <int SLOT_BIT, int LANE_BIT>
-__device__ __forceinline__ void slots_swap(float2 (&e)[4], int lane) {
+template <int SLOT_BIT, int LANE_BIT, bool ROW_SELECTS>
+__device__ __forceinline__ void slots_swap(float2 (&e)[4]) {
     if constexpr (SLOT_BIT == 0) {
-        lane_slot_swap<LANE_BIT>(e[0], e[1], lane);
-        lane_slot_swap<LANE_BIT>(e[2], e[3], lane);
+        lane_slot_swap<LANE_BIT, ROW_SELECTS>(e[0], e[1]);
+        lane_slot_swap<LANE_BIT, ROW_SELECTS>(e[2], e[3]);
     } else {
-        lane_slot_swap<LANE_BIT>(e[0], e[2], lane);
-        lane_slot_swap<LANE_BIT>(e[1], e[3], lane);
+        lane_slot_swap<LANE_BIT, ROW_SELECTS>(e[0], e[2]);
+        lane_slot_swap<LANE_BIT, ROW_SELECTS>(e[1], e[3]);
     }
 }
 template <int N, int DIR, int REORDER>
@@ -286,13 +287,13 @@ struct QuarterLanes {
 
     // (TW: the QuarterTwiddles of this length or of a longer one -- the rows W_4P^k depend on P only)
     template <int P_INDEX, class TW>
-    __device__ static __forceinline__ void passes(float2 (&e)[4], const TW& tw, int lane) {
+    __device__ static __forceinline__ void passes(float2 (&e)[4], const TW& tw) {
         if constexpr (P_INDEX < R::kPasses) {
-            slots_swap<0, lane_bit_of(2 * P_INDEX - 2)>(e, lane);
-            slots_swap<1, lane_bit_of(2 * P_INDEX - 1)>(e, lane);
+            slots_swap<0, lane_bit_of(2 * P_INDEX - 2), TW::kRowSelects>(e);
+            slots_swap<1, lane_bit_of(2 * P_INDEX - 1), TW::kRowSelects>(e);
             // slots: e[1] = element k + 2P, e[2] = element k + P of the two-stage form (t1 = w1 e[1], u2 = w2 (e[2] + w1 e[3]))
             quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(P_INDEX), TW::late(P_INDEX));
-            passes<P_INDEX + 1>(e, tw, lane);
+            passes<P_INDEX + 1>(e, tw);
         }
     }
     // the thread's twiddles: k = base mod P in every pass
@@ -303,15 +304,15 @@ struct QuarterLanes {
     }
     // e[slot]: natural order e[rev2(m)] = x[t + m N/4], no reorder e[i] = x[4 t + i]; on return e[i] = result element base + out_offset(i)
     template <class TW>
-    __device__ static __forceinline__ void run(float2 (&e)[4], const TW& tw, int lane) {
+    __device__ static __forceinline__ void run(float2 (&e)[4], const TW& tw) {
         {   // pass 0: twiddles 1, 1, -+i
             const float2 s0 = cadd(e[0], e[1]), d0 = csub(e[0], e[1]), s1 = cadd(e[2], e[3]), d1 = csub(e[2], e[3]);
             const float2 jd1 = DIR ? make_float2(-d1.y, d1.x) : make_float2(d1.y, -d1.x);
             e[0] = cadd(s0, s1), e[1] = cadd(d0, jd1), e[2] = csub(s0, s1), e[3] = csub(d0, jd1);
         }
-        passes<1>(e, tw, lane);
+        passes<1>(e, tw);
         if constexpr (R::kOdd) {
-            slots_swap<0, lane_bit_of(N_BITS - 3)>(e, lane);
+            slots_swap<0, lane_bit_of(N_BITS - 3), TW::kRowSelects>(e);
             const float2 w = tw.wr;
             const float2 t1 = cmul(e[1], w), v3 = cmul(e[3], w);
             const float2 t3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);
@@ -332,7 +333,7 @@ struct QuarterLanes {
 #pragma unroll
             for (int i = 0; i < 4; ++i) e[i] = IN_REGS ? x[i] : sf[4 * t + i];
         }
-        run(e, tw, (int)(threadIdx.x & 63));
+        run(e, tw);
         if constexpr (!IN_REGS) fft_sync<false>();                  // every load of the transform's lanes precedes the stores (one wave)
         const int base = base_of(t);
 #pragma unroll
@@ -386,7 +387,7 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
     if constexpr (kLanesHead) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) e[i] = IN_REGS ? x[i] : sf[4 * t + i];
-        QuarterLanes<256, DIR, 0>::run(e, tw, t & 63);
+        QuarterLanes<256, DIR, 0>::run(e, tw);
         if constexpr (!IN_REGS) fft_sync<false>();            // the wave's own loads precede its stores into the same 256 elements
         const int j0 = region_offset + (t & ~63) * 4 + (t & 63);
 #pragma unroll
@@ -420,7 +421,7 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
         const int b0 = quarter_swizzle(region_offset + 4 * t);     // elements 4 t + i: one aligned group of four
 #pragma unroll
         for (int i = 0; i < 4; ++i) e[i] = s[b0 ^ i];
-        QuarterLanes<256, DIR, 0>::template passes<1>(e, tw, t & 63);
+        QuarterLanes<256, DIR, 0>::template passes<1>(e, tw);
         fft_sync<false>();                                         // the wave's own loads precede its stores into the same 256 elements
         const int j0 = region_offset + (t & ~63) * 4 + (t & 63);
 #pragma unroll
@@ -651,7 +652,7 @@ __global__ void SMFFT_DIT_external(float2* d_input, float2* d_output) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) e[i] = in[4 * t + i];
         }
-        L::run(e, tw, (int)(threadIdx.x & 63));
+        L::run(e, tw);
         const int base = L::base_of(t);
 #pragma unroll
         for (int i = 0; i < 4; ++i) out[base + L::out_offset(i)] = e[i];

@@ -556,12 +556,45 @@ struct Engine {
             for (int r2 = 0; r2 < RM; ++r2) r[c * RM + r2] = t[BM * r2 + c];
     }
 
-    // The same one-bit transpose for lane bits 2 and 3 (inside a 16-lane row) with DPP: lanes with the bit clear send B and
-    // receive the partner's A into B, lanes with it set send A and receive the partner's B into A.  The receiving lanes are
-    // selected with the DPP bank mask (a bank = 4 lanes of a row): two v_mov_b32_dpp per dword pair.
+    // The same one-bit transpose for the lane bits 0 ... 3 (partner inside the 16-lane row) on a float2 pair in FOUR instructions:
+    // v_cndmask_b32 takes its first source through DPP, so "keep mine or take the partner's" is ONE instruction per dword and side --
+    // the lanes with the bit clear keep A and take the partner's A into B, the others keep B and take the partner's B into A;
+    // partner = quad_perm (bits 0 / 1) or a rotation of the row (bits 2 / 3: the lanes with the bit set read lane - 2^bit =
+    // row_ror:2^bit, the others lane + 2^bit = row_ror:16 - 2^bit).  hipcc does not fold a DPP move into the select (it emits
+    // v_mov_b32_dpp + v_cndmask_b32), hence the inline assembly; the lane masks are constants because every transform's lanes start
+    // at a multiple of their count.  s_nop 1: the two wait states a DPP read needs after a VALU write of the same register (the
+    // assembler does not see into the block).  Measured (profiles/r05_select_row_swap.txt): eight selects per block, or the blocks
+    // without `volatile` (free to be scheduled), are slower than this.
+#define SMFFT_SELECT(CTL_A, CTL_B)                                                                          \
+    "s_nop 1\n\ts_mov_b64 vcc, %8\n\t"                                                                     \
+    "v_cndmask_b32_dpp %0, %6, %4, vcc " CTL_A " row_mask:0xf bank_mask:0xf\n\t"                            \
+    "v_cndmask_b32_dpp %1, %7, %5, vcc " CTL_A " row_mask:0xf bank_mask:0xf\n\t"                            \
+    "s_not_b64 vcc, vcc\n\t"                                                                               \
+    "v_cndmask_b32_dpp %2, %4, %6, vcc " CTL_B " row_mask:0xf bank_mask:0xf\n\t"                            \
+    "v_cndmask_b32_dpp %3, %5, %7, vcc " CTL_B " row_mask:0xf bank_mask:0xf"
     template <int LANE_BIT>
-    __device__ static __forceinline__ void swap_bit_dpp_dword(float& A, float& B, bool) {
-        static_assert(LANE_BIT == 2 || LANE_BIT == 3, "bits 0 / 1: swap_bit_quad");
+    __device__ static __forceinline__ void swap_bit_select(float2& A, float2& B) {
+        static_assert(LANE_BIT >= 0 && LANE_BIT <= 3, "inside a 16-lane row");
+        constexpr unsigned long long lo = LANE_BIT == 0 ? 0x5555555555555555ull : LANE_BIT == 1 ? 0x3333333333333333ull
+                                        : LANE_BIT == 2 ? 0x0F0F0F0F0F0F0F0Full : 0x00FF00FF00FF00FFull;     // lanes with the bit clear
+        float nax, nay, nbx, nby;
+#define SMFFT_SELECT_OPERANDS : "=&v"(nax), "=&v"(nay), "=&v"(nbx), "=&v"(nby) : "v"(A.x), "v"(A.y), "v"(B.x), "v"(B.y), "s"(lo) : "vcc", "scc"   /* (s_not_b64 writes SCC) */
+        if constexpr (LANE_BIT == 0) asm volatile(SMFFT_SELECT("quad_perm:[1,0,3,2]", "quad_perm:[1,0,3,2]") SMFFT_SELECT_OPERANDS);
+        else if constexpr (LANE_BIT == 1) asm volatile(SMFFT_SELECT("quad_perm:[2,3,0,1]", "quad_perm:[2,3,0,1]") SMFFT_SELECT_OPERANDS);
+        else if constexpr (LANE_BIT == 2) asm volatile(SMFFT_SELECT("row_ror:4", "row_ror:12") SMFFT_SELECT_OPERANDS);
+        else asm volatile(SMFFT_SELECT("row_ror:8", "row_ror:8") SMFFT_SELECT_OPERANDS);
+#undef SMFFT_SELECT_OPERANDS
+        A = make_float2(nax, nay);     // lanes with the bit clear keep A; the others take the partner's B
+        B = make_float2(nbx, nby);     // lanes with the bit set keep B; the others take the partner's A
+    }
+#undef SMFFT_SELECT
+    // Lane bits 2 / 3 with two bank-masked v_mov_b32_dpp per dword pair, in place (a bank = 4 lanes of a row): the second move reads
+    // what the first overwrote, so the compiler copies one register first -- three instructions per dword pair against the selects'
+    // two, but instructions the compiler schedules.  The reference-contract ladder of N >= 1024 (4 ... 16 waves per block between
+    // barriers) measured 2 ... 8 % FASTER with this form, every other user 3 ... 13 % slower (profiles/r05_select_row_swap.txt).
+    template <int LANE_BIT>
+    __device__ static __forceinline__ void swap_bit_dpp_dword(float& A, float& B) {
+        static_assert(LANE_BIT == 2 || LANE_BIT == 3, "bits 0 / 1: swap_bit_select");
         const int a = __float_as_int(A), b = __float_as_int(B);
         int na, nb;
         if constexpr (LANE_BIT == 2) {
@@ -574,50 +607,18 @@ struct Engine {
         A = __int_as_float(na);
         B = __int_as_float(nb);
     }
-    // Lane bits 0 / 1 (partner inside the quad) on a float2 pair in FOUR instructions: v_cndmask_b32 takes its first
-    // source through DPP, so "keep mine or take the partner's" is one instruction per dword and side -- hipcc does not fold the
-    // quad-perm move into the select (it emits v_mov_b32_dpp + v_cndmask_b32: eight), hence the inline assembly.  The lane masks are
-    // constants because every transform's lanes start at a multiple of their count.  s_nop 1: the two wait states a DPP read
-    // needs after a VALU write of the same register (the assembler does not see into the block).
-    template <int LANE_BIT>
-    __device__ static __forceinline__ void swap_bit_quad(float2& A, float2& B, bool hi) {
-        static_assert(LANE_BIT == 0 || LANE_BIT == 1, "inside a quad");
-        constexpr unsigned long long lo = LANE_BIT == 0 ? 0x5555555555555555ull : 0x3333333333333333ull;   // lanes with the bit clear
-        float nax, nay, nbx, nby;
-        if constexpr (LANE_BIT == 0) {
-            asm volatile("s_nop 1\n\ts_mov_b64 vcc, %8\n\t"
-                         "v_cndmask_b32_dpp %0, %6, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                         "v_cndmask_b32_dpp %1, %7, %5, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                         "s_not_b64 vcc, vcc\n\t"
-                         "v_cndmask_b32_dpp %2, %4, %6, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                         "v_cndmask_b32_dpp %3, %5, %7, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-                         : "=&v"(nax), "=&v"(nay), "=&v"(nbx), "=&v"(nby) : "v"(A.x), "v"(A.y), "v"(B.x), "v"(B.y), "s"(lo) : "vcc", "scc");      // (s_not_b64 writes SCC)
-        } else {
-            asm volatile("s_nop 1\n\ts_mov_b64 vcc, %8\n\t"
-                         "v_cndmask_b32_dpp %0, %6, %4, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                         "v_cndmask_b32_dpp %1, %7, %5, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                         "s_not_b64 vcc, vcc\n\t"
-                         "v_cndmask_b32_dpp %2, %4, %6, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                         "v_cndmask_b32_dpp %3, %5, %7, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-                         : "=&v"(nax), "=&v"(nay), "=&v"(nbx), "=&v"(nby) : "v"(A.x), "v"(A.y), "v"(B.x), "v"(B.y), "s"(lo) : "vcc", "scc");      // (s_not_b64 writes SCC)
-        }
-        A = make_float2(nax, nay);     // lanes with the bit clear keep A; the others take the partner's B
-        B = make_float2(nbx, nby);     // lanes with the bit set keep B; the others take the partner's A
-        (void)hi;
-    }
     // all 8 register pairs (c, c | 1 << reg_bit), c with that bit clear
     __device__ __forceinline__ void swap_lane_bit_with_register_bit(float2 (&r)[16], int lane_bit, int reg_bit) const {
-        const bool hi = (u >> lane_bit) & 1;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             if ((c >> reg_bit) & 1) continue;
             float2& A = r[c];
             float2& B = r[c | (1 << reg_bit)];
             switch (lane_bit + kLaneShift) {
-                case 0: swap_bit_quad<0>(A, B, hi); break;
-                case 1: swap_bit_quad<1>(A, B, hi); break;
-                case 2: swap_bit_dpp_dword<2>(A.x, B.x, hi); swap_bit_dpp_dword<2>(A.y, B.y, hi); break;
-                default: swap_bit_dpp_dword<3>(A.x, B.x, hi); swap_bit_dpp_dword<3>(A.y, B.y, hi); break;
+                case 0: swap_bit_select<0>(A, B); break;
+                case 1: swap_bit_select<1>(A, B); break;
+                case 2: swap_bit_select<2>(A, B); break;
+                default: swap_bit_select<3>(A, B); break;
             }
         }
     }
