@@ -744,4 +744,137 @@ __device__ __forceinline__ void fft_lds_inplace(float2* s, const Engine<N, DIR, 
     eng.store_lds(r, sf);
 }
 
+// ------------------------------------------------------------------------------------------------
+// N = 32 in the in-LDS path: the FFT is a PAIR of lanes (u = 0 / 1, eight lanes apart: row_ror:8) with sixteen registers each,
+// and the radix-2 stage that crosses the pair is one v_fmac_f32 per dword whose first source comes through DPP:
+//     own <- own + s * partner's own                 (s = +-1 per lane, a register)
+// -- exchange and butterfly in ONE instruction, where the general engine spends a select per dword for the exchange and an
+// addition per dword for the butterfly (32 + 32 of its 252 instructions per application).  What makes it possible is to let the
+// LAYOUT alternate instead of restoring it:
+//     layout A: r[c] = x[u + 2c]         layout B: r[n] = x[n + 16u]
+//     dit:  A -> B    Z_u = DFT16(r) . W_32^(u q),      lane p ends with X[q + 16p] = Z_0[q] + (-1)^p Z_1[q]
+//     dif:  B -> A    y_0 = x[n] + x[n+16], y_1 = (x[n] - x[n+16]) W_32^n,   lane u ends with X[u + 2k] = DFT16(y_u)[k]
+// Natural order: applications alternate dit, dif (the output of one IS the input layout of the other).  No reorder (the
+// transform of x o bitrev, natural output): bitrev(u + 2c) = 16u + rev4(c), so layout A of x o bitrev is layout B of x with the
+// registers renamed -- dit every time.  Signs: with s = (+1, -1) lane 1 ends a dit with -X[q + 16]; the next stage takes
+// s = (-1, +1) and comes out plain (both dit and dif are linear in lane 1's registers), so nothing is ever negated in the
+// loop -- only where a piece of a chain starts or ends on an odd application (load_b / store_b with `negated`).  Which form an
+// application takes depends on its index in the CHAIN only, so a chain cut between two workgroups computes the same bits.
+// Per application: 128 (radix 16) + 60 (fifteen twiddles) + 32 fused = 220 instructions, no LDS access, no exchange.
+// ------------------------------------------------------------------------------------------------
+template <int DIR, int REORDER>
+struct PairEngine32 {
+    static constexpr int N = 32;
+    using G = Geometry<N>;
+    int u, fft;
+    float s_plain;            // +1 (lane 0) / -1 (lane 1): the stage whose inputs are plain; -s_plain: lane 1's are negated
+    float2 tw[16];            // W_32^(u n): 1 in lane 0
+
+    __device__ __forceinline__ void init(int tid) {
+        const int lane = tid & 63;
+        u = (lane >> 3) & 1;
+        fft = (tid >> 6) * 32 + (lane >> 4) * 8 + (lane & 7);
+        s_plain = u ? -1.f : 1.f;
+#pragma unroll
+        for (int n = 1; n < 16; ++n) {
+            const float2 w = twiddle<DIR>(n * (4096 / N));
+            tw[n] = u ? w : make_float2(1.f, 0.f);
+        }
+    }
+    // r[i] <- r[i] + s * (partner's r[i]), i = 0 .. 15 (both dwords): two blocks of sixteen v_fmac_f32_dpp
+    // (s_nop 1: the two wait states a DPP read needs after a VALU write of the same register)
+    __device__ static __forceinline__ void cross(float2 (&r)[16], float s) {
+#define SMFFT_FUSED8(B)                                                                                                  \
+        asm volatile("s_nop 1\n\t"                                                                                       \
+                     "v_fmac_f32_dpp %0, %0, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                               \
+                     "v_fmac_f32_dpp %1, %1, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                               \
+                     "v_fmac_f32_dpp %2, %2, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                               \
+                     "v_fmac_f32_dpp %3, %3, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                               \
+                     "v_fmac_f32_dpp %4, %4, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                               \
+                     "v_fmac_f32_dpp %5, %5, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                               \
+                     "v_fmac_f32_dpp %6, %6, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                               \
+                     "v_fmac_f32_dpp %7, %7, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                               \
+                     "v_fmac_f32_dpp %8, %8, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                               \
+                     "v_fmac_f32_dpp %9, %9, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                               \
+                     "v_fmac_f32_dpp %10, %10, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                             \
+                     "v_fmac_f32_dpp %11, %11, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                             \
+                     "v_fmac_f32_dpp %12, %12, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                             \
+                     "v_fmac_f32_dpp %13, %13, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                             \
+                     "v_fmac_f32_dpp %14, %14, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                             \
+                     "v_fmac_f32_dpp %15, %15, %16 row_ror:8 row_mask:0xf bank_mask:0xf"                                  \
+                     : "+v"(r[B].x), "+v"(r[B].y), "+v"(r[B + 1].x), "+v"(r[B + 1].y), "+v"(r[B + 2].x), "+v"(r[B + 2].y),          \
+                       "+v"(r[B + 3].x), "+v"(r[B + 3].y), "+v"(r[B + 4].x), "+v"(r[B + 4].y), "+v"(r[B + 5].x), "+v"(r[B + 5].y),  \
+                       "+v"(r[B + 6].x), "+v"(r[B + 6].y), "+v"(r[B + 7].x), "+v"(r[B + 7].y)                                       \
+                     : "v"(s))
+        SMFFT_FUSED8(0);
+        SMFFT_FUSED8(8);
+#undef SMFFT_FUSED8
+    }
+    // layout A -> layout B: r[c] = x[u + 2c] -> r[q] = X[q + 16u]   (s: s_plain for plain inputs, -s_plain for a negated lane 1;
+    // lane 1's results are negated in the first case, plain in the second)
+    __device__ __forceinline__ void dit(float2 (&r)[16], float s) const {
+        float2 y[16];
+        SmallDft<16, 1, DIR, false>::run(r, y);
+#pragma unroll
+        for (int q = 1; q < 16; ++q) y[q] = cmul(y[q], tw[q]);
+        cross(y, s);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) r[q] = y[q];
+    }
+    // layout B -> layout A: r[n] = x[n + 16u] -> r[k] = X[u + 2k]   (same convention for s; the results are plain when lane 1's inputs were negated)
+    __device__ __forceinline__ void dif(float2 (&r)[16], float s) const {
+        cross(r, s);
+#pragma unroll
+        for (int n = 1; n < 16; ++n) r[n] = cmul(r[n], tw[n]);
+        float2 y[16];
+        SmallDft<16, 1, DIR, false>::run(r, y);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r[k] = y[k];
+    }
+    // one application, number f of its chain (see the head of the struct); `f` odd: lane 1's registers come in negated
+    __device__ __forceinline__ void apply(float2 (&r)[16], bool odd) const {
+        const float s = odd ? -s_plain : s_plain;
+        if constexpr (REORDER) {
+            if (!odd) dit(r, s);
+            else dif(r, s);
+        } else {
+            float2 x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x[c] = r[((c & 1) << 3) | ((c & 2) << 1) | ((c & 4) >> 1) | ((c & 8) >> 3)];     // layout A of x o bitrev
+            dit(x, s);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) r[q] = x[q];
+        }
+    }
+    // the registers of a piece that starts at application f0 / ends before application f1 of its chain <-> the FFT's region of the
+    // LDS image (natural order; PADDED: element p at p + (p >> 4), the no-reorder image of the tile copies)
+    static constexpr bool kPadded = !REORDER;
+    __device__ static __forceinline__ int image(int p) { return p + (kPadded ? (p >> G::kPadShift) : 0); }
+    __device__ __forceinline__ void load(float2 (&r)[16], const float2* sf, int f0) const {
+        const bool odd = f0 & 1;
+        if (REORDER && !odd) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) r[c] = sf[image(u + 2 * c)];
+        } else {
+            const float m = odd ? s_plain : 1.f;
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const float2 v = sf[image(n + 16 * u)];
+                r[n] = make_float2(m * v.x, m * v.y);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(const float2 (&r)[16], float2* sf, int f1) const {
+        const bool odd = f1 & 1;
+        if (REORDER && !odd) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) sf[image(u + 2 * c)] = r[c];
+        } else {
+            const float m = odd ? s_plain : 1.f;
+#pragma unroll
+            for (int n = 0; n < 16; ++n) sf[image(n + 16 * u)] = make_float2(m * r[n].x, m * r[n].y);
+        }
+    }
+};
+
 }  // namespace smfft

@@ -426,20 +426,21 @@ struct Piece {
     __device__ __forceinline__ bool resumed() const { return app0 > 0; }
 };
 
-// C2C, multiple, on the float2 engine (N = 32: its transform never leaves the registers -- two threads per FFT, one DPP
-// transposition -- and the planar engine measured 10 % slower there, profiles/r03_ab_planar_small.txt):
-// the first nSlots FFTs are loaded once, transformed nreuses (= NREUSES = 100 in the
-// benchmark; a kernel argument so the tests can run 1, 2 and 4 applications) times in LDS, stored once.
-// Every application reads its input from LDS and writes its result to LDS (the device function's contract);
-// what the kernel chooses is the IMAGE the data are kept in between applications: natural order for the reorder
-// variants, the padded image of Engine::bitrev_write for the no-reorder variants -- a result is stored straight into
-// the layout the next application's bit-reversed read wants, instead of natural order + a second write and read.
+// C2C, multiple, N = 32 (CT:553-572): the first nSlots FFTs are loaded once, transformed nreuses (= NREUSES = 100 in the benchmark; a
+// kernel argument so the tests can run 1, 2 and 4 applications) times, stored once.  An FFT is a pair of lanes and lives in their
+// registers from the first application of a piece to its last (PairEngine32, smfft_engine.hpp: the stage across the pair is one
+// DPP-fed v_fmac_f32 per dword, the layout alternates instead of being restored); the image in LDS -- natural order, padded for
+// the no-reorder variants as the tile copies have it -- is touched where a piece starts and ends.  (Rounds 2-4 ran this length on
+// the general float2 engine -- a radix-2 stage, a lane <-> register transpose of 32 selects, a radix-16 stage and, without reorder,
+// a bit-reversal through LDS per application: profiles/r05_pair32.txt has both; the planar engine measured 10 % slower than that
+// one, profiles/r03_ab_planar_small.txt.)
 // (d_input / d_output are not __restrict__ here: a resumed piece READS the tile another workgroup of this launch parked in d_output)
 template <int N, int DIR, int REORDER>
 __device__ __forceinline__ void c2c_multiple_body(const float2* d_input, float2* d_output, int nSlots, int nreuses, MultipleSchedule sch, float2* s) {
+    static_assert(N == 32, "the planar engine takes every longer length");
     using G = Geometry<N>;
     constexpr bool kPaddedImage = !REORDER;
-    Engine<N, DIR, REORDER> eng;
+    PairEngine32<DIR, REORDER> eng;
     eng.init(threadIdx.x);
     float2* sf = s + eng.fft * G::SF;
     const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
@@ -452,39 +453,34 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* d_input, float2*
         const Piece piece(pieces, sch, k);
         if (piece.skip) continue;
         const long first = (long)piece.tile * G::kCompactFfts;
-        const int napps = piece.app1 - piece.app0;
         fft_sync<G::kMultiWave>();
         if (piece.resumed()) shared_tile_to_lds<N, kPaddedImage>(d_output + first * N, s, first, nSlots);
         else tile_to_lds<N, kPaddedImage>(d_input + first * N, s, first, nSlots);
         fft_sync<G::kMultiWave>();
         trace_piece(sch.trace, k, 0);
-        if constexpr (kPaddedImage) {
-            for (int f = 0; f < napps; ++f) {
-                priority.at_application();
-                float2 r[16];
-                eng.bitrev_read(r, sf);
-                fft_sync<G::kMultiWave>();          // all inputs are in registers before the region is reused
-                eng.transform_from_pass1_slots(r, sf);
-                fft_sync<G::kMultiWave>();          // all exchange reads done before the results overwrite them
-                eng.bitrev_write(r, sf);
-                fft_sync<G::kMultiWave>();          // the reference omits this (latent race, CT:563-565)
-            }
-        } else {
-            // Natural-order image: what a thread stores at the end of an application (r[q] -> sf[u + T*q]) is exactly what
-            // it would load at the start of the next one (r[c] <- sf[u + T*c]).  Every result is still stored (the data
-            // are in LDS, natural order, after every application, as the device function's contract has it); the re-load
-            // of the thread's own stores is forwarded from its registers: 16 of the 64 LDS operations per application.
-            float2 r[16];
-            eng.load_lds(r, sf);
-            for (int f = 0; f < napps; ++f) {
-                priority.at_application();
-                fft_sync<G::kMultiWave>();
-                eng.transform(r, sf);
-                fft_sync<G::kMultiWave>();
-                eng.store_lds(r, sf);
-                fft_sync<G::kMultiWave>();          // the reference omits this (latent race, CT:563-565)
-            }
+        // The applications run on the pair's registers alone (PairEngine32): the image in LDS is read where the piece starts and
+        // written where it ends.  An application's form follows from its number in the chain, so the loop is unrolled by two.
+        float2 r[16];
+        eng.load(r, sf, piece.app0);
+        int f = piece.app0;
+        if (f & 1) {
+            priority.at_application();
+            eng.apply(r, true);
+            ++f;
         }
+        for (; f + 1 < piece.app1; f += 2) {
+            priority.at_application();
+            eng.apply(r, false);
+            priority.at_application();
+            eng.apply(r, true);
+        }
+        if (f < piece.app1) {
+            priority.at_application();
+            eng.apply(r, false);
+        }
+        fft_sync<G::kMultiWave>();              // (the wave's loads of the image precede its stores)
+        eng.store(r, sf, piece.app1);
+        fft_sync<G::kMultiWave>();
         priority.between_applications();
         trace_piece(sch.trace, k, 1);
         if (!piece.park) {
