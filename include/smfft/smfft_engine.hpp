@@ -758,7 +758,7 @@ __device__ __forceinline__ void fft_lds_inplace(float2* s, const Engine<N, DIR, 
 // transform of x o bitrev, natural output): bitrev(u + 2c) = 16u + rev4(c), so layout A of x o bitrev is layout B of x with the
 // registers renamed -- dit every time.  Signs: with s = (+1, -1) lane 1 ends a dit with -X[q + 16]; the next stage takes
 // s = (-1, +1) and comes out plain (both dit and dif are linear in lane 1's registers), so nothing is ever negated in the
-// loop -- only where a piece of a chain starts or ends on an odd application (load_b / store_b with `negated`).  Which form an
+// loop -- only where a piece of a chain starts or ends on an odd application (load / store flip lane 1's sign bits there).  Which form an
 // application takes depends on its index in the CHAIN only, so a chain cut between two workgroups computes the same bits.
 // Per application: 128 (radix 16) + 60 (fifteen twiddles) + 32 fused = 220 instructions, no LDS access, no exchange.
 // ------------------------------------------------------------------------------------------------
@@ -848,6 +848,10 @@ struct PairEngine32 {
     }
     // the registers of a piece that starts at application f0 / ends before application f1 of its chain <-> the FFT's region of the
     // LDS image (natural order; PADDED: element p at p + (p >> 4), the no-reorder image of the tile copies)
+    // (lane 1's negation where a piece starts or ends on an odd application is a flip of the SIGN BIT, not a product with -1: the
+    //  README benchmark's 100 un-normalised applications overflow to infinities and NaNs half way, and a cut chain must still
+    //  end with the bits of an uncut one -- flipping twice restores any bit pattern, multiplying a NaN twice need not)
+    __device__ static __forceinline__ float negate_bits(float v, unsigned flip) { return __uint_as_float(__float_as_uint(v) ^ flip); }
     static constexpr bool kPadded = !REORDER;
     __device__ static __forceinline__ int image(int p) { return p + (kPadded ? (p >> G::kPadShift) : 0); }
     __device__ __forceinline__ void load(float2 (&r)[16], const float2* sf, int f0) const {
@@ -856,11 +860,11 @@ struct PairEngine32 {
 #pragma unroll
             for (int c = 0; c < 16; ++c) r[c] = sf[image(u + 2 * c)];
         } else {
-            const float m = odd ? s_plain : 1.f;
+            const unsigned flip = (odd && u) ? 0x80000000u : 0u;
 #pragma unroll
             for (int n = 0; n < 16; ++n) {
                 const float2 v = sf[image(n + 16 * u)];
-                r[n] = make_float2(m * v.x, m * v.y);
+                r[n] = make_float2(negate_bits(v.x, flip), negate_bits(v.y, flip));
             }
         }
     }
@@ -870,9 +874,9 @@ struct PairEngine32 {
 #pragma unroll
             for (int c = 0; c < 16; ++c) sf[image(u + 2 * c)] = r[c];
         } else {
-            const float m = odd ? s_plain : 1.f;
+            const unsigned flip = (odd && u) ? 0x80000000u : 0u;
 #pragma unroll
-            for (int n = 0; n < 16; ++n) sf[image(n + 16 * u)] = make_float2(m * r[n].x, m * r[n].y);
+            for (int n = 0; n < 16; ++n) sf[image(n + 16 * u)] = make_float2(negate_bits(r[n].x, flip), negate_bits(r[n].y, flip));
         }
     }
 };

@@ -161,6 +161,37 @@ def test_ct_multiple_balanced_schedule_is_bit_identical(sm, n, inv, reo):
         sm.lib.smfft_set_multiple_balance(-1)
 
 
+def test_n32_hundred_applications_return_the_input_times_n_to_the_50(sm):
+    """The README count on data that stay finite (scaled by 2^-125: N^50 = 2^250 fits fp32 only for N = 32; with the harness's U[0,1)
+    data every word of a 100-application result is a NaN, which compares equal whatever happened): F^4 = N^2 I, so a hundred forward
+    natural-order transforms return x * 32^50 -- a size-independent check of the pair engine's alternating layouts at the README
+    batch's chain length, cut chains with odd and even cuts included; and the balanced schedule has the bits of one chain per
+    workgroup there too."""
+    n, reuses = 32, 100
+    ntiles = 61
+    nffts = (ntiles * 32 - 5) * 100
+    slots = _slots(n, nffts)
+    rng = np.random.default_rng(3232)
+    x = (((rng.random((nffts, n), dtype=np.float32) - 0.5) + 1j * (rng.random((nffts, n), dtype=np.float32) - 0.5)) * np.ldexp(np.float32(1), -125)).astype(np.complex64)
+    try:
+        sm.lib.smfft_set_nreuses(reuses)
+        sm.lib.smfft_set_multiple_balance(0)
+        want = sm.c2c(x, False, True, path="multiple")
+        assert np.isfinite(want[:slots].view(np.float32)).all()
+        ref_out = x[:slots].astype(np.complex128) * 2.0 ** 250
+        err = np.linalg.norm(want[:slots] - ref_out) / np.linalg.norm(ref_out)
+        assert err <= 5e-6, err
+        for g in (-1, 7, 11):
+            sm.lib.smfft_set_multiple_balance(g)
+            got = sm.c2c(x, False, True, path="multiple")
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), g
+        cuts = _cut_chains(ntiles, reuses, 7) + _cut_chains(ntiles, reuses, 11)
+        assert any(k % 2 for _, k in cuts) and any(k % 2 == 0 for _, k in cuts)
+    finally:
+        sm.lib.smfft_set_nreuses(0)
+        sm.lib.smfft_set_multiple_balance(-1)
+
+
 def _cut_chains(ntiles, reuses, g):
     """chains a balanced launch over g workgroups cuts, with the application they are cut at (smfft_inst.hip, launch_compact)"""
     total = ntiles * reuses

@@ -22,13 +22,21 @@ stream = ctypes.c_void_p()
 assert hip.hipStreamCreate(ctypes.byref(stream)) == 0
 checked = 0
 takeovers = 0
+finite_words = words = 0
 for n in (32, 64, 128, 256, 512, 1024, 2048, 4096):
     nffts = total // n
     slots = nffts // 400 * 4 if n == 32 else nffts // 200 * 2 if n == 64 else nffts // 100
-    x = ((rng.random((slots, n), dtype=np.float32) - 0.5) + 1j * (rng.random((slots, n), dtype=np.float32) - 0.5)).astype(np.complex64)
+    # Data scaled by 2^-125 and, beside the README count of 100, the largest even count whose N^(count/2) keeps them finite (100 itself
+    # for N = 32; fp32 has 277 binades, N^50 needs 300 ... 600 for N >= 64): a result full of NaNs -- which is what every word of a
+    # 100-application run was in rounds 4-5 -- compares equal whatever happened.  Words that are NaN on both sides count as equal
+    # whatever their sign bit (N = 32 keeps lane 1 negated between applications: which of two NaNs an addition returns depends on
+    # the operand order the compiler chose in that copy of the loop body); finite words and infinities are compared bit for bit.
+    lg = int(np.log2(n))
+    finite_count = min(100, (248 // lg) // 2 * 2)
+    x = (((rng.random((slots, n), dtype=np.float32) - 0.5) + 1j * (rng.random((slots, n), dtype=np.float32) - 0.5)) * np.ldexp(np.float32(1.0), -125)).astype(np.complex64)
     din, dout = sm.DeviceBuffer.from_host(x), sm.DeviceBuffer(x.nbytes)
     for reo in (1, 0):
-        for reuses in (4, 100):
+        for reuses in sorted({4, finite_count, 100}):
             sm.lib.smfft_set_nreuses(reuses)
             sm.lib.smfft_set_multiple_balance(0)
             sm.lib.smfft_memset(dout.ptr, 0xFF, x.nbytes)
@@ -48,12 +56,15 @@ for n in (32, 64, 128, 256, 512, 1024, 2048, 4096):
                 sm.launch("ct", "multiple", din.ptr, dout.ptr, n, nffts, False, bool(reo))      # back to back: same tiles, other workgroups' L1s warm
                 assert sm.lib.smfft_synchronize() == 0
                 got = dout.to_host(np.uint32, (x.nbytes // 4,))
-                bad = np.flatnonzero(got != want)
+                bad = np.flatnonzero((got != want) & ~(np.isnan(got.view(np.float32)) & np.isnan(want.view(np.float32))))
                 assert bad.size == 0, (n, reo, reuses, r, loaded, bad.size, int(bad[0]))
+                finite_words += int(np.count_nonzero(np.isfinite(want.view(np.float32))))
+                words += want.size
                 sm.lib.smfft_set_handoff_wait_us(-1)
                 checked += 1
     din.free()
     dout.free()
     print(f"N={n}: ok", flush=True)
 sm.lib.smfft_set_nreuses(0)
-print(f"{checked} pairs of README-batch launches on the balanced schedule (idle chip / competing kernel / impatient resumers): every word has the bits of one chain per workgroup")
+print(f"{checked} pairs of README-batch launches on the balanced schedule (idle chip / competing kernel / impatient resumers): every word has the bits of one chain per workgroup "
+      f"({finite_words / words:.0%} of the {words:.3e} words compared are finite; NaN against NaN counts as equal)")
