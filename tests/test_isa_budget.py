@@ -78,7 +78,7 @@ def built():
     with ThreadPoolExecutor(max_workers=4) as ex:
         futs = {n: ex.submit(_resources, n) for n in (256, 1024, 2048)}
         isa = ex.submit(_example_isa)
-        inst = {n: ex.submit(_inst_isa, n) for n in (2048, 4096)}
+        inst = {n: ex.submit(_inst_isa, n) for n in (32, 2048, 4096)}
         return {"res": {n: f.result() for n, f in futs.items()}, "isa": isa.result(), "inst": {n: f.result() for n, f in inst.items()}}
 
 
@@ -136,3 +136,47 @@ def test_reference_shaped_multiple_loop_barriers_at_4096(built):
     isa = built["isa"]
     assert _loop_barriers(isa, "SMFFT_DIT_multipleI16FFT_4096_forwardE", "SMFFT_DIT_multiple<FFT_4096_forward>") <= 5
     assert _loop_barriers(isa, "SMFFT_DIT_multipleI26FFT_4096_forward_noreorderE", "SMFFT_DIT_multiple<FFT_4096_forward_noreorder>") <= 3
+
+
+def _loops(body):
+    """(first, last) line of every loop of a kernel body: a label that a later conditional branch jumps back to"""
+    labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    out = []
+    for i, l in enumerate(body):
+        m = re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            out.append((labels[m.group(1)], i))
+    return out
+
+
+def test_n32_applications_stay_in_registers(built):
+    """N = 32 in the in-LDS path (PairEngine32): the loop over two applications holds the two fused cross stages --
+    64 v_fmac_f32_dpp -- and no LDS instruction, no barrier, no scratch access: the image in LDS is touched where a piece starts
+    and ends only"""
+    isa = built["inst"][32]
+    for frag in ("SMFFT_DIT_multipleI14FFT_32_forwardE", "SMFFT_DIT_multipleI24FFT_32_forward_noreorderE", "SMFFT_DIT_multipleI14FFT_32_inverseE"):
+        m = re.search(r"^(_Z\w*%s\w*):[^\n]*\n(.*?)\n\s*s_endpgm" % frag, isa, re.S | re.M)
+        assert m, frag
+        body = m.group(2).split("\n")
+        pair = [(a, b) for a, b in _loops(body) if sum("v_fmac_f32_dpp" in l for l in body[a:b + 1]) == 64]
+        assert pair, frag
+        a, b = min(pair, key=lambda ab: ab[1] - ab[0])
+        loop = [l.strip() for l in body[a:b + 1] if l.strip() and not l.strip().startswith((";", "."))]
+        assert not any(l.startswith(("ds_", "s_barrier", "scratch_", "global_", "buffer_")) for l in loop), [l for l in loop if l.startswith(("ds_", "s_barrier", "scratch_", "global_", "buffer_"))][:4]
+        valu = sum(l.startswith("v_") and "dpp" not in l for l in loop)
+        assert valu <= 2 * 240, (frag, valu)          # 216 (natural order) / 233 (no reorder) per application
+
+
+def test_reference_shaped_multiple_loop_keeps_its_twiddles(built):
+    """SMFFT_DIT_multiple<P> in the reference's shape: the twiddles of do_SMFFT_CT_DIT are fetched in front of its first
+    synchronisation, so the loop of NREUSES calls holds no global load for the lengths that keep them (N = 256 ... 1024; N = 2048 keeps
+    all but its last pass) -- DESIGN.md 2.3, CT:553-572"""
+    isa = built["isa"]
+    for frag, allowed in (("SMFFT_DIT_multipleI15FFT_256_forwardE", 0), ("SMFFT_DIT_multipleI16FFT_1024_forwardE", 0), ("SMFFT_DIT_multipleI26FFT_1024_forward_noreorderE", 0),
+                          ("SMFFT_DIT_multipleI16FFT_2048_forwardE", 1)):
+        m = re.search(r"^(_Z\w*%s\w*):[^\n]*\n(.*?)\n\s*s_endpgm" % frag, isa, re.S | re.M)
+        assert m, frag
+        body = m.group(2).split("\n")
+        a, b = max(_loops(body), key=lambda ab: ab[1] - ab[0])
+        loads = sum("global_load" in l for l in body[a:b + 1])
+        assert loads <= allowed, (frag, loads)
