@@ -359,14 +359,10 @@ struct Engine {
     static constexpr int E_BITS = ilog2c(N), T_BITS = ilog2c(T), R1_BITS = ilog2c(R1), B1_BITS = ilog2c(B1);
 
     // physical lane bit of thread bit i of a register-two-pass FFT: i + kLaneShift -- the top log2(T) bits of the position inside a
-    // 16-lane row (row-DPP transposes).  (N = 32 with its two threads in neighbouring 16-lane rows instead -- lane bit 4, one
-    // v_permlane16_swap per dword pair where the row form takes two v_mov_b32_dpp and a copy: 125 against 210 SIMD cycles by the
-    // microbenchmark of the forms, profiles/r02_valu_forms.txt -- measured 8-10 % SLOWER in the in-LDS kernel: the swaps do not
-    // overlap with the other waves' arithmetic the way the DPP moves do; profiles/r05_ab_n32_permlane.txt.  kLaneShift = 4 builds it.)
+    // 16-lane row (row-DPP transposes).  (These transposes serve the external kernels of N = 32 / 64 and the no-reorder bit reversal;
+    // the in-LDS path of N = 32, whose cost they were, runs on PairEngine32 below since round 5.  What was measured on them there --
+    // neighbouring rows + v_permlane16_swap -8...-10 %, ds_swizzle + selects -20 % -- is in profiles/HISTORY.md.)
     static constexpr int kLaneShift = !G::kRegTwoPass ? 0 : 4 - T_BITS;
-    // (N = 32's one exchange through the LDS crossbar instead -- ds_swizzle lane ^ 8 of both registers of a pair and a select per
-    //  dword, 32 selects where the row-DPP form spends 32 moves at 5.4 cycles and 17 copies -- measured 20 % SLOWER in the in-LDS
-    //  kernel with the swizzles consumed four at a time, and with all of them in flight the kernel spills: profiles/r05_ab_n32_swizzle.txt)
 
     int u;        // thread inside the FFT
     int fft;      // FFT inside the workgroup
