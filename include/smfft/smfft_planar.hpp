@@ -464,7 +464,10 @@ struct PlanarEngine {
                                   0.92387953251128674f, 0.98078528040323043f};
         const float* p = planes + off_partner;
         float2 w = herm_w;
-        asm volatile("" : "+v"(w.x), "+v"(w.y));     // the seven products W_2L^i are recomputed per application
+        // The seven products W_2L^i = herm_w * W_32^q are loop invariant: L <= 512 keeps them (14 registers: 108 / 112 -> 122 / 126 of
+        // the 128 that four waves per SIMD allow; R2C / C2R of real N = 512 / 1024 -2.5...-3 %, profiles/r05_ab_rc_keep.txt), the longer
+        // lengths have no room and recompute them per application behind an opaque copy of herm_w.
+        if constexpr (N > 512) asm volatile("" : "+v"(w.x), "+v"(w.y));
         float2 other[8];
         const float2 r8 = r[8];
 #pragma unroll
