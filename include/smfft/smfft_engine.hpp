@@ -85,6 +85,12 @@ constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n >> 1); }
 __device__ __forceinline__ float2 cmul(float2 a, float2 w) {
     return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
 }
+// the same product with its rounding WRITTEN DOWN (one rounded product, one fused multiply-add per component): two inlined copies of
+// cmul need not round alike -- the compiler contracts a*b - c*d either way round -- and the lane engines below run the same source
+// in several copies whose results must agree to the bit
+__device__ __forceinline__ float2 cmul_fixed(float2 a, float2 w) {
+    return make_float2(__builtin_fmaf(a.x, w.x, -(a.y * w.y)), __builtin_fmaf(a.x, w.y, a.y * w.x));
+}
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
@@ -246,7 +252,7 @@ __device__ __forceinline__ void lds_read16(float2 (&r)[16], const float2* base) 
 // Small in-register DFTs (R = 2, 4, 8, 16), decimation in time on compile-time indices.
 // in[k*STRIDE], k < R  ->  out[q], q < R (natural order).  DIR = 0: e^{-2 pi i/R}, 1: e^{+}.
 // ------------------------------------------------------------------------------------------------
-template <int IDX16, int DIR>
+template <int IDX16, int DIR, bool FIXED = false>
 __device__ __forceinline__ float2 mul_w16(float2 a) {
     // multiplies by W_16^IDX16 (IDX16 in [0,8)); conjugate for DIR = 1
     constexpr float c1 = 0.92387953251128673848f, s1 = 0.38268343236508978178f, h = 0.70710678118654752440f;
@@ -258,16 +264,18 @@ __device__ __forceinline__ float2 mul_w16(float2 a) {
         constexpr float wr = (IDX16 == 1) ? c1 : (IDX16 == 3) ? s1 : (IDX16 == 5) ? -s1 : -c1;
         constexpr float wi_f = (IDX16 == 1) ? -s1 : (IDX16 == 3) ? -c1 : (IDX16 == 5) ? -c1 : -s1;
         constexpr float wi = DIR ? -wi_f : wi_f;
-        return make_float2(a.x * wr - a.y * wi, a.x * wi + a.y * wr);
+        if constexpr (FIXED) return make_float2(__builtin_fmaf(a.x, wr, -(a.y * wi)), __builtin_fmaf(a.x, wi, a.y * wr));     // (cmul_fixed's reason)
+        else return make_float2(a.x * wr - a.y * wi, a.x * wi + a.y * wr);
     }
 }
 
-template <int R, int STRIDE, int DIR, bool TAN = true>
+template <int R, int STRIDE, int DIR, bool TAN = true, bool FIXED = false>
 struct SmallDft {
+    static_assert(!(TAN && FIXED), "the tangent form is fused multiply-adds throughout: nothing to fix");
     __device__ static __forceinline__ void run(const float2* in, float2* out) {
         float2 e[R / 2], o[R / 2];
-        SmallDft<R / 2, 2 * STRIDE, DIR, TAN>::run(in, e);
-        SmallDft<R / 2, 2 * STRIDE, DIR, TAN>::run(in + STRIDE, o);
+        SmallDft<R / 2, 2 * STRIDE, DIR, TAN, FIXED>::run(in, e);
+        SmallDft<R / 2, 2 * STRIDE, DIR, TAN, FIXED>::run(in + STRIDE, o);
         combine<0>(e, o, out);
     }
     template <int K>
@@ -288,7 +296,7 @@ struct SmallDft {
                 out[K] = make_float2(fmaf(wr, ux, e[K].x), fmaf(wr, uy, e[K].y));
                 out[K + R / 2] = make_float2(fmaf(-wr, ux, e[K].x), fmaf(-wr, uy, e[K].y));
             } else {
-                float2 t = mul_w16<IDX, DIR>(o[K]);
+                float2 t = mul_w16<IDX, DIR, FIXED>(o[K]);
                 out[K] = cadd(e[K], t);
                 out[K + R / 2] = csub(e[K], t);
             }
@@ -296,8 +304,8 @@ struct SmallDft {
         }
     }
 };
-template <int STRIDE, int DIR, bool TAN>
-struct SmallDft<1, STRIDE, DIR, TAN> {
+template <int STRIDE, int DIR, bool TAN, bool FIXED>
+struct SmallDft<1, STRIDE, DIR, TAN, FIXED> {
     __device__ static __forceinline__ void run(const float2* in, float2* out) { out[0] = in[0]; }
 };
 
@@ -810,9 +818,9 @@ struct PairEngine32 {
     // lane 1's results are negated in the first case, plain in the second)
     __device__ __forceinline__ void dit(float2 (&r)[16], float s) const {
         float2 y[16];
-        SmallDft<16, 1, DIR, false>::run(r, y);
+        SmallDft<16, 1, DIR, false, true>::run(r, y);
 #pragma unroll
-        for (int q = 1; q < 16; ++q) y[q] = cmul(y[q], tw[q]);
+        for (int q = 1; q < 16; ++q) y[q] = cmul_fixed(y[q], tw[q]);
         cross(y, s);
 #pragma unroll
         for (int q = 0; q < 16; ++q) r[q] = y[q];
@@ -821,9 +829,9 @@ struct PairEngine32 {
     __device__ __forceinline__ void dif(float2 (&r)[16], float s) const {
         cross(r, s);
 #pragma unroll
-        for (int n = 1; n < 16; ++n) r[n] = cmul(r[n], tw[n]);
+        for (int n = 1; n < 16; ++n) r[n] = cmul_fixed(r[n], tw[n]);
         float2 y[16];
-        SmallDft<16, 1, DIR, false>::run(r, y);
+        SmallDft<16, 1, DIR, false, true>::run(r, y);
 #pragma unroll
         for (int k = 0; k < 16; ++k) r[k] = y[k];
     }
@@ -874,6 +882,120 @@ struct PairEngine32 {
 #pragma unroll
             for (int n = 0; n < 16; ++n) sf[image(n + 16 * u)] = make_float2(negate_bits(r[n].x, flip), negate_bits(r[n].y, flip));
         }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// N = 64 WITHOUT reorder in the in-LDS path, the same way: the FFT is a QUAD of lanes (j = 0 ... 3, a DPP quad) with sixteen registers
+// each, and the radix-4 stage across the quad is two fused stages of v_fmac_f32_dpp (partner j ^ 2, then j ^ 1) with a turn by -+i in
+// lane 3 between them.  No reorder only: S2 transforms x o bitrev, and bitrev(j + 4c) = 16 rev2(j) + rev4(c) makes the input of lane
+// j (role t1 = j: x'[j + 4c]) the contiguous block rev2(j) of the stored array with its registers renamed -- while the in-place radix-2
+// network over the two lane bits leaves output block k in the lane rev2(k): lane j holds block rev2(j) before and after, for ever.
+//     Z_j = DFT16(x'[j + 4c]) . W_64^(j q)
+//     stage 1 (j ^ 2):  a = Z_0 + Z_2 (lane 0), b = Z_0 - Z_2 (lane 2), c = Z_1 + Z_3 (lane 1), d = Z_1 - Z_3 (lane 3);  lane 3: d <- -+i d
+//     stage 2 (j ^ 1):  X[q] = a + c (lane 0), X[q + 32] = a - c (lane 1), X[q + 16] = b + d (lane 2), X[q + 48] = b - d (lane 3)
+// Signs as in PairEngine32: own + s * partner's own cannot negate `own`, so a lane that wants "partner - own" ends negated.  From plain
+// inputs, s1 = (+, +, -, -) and s2 = (+, -, +, -) leave the lanes (+, -, -, +); from inputs in that state the NEGATED sign vectors leave
+// them plain: the state alternates with the application's number in the chain, nothing is negated in the loop, and a piece that starts
+// or ends on an odd application flips the sign bits of lanes 1 and 2 where it loads / stores.  The natural-order variant stays on the
+// planar engine (one LDS exchange per application there; this form would take a dit / dif pair like N = 32 and prices the same);
+// the no-reorder one spent its time on the LDS unit (two exchanges per application, 89 % busy: DESIGN.md 5.2) and has none left.
+// ------------------------------------------------------------------------------------------------
+template <int DIR>
+struct QuadEngine64 {
+    static constexpr int N = 64;
+    using G = Geometry<N>;
+    int j, fft;
+    float s1, s2;             // the sign vectors of an application whose inputs are plain; negated for one whose lanes 1 and 2 are
+    bool turns;               // lane 3
+    unsigned flip;            // the sign bit, in lanes 1 and 2
+    float2 tw[16];            // W_64^(j q)
+
+    __device__ __forceinline__ void init(int tid) {
+        const int lane = tid & 63;
+        j = lane & 3;
+        fft = (tid >> 6) * 16 + (lane >> 2);
+        s1 = (j & 2) ? -1.f : 1.f;
+        s2 = (j & 1) ? -1.f : 1.f;
+        turns = j == 3;
+        flip = (j == 1 || j == 2) ? 0x80000000u : 0u;
+#pragma unroll
+        for (int q = 1; q < 16; ++q) tw[q] = twiddle<DIR>(j * q * (4096 / N));
+    }
+    // r[i] <- r[i] + s * (partner's r[i]), both dwords of sixteen registers; PARTNER: 2 = lane ^ 2, 1 = lane ^ 1
+    template <int PARTNER>
+    __device__ static __forceinline__ void cross(float2 (&r)[16], float s) {
+#define SMFFT_QUAD8(B, CTL)                                                                                              \
+        asm volatile("s_nop 1\n\t"                                                                                       \
+                     "v_fmac_f32_dpp %0, %0, %16 " CTL " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                     "v_fmac_f32_dpp %1, %1, %16 " CTL " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                     "v_fmac_f32_dpp %2, %2, %16 " CTL " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                     "v_fmac_f32_dpp %3, %3, %16 " CTL " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                     "v_fmac_f32_dpp %4, %4, %16 " CTL " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                     "v_fmac_f32_dpp %5, %5, %16 " CTL " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                     "v_fmac_f32_dpp %6, %6, %16 " CTL " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                     "v_fmac_f32_dpp %7, %7, %16 " CTL " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                     "v_fmac_f32_dpp %8, %8, %16 " CTL " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                     "v_fmac_f32_dpp %9, %9, %16 " CTL " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                     "v_fmac_f32_dpp %10, %10, %16 " CTL " row_mask:0xf bank_mask:0xf\n\t"                                \
+                     "v_fmac_f32_dpp %11, %11, %16 " CTL " row_mask:0xf bank_mask:0xf\n\t"                                \
+                     "v_fmac_f32_dpp %12, %12, %16 " CTL " row_mask:0xf bank_mask:0xf\n\t"                                \
+                     "v_fmac_f32_dpp %13, %13, %16 " CTL " row_mask:0xf bank_mask:0xf\n\t"                                \
+                     "v_fmac_f32_dpp %14, %14, %16 " CTL " row_mask:0xf bank_mask:0xf\n\t"                                \
+                     "v_fmac_f32_dpp %15, %15, %16 " CTL " row_mask:0xf bank_mask:0xf"                                     \
+                     : "+v"(r[B].x), "+v"(r[B].y), "+v"(r[B + 1].x), "+v"(r[B + 1].y), "+v"(r[B + 2].x), "+v"(r[B + 2].y),          \
+                       "+v"(r[B + 3].x), "+v"(r[B + 3].y), "+v"(r[B + 4].x), "+v"(r[B + 4].y), "+v"(r[B + 5].x), "+v"(r[B + 5].y),  \
+                       "+v"(r[B + 6].x), "+v"(r[B + 6].y), "+v"(r[B + 7].x), "+v"(r[B + 7].y)                                       \
+                     : "v"(s))
+        if constexpr (PARTNER == 2) {
+            SMFFT_QUAD8(0, "quad_perm:[2,3,0,1]");
+            SMFFT_QUAD8(8, "quad_perm:[2,3,0,1]");
+        } else {
+            SMFFT_QUAD8(0, "quad_perm:[1,0,3,2]");
+            SMFFT_QUAD8(8, "quad_perm:[1,0,3,2]");
+        }
+#undef SMFFT_QUAD8
+    }
+    // lane 3: d <- -+i d (forward: (d.y, -d.x); inverse: (-d.y, d.x)), the other lanes unchanged: two selects per value (hipcc: v_cndmask_b32_e64
+    // on an SGPR mask with the negation as a source modifier).  The same with v_swap_b32 under an EXEC mask of the lanes 3 and the sign
+    // as a product measured 10 % SLOWER per launch (profiles/r05_quad64.txt).  That the turn cannot be folded into twiddles, signs or a
+    // swapped / conjugated representation of some lanes is a parity argument: DESIGN.md 2.1a.
+    __device__ __forceinline__ void turn(float2 (&y)[16]) const {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float2 d = y[q];
+            y[q] = turns ? (DIR ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x)) : d;
+        }
+    }
+    // one application, number f of its chain; r[i] = (the lane's sign) * stored element 16 rev2(j) + i, before and after
+    __device__ __forceinline__ void apply(float2 (&r)[16], bool odd) const {
+        float2 x[16], y[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) x[c] = r[((c & 1) << 3) | ((c & 2) << 1) | ((c & 4) >> 1) | ((c & 8) >> 3)];     // x'[j + 4c]
+        SmallDft<16, 1, DIR, false, true>::run(x, y);
+#pragma unroll
+        for (int q = 1; q < 16; ++q) y[q] = cmul_fixed(y[q], tw[q]);
+        cross<2>(y, odd ? -s1 : s1);
+        turn(y);
+        cross<1>(y, odd ? -s2 : s2);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) r[q] = y[q];
+    }
+    // the registers of a piece that starts at application f0 / ends before application f1 of its chain <-> the FFT's region of the
+    // padded LDS image of the tile copies (element p at p + (p >> 4))
+    __device__ __forceinline__ int block_base() const { return 17 * (((j & 1) << 1) | (j >> 1)); }      // 16 rev2(j), padded
+    __device__ __forceinline__ void load(float2 (&r)[16], const float2* sf, int f0) const {
+        const unsigned m = (f0 & 1) ? flip : 0u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float2 v = sf[block_base() + i];
+            r[i] = make_float2(__uint_as_float(__float_as_uint(v.x) ^ m), __uint_as_float(__float_as_uint(v.y) ^ m));
+        }
+    }
+    __device__ __forceinline__ void store(const float2 (&r)[16], float2* sf, int f1) const {
+        const unsigned m = (f1 & 1) ? flip : 0u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sf[block_base() + i] = make_float2(__uint_as_float(__float_as_uint(r[i].x) ^ m), __uint_as_float(__float_as_uint(r[i].y) ^ m));
     }
 };
 

@@ -426,8 +426,14 @@ struct Piece {
     __device__ __forceinline__ bool resumed() const { return app0 > 0; }
 };
 
-// C2C, multiple, N = 32 (CT:553-572): the first nSlots FFTs are loaded once, transformed nreuses (= NREUSES = 100 in the benchmark; a
-// kernel argument so the tests can run 1, 2 and 4 applications) times, stored once.  An FFT is a pair of lanes and lives in their
+// the engines whose transforms live on lanes and registers alone (smfft_engine.hpp): N = 32 (a pair of lanes), N = 64 without reorder (a quad)
+template <int N, int DIR, int REORDER> struct LaneEngine;
+template <int DIR, int REORDER> struct LaneEngine<32, DIR, REORDER> { using type = PairEngine32<DIR, REORDER>; };
+template <int DIR> struct LaneEngine<64, DIR, 0> { using type = QuadEngine64<DIR>; };
+constexpr bool on_lanes(int n, int reorder) { return n == 32 || (n == 64 && !reorder); }
+
+// C2C, multiple, N = 32 and N = 64 without reorder (CT:553-572): the first nSlots FFTs are loaded once, transformed nreuses (= NREUSES = 100 in the benchmark; a
+// kernel argument so the tests can run 1, 2 and 4 applications) times, stored once.  An FFT is a pair (N = 64: a quad) of lanes and lives in their
 // registers from the first application of a piece to its last (PairEngine32, smfft_engine.hpp: the stage across the pair is one
 // DPP-fed v_fmac_f32 per dword, the layout alternates instead of being restored); the image in LDS -- natural order, padded for
 // the no-reorder variants as the tile copies have it -- is touched where a piece starts and ends.  (Rounds 2-4 ran this length on
@@ -437,10 +443,10 @@ struct Piece {
 // (d_input / d_output are not __restrict__ here: a resumed piece READS the tile another workgroup of this launch parked in d_output)
 template <int N, int DIR, int REORDER>
 __device__ __forceinline__ void c2c_multiple_body(const float2* d_input, float2* d_output, int nSlots, int nreuses, MultipleSchedule sch, float2* s) {
-    static_assert(N == 32, "the planar engine takes every longer length");
+    static_assert(N == 32 || (N == 64 && !REORDER), "the planar engine takes everything else");
     using G = Geometry<N>;
     constexpr bool kPaddedImage = !REORDER;
-    PairEngine32<DIR, REORDER> eng;
+    typename LaneEngine<N, DIR, REORDER>::type eng;
     eng.init(threadIdx.x);
     float2* sf = s + eng.fft * G::SF;
     const int ntiles = (nSlots + G::kCompactFfts - 1) / G::kCompactFfts;
@@ -458,8 +464,10 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* d_input, float2*
         else tile_to_lds<N, kPaddedImage>(d_input + first * N, s, first, nSlots);
         fft_sync<G::kMultiWave>();
         trace_piece(sch.trace, k, 0);
-        // The applications run on the pair's registers alone (PairEngine32): the image in LDS is read where the piece starts and
-        // written where it ends.  An application's form follows from its number in the chain, so the loop is unrolled by two.
+        // The applications run on the lanes' registers alone: the image in LDS is read where the piece starts and written where it
+        // ends.  An application's form follows from its number in the chain, so the loop is unrolled by two -- which puts several
+        // inlined copies of the same source into the kernel; their arithmetic is written with its rounding fixed (cmul_fixed,
+        // SmallDft<..., FIXED>), or a chain cut on an odd application would not end with the bits of an uncut one.
         float2 r[16];
         eng.load(r, sf, piece.app0);
         int f = piece.app0;
@@ -855,7 +863,7 @@ constexpr int compact_lds_floats(int needed) { return (N <= 1024 && needed * 4 <
 template <class const_params>
 __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_size) SMFFT_DIT_multiple(const float2* d_input, float2* d_output, int nSlots, int nreuses, smfft::MultipleSchedule sch) {
     constexpr int N = const_params::fft_size;
-    if constexpr (N >= smfft::kPlanarMinN) {
+    if constexpr (!smfft::on_lanes(N, const_params::fft_reorder)) {
         __shared__ __attribute__((aligned(16))) float s_planes[smfft::compact_lds_floats<N>(smfft::PlanarGeometry<N, const_params::fft_reorder>::kLdsFloats)];
         smfft::c2c_multiple_body_planar<N, const_params::fft_direction, const_params::fft_reorder>(d_input, d_output, nSlots, nreuses, sch, s_planes);
     } else {

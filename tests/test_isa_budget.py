@@ -78,7 +78,7 @@ def built():
     with ThreadPoolExecutor(max_workers=4) as ex:
         futs = {n: ex.submit(_resources, n) for n in (256, 1024, 2048)}
         isa = ex.submit(_example_isa)
-        inst = {n: ex.submit(_inst_isa, n) for n in (32, 2048, 4096)}
+        inst = {n: ex.submit(_inst_isa, n) for n in (32, 64, 2048, 4096)}
         return {"res": {n: f.result() for n, f in futs.items()}, "isa": isa.result(), "inst": {n: f.result() for n, f in inst.items()}}
 
 
@@ -149,22 +149,23 @@ def _loops(body):
     return out
 
 
-def test_n32_applications_stay_in_registers(built):
-    """N = 32 in the in-LDS path (PairEngine32): the loop over two applications holds the two fused cross stages --
-    64 v_fmac_f32_dpp -- and no LDS instruction, no barrier, no scratch access: the image in LDS is touched where a piece starts
-    and ends only"""
-    isa = built["inst"][32]
-    for frag in ("SMFFT_DIT_multipleI14FFT_32_forwardE", "SMFFT_DIT_multipleI24FFT_32_forward_noreorderE", "SMFFT_DIT_multipleI14FFT_32_inverseE"):
+def test_lane_engine_applications_stay_in_registers(built):
+    """N = 32 and N = 64 without reorder in the in-LDS path (PairEngine32 / QuadEngine64): the loop over two applications
+    holds the fused cross stages -- 64 / 128 v_fmac_f32_dpp -- and no LDS instruction, no barrier, no scratch access: the image in LDS is touched where a piece starts and ends
+    only"""
+    for n, frag, fused in ((32, "SMFFT_DIT_multipleI14FFT_32_forwardE", 64), (32, "SMFFT_DIT_multipleI24FFT_32_forward_noreorderE", 64), (32, "SMFFT_DIT_multipleI14FFT_32_inverseE", 64),
+                           (64, "SMFFT_DIT_multipleI24FFT_64_forward_noreorderE", 128), (64, "SMFFT_DIT_multipleI24FFT_64_inverse_noreorderE", 128)):
+        isa = built["inst"][n]
         m = re.search(r"^(_Z\w*%s\w*):[^\n]*\n(.*?)\n\s*s_endpgm" % frag, isa, re.S | re.M)
         assert m, frag
         body = m.group(2).split("\n")
-        pair = [(a, b) for a, b in _loops(body) if sum("v_fmac_f32_dpp" in l for l in body[a:b + 1]) == 64]
+        pair = [(a, b) for a, b in _loops(body) if sum("v_fmac_f32_dpp" in l for l in body[a:b + 1]) == fused]
         assert pair, frag
         a, b = min(pair, key=lambda ab: ab[1] - ab[0])
         loop = [l.strip() for l in body[a:b + 1] if l.strip() and not l.strip().startswith((";", "."))]
         assert not any(l.startswith(("ds_", "s_barrier", "scratch_", "global_", "buffer_")) for l in loop), [l for l in loop if l.startswith(("ds_", "s_barrier", "scratch_", "global_", "buffer_"))][:4]
         valu = sum(l.startswith("v_") and "dpp" not in l for l in loop)
-        assert valu <= 2 * 240, (frag, valu)          # 216 (natural order) / 233 (no reorder) per application
+        assert valu <= 2 * (240 if n == 32 else 265), (frag, valu)          # N = 32: 216 (natural order) / 233 (no reorder) per application; N = 64: 249
 
 
 def test_reference_shaped_multiple_loop_keeps_its_twiddles(built):

@@ -18,9 +18,11 @@ ncases = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 rng = np.random.default_rng(seed0)
 MAXB = 48 << 20
 din, dout = sm.DeviceBuffer(MAXB), sm.DeviceBuffer(MAXB)
-host = (rng.random(MAXB // 4, dtype=np.float32) - 0.5).astype(np.float32)
+# scaled by 2^-100 so that N^(NREUSES/2) stays finite for most of the cases drawn (a result full of NaNs compares equal whatever happened)
+host = ((rng.random(MAXB // 4, dtype=np.float32) - 0.5) * np.ldexp(np.float32(1.0), -100)).astype(np.float32)
 sm.lib.smfft_memcpy_h2d(din.ptr, host.ctypes.data, MAXB)
 tally = {}
+finite_words = words = 0
 for case in range(ncases):
     prog = ("ct_reorder", "ct_noreorder", "ct_unfused", "st", "r2c", "c2r")[int(rng.integers(0, 6))]
     if prog in ("r2c", "c2r"):
@@ -55,9 +57,15 @@ for case in range(ncases):
         for rot in (1, 0):
             sm.lib.smfft_set_multiple_rotation(rot)
             got = run()
-            assert np.array_equal(got, want), (case, prog, n, nffts, reuses, g, rot, int(np.flatnonzero(got != want)[0]))
+            # (NaN against NaN counts as equal whatever the sign bit: the lane engines of N = 32 / 64 keep some lanes negated between
+            #  applications, and which of two NaNs an addition returns depends on the operand order of that copy of the loop body)
+            bad = np.flatnonzero((got != want) & ~(np.isnan(got.view(np.float32)) & np.isnan(want.view(np.float32))))
+            assert bad.size == 0, (case, prog, n, nffts, reuses, g, rot, bad.size, int(bad[0]))
+    written = want != 0xFFFFFFFF                      # (the launch writes the first nFFTs / 100 slots; the rest keeps the fill)
+    finite_words += int(np.count_nonzero(np.isfinite(want.view(np.float32)[written])))
+    words += int(np.count_nonzero(written))
     sm.lib.smfft_set_multiple_rotation(-1)
     tally[prog] = tally.get(prog, 0) + 1
 sm.lib.smfft_set_nreuses(0)
 sm.lib.smfft_set_multiple_balance(-1)
-print(f"{ncases} random in-LDS launches from seed {seed0}, each on 3 balanced grids x rotation on / off: bit-identical to one chain per workgroup; {tally}")
+print(f"{ncases} random in-LDS launches from seed {seed0}, each on 3 balanced grids x rotation on / off: bit-identical to one chain per workgroup ({finite_words / words:.0%} of the words the launches wrote are finite); {tally}")
