@@ -87,7 +87,8 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 w) {
 }
 // the same product with its rounding WRITTEN DOWN (one rounded product, one fused multiply-add per component): two inlined copies of
 // cmul need not round alike -- the compiler contracts a*b - c*d either way round -- and the lane engines below run the same source
-// in several copies whose results must agree to the bit
+// in several copies whose results must agree to the bit (their radix-16 transform is the tangent form of SmallDft, which is explicit
+// fused multiply-adds throughout; SmallDft<..., false, FIXED> is the same remedy for the plain form)
 __device__ __forceinline__ float2 cmul_fixed(float2 a, float2 w) {
     return make_float2(__builtin_fmaf(a.x, w.x, -(a.y * w.y)), __builtin_fmaf(a.x, w.y, a.y * w.x));
 }
@@ -286,8 +287,8 @@ struct SmallDft {
                 // e +- W*o with W = wr * (1 + i*tn): two multiply-adds for u = o * (1 + i*tn), four for e +- wr*u -- six
                 // instructions where product, sum and difference take eight (the odd powers of W_16 only: the others are
                 // cheaper still as they are).  16 instructions fewer per N = 1024 FFT; in-LDS path N >= 256 +0.5-2.5 %,
-                // N = 32 / 64 1-7 % SLOWER (their register-transposed kernels schedule worse with it): TAN = false there
-                // (profiles/r02_ab_tan.txt)
+                // N = 32 / 64 1-7 % SLOWER on the general engine (their register-transposed kernels schedule worse with it): TAN = false
+                // there (profiles/r02_ab_tan.txt); the lane engines of round 5 take it: +2...+4 % (profiles/r05_quad64.txt)
                 constexpr float c1 = 0.92387953251128673848f, s1 = 0.38268343236508978178f;
                 constexpr float wr = (IDX == 1) ? c1 : (IDX == 3) ? s1 : (IDX == 5) ? -s1 : -c1;
                 constexpr float wi_f = (IDX == 1) ? -s1 : (IDX == 3) ? -c1 : (IDX == 5) ? -c1 : -s1;
@@ -818,7 +819,7 @@ struct PairEngine32 {
     // lane 1's results are negated in the first case, plain in the second)
     __device__ __forceinline__ void dit(float2 (&r)[16], float s) const {
         float2 y[16];
-        SmallDft<16, 1, DIR, false, true>::run(r, y);
+        SmallDft<16, 1, DIR, true>::run(r, y);
 #pragma unroll
         for (int q = 1; q < 16; ++q) y[q] = cmul_fixed(y[q], tw[q]);
         cross(y, s);
@@ -831,7 +832,7 @@ struct PairEngine32 {
 #pragma unroll
         for (int n = 1; n < 16; ++n) r[n] = cmul_fixed(r[n], tw[n]);
         float2 y[16];
-        SmallDft<16, 1, DIR, false, true>::run(r, y);
+        SmallDft<16, 1, DIR, true>::run(r, y);
 #pragma unroll
         for (int k = 0; k < 16; ++k) r[k] = y[k];
     }
@@ -972,7 +973,7 @@ struct QuadEngine64 {
         float2 x[16], y[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) x[c] = r[((c & 1) << 3) | ((c & 2) << 1) | ((c & 4) >> 1) | ((c & 8) >> 3)];     // x'[j + 4c]
-        SmallDft<16, 1, DIR, false, true>::run(x, y);
+        SmallDft<16, 1, DIR, true>::run(x, y);
 #pragma unroll
         for (int q = 1; q < 16; ++q) y[q] = cmul_fixed(y[q], tw[q]);
         cross<2>(y, odd ? -s1 : s1);
