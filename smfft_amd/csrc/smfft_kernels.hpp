@@ -8,7 +8,7 @@
 // The EXTERNAL kernels use 256-thread workgroups that own a tile of 4096 float2 (= 4096/N FFTs) and
 // P::fft_sm_required = 4352 float2 of LDS (34 KiB -> 4 workgroups = 16 waves per CU), on the float2 engine
 // (smfft_engine.hpp).  The IN-LDS (`multiple`) kernels use compact workgroups (one wave per 1024 elements, one FFT per
-// workgroup above) on the planar engine (smfft_planar.hpp; N = 32: the pair engine of smfft_engine.hpp).  For
+// workgroup above) on the planar engine (smfft_planar.hpp; N = 32 and N = 64 without reorder: the lane engines of smfft_engine.hpp).  For
 // N >= 256 the external kernels do not stage through LDS on the way in or out: pass 1 loads
 // straight from global memory into registers (each wave instruction reads 512 contiguous bytes
 // for N >= 1024) and the last pass stores straight from registers, so the only LDS traffic is the
