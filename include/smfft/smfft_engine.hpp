@@ -788,7 +788,18 @@ struct PairEngine32 {
     }
     // r[i] <- r[i] + s * (partner's r[i]), i = 0 .. 15 (both dwords): two blocks of sixteen v_fmac_f32_dpp
     // (s_nop 1: the two wait states a DPP read needs after a VALU write of the same register)
+    // The last SWZ of the sixteen values take the other road to the partner: ds_swizzle (lane ^ 8 through the LDS crossbar, no memory
+    // access) + a plain v_fmac_f32 -- 2.3 vector cycles per dword instead of the fused form's 4.5, paid for on the otherwise idle LDS
+    // pipe and in registers for the values in flight.  Measured (profiles/r05_lane_swizzle.txt): eight of sixteen in the dif form
+    // +6 % (all sixteen +5 %, with spills), in the no-reorder dit +4 %; in the natural-order dit 0...+2 %: none there.
+    template <int SWZ>
     __device__ static __forceinline__ void cross(float2 (&r)[16], float s) {
+#pragma unroll
+        for (int q = 16 - SWZ; q < 16; ++q) {
+            const float px = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(r[q].x), 0x201F));     // bit mode: and 0x1f, or 0, xor 8
+            const float py = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(r[q].y), 0x201F));
+            r[q] = make_float2(__builtin_fmaf(px, s, r[q].x), __builtin_fmaf(py, s, r[q].y));
+        }
 #define SMFFT_FUSED8(B)                                                                                                  \
         asm volatile("s_nop 1\n\t"                                                                                       \
                      "v_fmac_f32_dpp %0, %0, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                               \
@@ -812,7 +823,7 @@ struct PairEngine32 {
                        "+v"(r[B + 6].x), "+v"(r[B + 6].y), "+v"(r[B + 7].x), "+v"(r[B + 7].y)                                       \
                      : "v"(s))
         SMFFT_FUSED8(0);
-        SMFFT_FUSED8(8);
+        if constexpr (SWZ < 8) SMFFT_FUSED8(8);
 #undef SMFFT_FUSED8
     }
     // layout A -> layout B: r[c] = x[u + 2c] -> r[q] = X[q + 16u]   (s: s_plain for plain inputs, -s_plain for a negated lane 1;
@@ -822,13 +833,13 @@ struct PairEngine32 {
         SmallDft<16, 1, DIR, true>::run(r, y);
 #pragma unroll
         for (int q = 1; q < 16; ++q) y[q] = cmul_fixed(y[q], tw[q]);
-        cross(y, s);
+        cross<REORDER ? 0 : 8>(y, s);
 #pragma unroll
         for (int q = 0; q < 16; ++q) r[q] = y[q];
     }
     // layout B -> layout A: r[n] = x[n + 16u] -> r[k] = X[u + 2k]   (same convention for s; the results are plain when lane 1's inputs were negated)
     __device__ __forceinline__ void dif(float2 (&r)[16], float s) const {
-        cross(r, s);
+        cross<8>(r, s);
 #pragma unroll
         for (int n = 1; n < 16; ++n) r[n] = cmul_fixed(r[n], tw[n]);
         float2 y[16];
@@ -976,7 +987,16 @@ struct QuadEngine64 {
         SmallDft<16, 1, DIR, true>::run(x, y);
 #pragma unroll
         for (int q = 1; q < 16; ++q) y[q] = cmul_fixed(y[q], tw[q]);
-        cross<2>(y, odd ? -s1 : s1);
+        {   // stage 1 through the LDS crossbar (ds_swizzle, quad_perm [2,3,0,1]) + plain v_fmac_f32: it follows the twiddle products, which
+            // cover its latency; +6 % against the fused form there.  Stage 2 the same way +4 %, both +1.5 %: the crossbar carries one.
+            const float s = odd ? -s1 : s1;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float px = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(y[q].x), 0x804E));
+                const float py = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(y[q].y), 0x804E));
+                y[q] = make_float2(__builtin_fmaf(px, s, y[q].x), __builtin_fmaf(py, s, y[q].y));
+            }
+        }
         turn(y);
         cross<1>(y, odd ? -s2 : s2);
 #pragma unroll
