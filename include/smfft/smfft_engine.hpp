@@ -765,7 +765,7 @@ __device__ __forceinline__ void fft_lds_inplace(float2* s, const Engine<N, DIR, 
 // s = (-1, +1) and comes out plain (both dit and dif are linear in lane 1's registers), so nothing is ever negated in the
 // loop -- only where a piece of a chain starts or ends on an odd application (load / store flip lane 1's sign bits there).  Which form an
 // application takes depends on its index in the CHAIN only, so a chain cut between two workgroups computes the same bits.
-// Per application: 128 (radix 16) + 60 (fifteen twiddles) + 32 fused = 220 instructions, no LDS access, no exchange.
+// Per application: 140 (radix 16, tangent form) + 60 (fifteen twiddles) + 32 for the stage across the pair, no LDS memory access.
 // ------------------------------------------------------------------------------------------------
 template <int DIR, int REORDER>
 struct PairEngine32 {
@@ -899,8 +899,8 @@ struct PairEngine32 {
 
 // ------------------------------------------------------------------------------------------------
 // N = 64 WITHOUT reorder in the in-LDS path, the same way: the FFT is a QUAD of lanes (j = 0 ... 3, a DPP quad) with sixteen registers
-// each, and the radix-4 stage across the quad is two fused stages of v_fmac_f32_dpp (partner j ^ 2, then j ^ 1) with a turn by -+i in
-// lane 3 between them.  No reorder only: S2 transforms x o bitrev, and bitrev(j + 4c) = 16 rev2(j) + rev4(c) makes the input of lane
+// each, and the radix-4 stage across the quad is two fused stages -- own <- own + s * partner's own, partner j ^ 2 through the LDS
+// crossbar (ds_swizzle + v_fmac_f32), then partner j ^ 1 through DPP (v_fmac_f32_dpp) -- with a turn by -+i in lane 3 between them.  No reorder only: S2 transforms x o bitrev, and bitrev(j + 4c) = 16 rev2(j) + rev4(c) makes the input of lane
 // j (role t1 = j: x'[j + 4c]) the contiguous block rev2(j) of the stored array with its registers renamed -- while the in-place radix-2
 // network over the two lane bits leaves output block k in the lane rev2(k): lane j holds block rev2(j) before and after, for ever.
 //     Z_j = DFT16(x'[j + 4c]) . W_64^(j q)
@@ -934,9 +934,9 @@ struct QuadEngine64 {
 #pragma unroll
         for (int q = 1; q < 16; ++q) tw[q] = twiddle<DIR>(j * q * (4096 / N));
     }
-    // r[i] <- r[i] + s * (partner's r[i]), both dwords of sixteen registers; PARTNER: 2 = lane ^ 2, 1 = lane ^ 1
-    template <int PARTNER>
-    __device__ static __forceinline__ void cross(float2 (&r)[16], float s) {
+    // stage 2: r[i] <- r[i] + s * (lane ^ 1's r[i]), both dwords of sixteen registers, as DPP-fed v_fmac_f32 (stage 1 goes through the
+    // LDS crossbar: apply)
+    __device__ static __forceinline__ void cross_neighbour(float2 (&r)[16], float s) {
 #define SMFFT_QUAD8(B, CTL)                                                                                              \
         asm volatile("s_nop 1\n\t"                                                                                       \
                      "v_fmac_f32_dpp %0, %0, %16 " CTL " row_mask:0xf bank_mask:0xf\n\t"                                  \
@@ -959,13 +959,8 @@ struct QuadEngine64 {
                        "+v"(r[B + 3].x), "+v"(r[B + 3].y), "+v"(r[B + 4].x), "+v"(r[B + 4].y), "+v"(r[B + 5].x), "+v"(r[B + 5].y),  \
                        "+v"(r[B + 6].x), "+v"(r[B + 6].y), "+v"(r[B + 7].x), "+v"(r[B + 7].y)                                       \
                      : "v"(s))
-        if constexpr (PARTNER == 2) {
-            SMFFT_QUAD8(0, "quad_perm:[2,3,0,1]");
-            SMFFT_QUAD8(8, "quad_perm:[2,3,0,1]");
-        } else {
-            SMFFT_QUAD8(0, "quad_perm:[1,0,3,2]");
-            SMFFT_QUAD8(8, "quad_perm:[1,0,3,2]");
-        }
+        SMFFT_QUAD8(0, "quad_perm:[1,0,3,2]");
+        SMFFT_QUAD8(8, "quad_perm:[1,0,3,2]");
 #undef SMFFT_QUAD8
     }
     // lane 3: d <- -+i d (forward: (d.y, -d.x); inverse: (-d.y, d.x)), the other lanes unchanged: two selects per value (hipcc: v_cndmask_b32_e64
@@ -998,7 +993,7 @@ struct QuadEngine64 {
             }
         }
         turn(y);
-        cross<1>(y, odd ? -s2 : s2);
+        cross_neighbour(y, odd ? -s2 : s2);
 #pragma unroll
         for (int q = 0; q < 16; ++q) r[q] = y[q];
     }
