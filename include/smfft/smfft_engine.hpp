@@ -767,6 +767,24 @@ __device__ __forceinline__ void fft_lds_inplace(float2* s, const Engine<N, DIR, 
 // application takes depends on its index in the CHAIN only, so a chain cut between two workgroups computes the same bits.
 // Per application: 140 (radix 16, tangent form) + 60 (fifteen twiddles) + 32 for the stage across the pair, no LDS memory access.
 // ------------------------------------------------------------------------------------------------
+// W_N^m, m < N, as ONE row (N = 32 / 64: 256 / 512 bytes): picked out of twiddle_4096 the lane engines' fifteen twiddles per lane lie
+// 128 / 64 entries apart -- a cache line each, 15 ... 45 lines per wave at the start of every workgroup (the quad engine's workgroups
+// reached their first tile 3 us later than the planar kernel's: profiles/r05_trace_summary.txt (c)).  Same values, same rounding.
+template <int N>
+struct LaneTwiddleRow {
+    TwiddleValue w[N];
+    constexpr LaneTwiddleRow() : w{} {
+        for (int m = 0; m < N; ++m) w[m] = twiddle_values[m * (4096 / N)];
+    }
+};
+template <int N>
+static __device__ const LaneTwiddleRow<N> lane_twiddle_row = LaneTwiddleRow<N>();
+template <int N, int DIR>
+__device__ __forceinline__ float2 lane_twiddle(int m) {
+    const TwiddleValue v = lane_twiddle_row<N>.w[m & (N - 1)];
+    return make_float2(v.x, DIR ? -v.y : v.y);
+}
+
 template <int DIR, int REORDER>
 struct PairEngine32 {
     static constexpr int N = 32;
@@ -782,7 +800,7 @@ struct PairEngine32 {
         s_plain = u ? -1.f : 1.f;
 #pragma unroll
         for (int n = 1; n < 16; ++n) {
-            const float2 w = twiddle<DIR>(n * (4096 / N));
+            const float2 w = lane_twiddle<N, DIR>(n);
             tw[n] = u ? w : make_float2(1.f, 0.f);
         }
     }
@@ -932,7 +950,7 @@ struct QuadEngine64 {
         turns = j == 3;
         flip = (j == 1 || j == 2) ? 0x80000000u : 0u;
 #pragma unroll
-        for (int q = 1; q < 16; ++q) tw[q] = twiddle<DIR>(j * q * (4096 / N));
+        for (int q = 1; q < 16; ++q) tw[q] = lane_twiddle<N, DIR>(j * q);
     }
     // stage 2: r[i] <- r[i] + s * (lane ^ 1's r[i]), both dwords of sixteen registers, as DPP-fed v_fmac_f32 (stage 1 goes through the
     // LDS crossbar: apply)
