@@ -132,6 +132,31 @@ def test_ct_multiple_k_applications(sm, oracle_lib, n, inv, reo, reuses):
     assert l2 <= 5e-7 * reuses ** 0.5 and mx <= 1e-6 * reuses ** 0.5, (l2, mx)
 
 
+@pytest.mark.parametrize("n,reuses", [(32, 39), (32, 40), (64, 39), (64, 40), (256, 27)])
+@pytest.mark.parametrize("inv,reo", [(0, 1), (0, 0), (1, 0)])
+def test_ct_multiple_long_chains_against_the_oracle(sm, oracle_lib, n, inv, reo, reuses):
+    """Chains of 27 ... 40 applications -- as long as fp32 holds N^(k/2) on data scaled by 2^-100 -- on the product schedule (61 tiles over the
+    chip: chains cut on odd and even applications) against k applications of the fp64 oracle: the lane engines of N = 32 / 64 alternate
+    their layouts and sign vectors with the application's number in the chain (odd and even k end in different states); N = 256 is a
+    planar kernel for comparison."""
+    tile_ffts = max(1, 1024 // n)
+    nffts = (61 * tile_ffts - tile_ffts // 2) * 100
+    slots = _slots(n, nffts)
+    rng = np.random.default_rng(6100 + n + reuses + 2 * inv + reo)
+    x = (((rng.random((nffts, n), dtype=np.float32) - 0.5) + 1j * (rng.random((nffts, n), dtype=np.float32) - 0.5)) * np.ldexp(np.float32(1), -100)).astype(np.complex64)
+    sm.lib.smfft_set_nreuses(reuses)
+    try:
+        got = sm.c2c(x, bool(inv), bool(reo), path="multiple")
+    finally:
+        sm.lib.smfft_set_nreuses(0)
+    assert np.isfinite(got[:slots].view(np.float32)).all()
+    want = x[:slots].astype(np.complex128)
+    for _ in range(reuses):
+        want = oa.ct_c2c(oracle_lib, want, inv, reo, "f64")
+    l2, mx = ref.fft_errors(got[:slots], want)
+    assert l2 <= 5e-7 * reuses ** 0.5 and mx <= 1e-6 * reuses ** 0.5, (l2, mx)
+
+
 @pytest.mark.parametrize("n", C2C_SIZES)
 @pytest.mark.parametrize("inv,reo", [(0, 1), (0, 0), (1, 0)])
 def test_ct_multiple_balanced_schedule_is_bit_identical(sm, n, inv, reo):
