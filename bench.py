@@ -237,6 +237,11 @@ def _minmax(values):
     return [min(vals), max(vals)] if vals else None
 
 
+def _r3(v):
+    return round(v, 3) if isinstance(v, float) and v == v and abs(v) != float("inf") else (v if isinstance(v, int) else None)
+
+
+LENGTHS = ("32", "64", "128", "256", "512", "1024", "2048", "4096")
 COMPACT_LIMIT = 4096      # bytes: the driver's parser lost round 3's 22.6 KB line
 REQUIRED_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                  "dtype", "data", "config", "roofline", "cpu_baseline", "pair_search", "comm_backend", "ranks_seen", "spot_check_relL2")
@@ -270,7 +275,15 @@ def compact_line(detail):
         # without cross-application fusion) next to the fused compact kernel
         "in_lds_1024_contract_FFTps": _minmax([_get(cref, "ct_multiple_reorder", "FFT/s"), _get(cref, "ct_multiple_noreorder", "FFT/s")]),
         "in_lds_1024_unfused_FFTps": _get(c3, "1024", "reorder", "unfused", "FFT/s"),
-        "config3_unfused_frac": _minmax([_get(c3, k, "reorder", "unfused", "frac_fp32_peak") for k in c3]),
+        "config3_unfused_frac": _minmax([_get(c3, k, o, "unfused", "frac_fp32_peak") for k in c3 for o in ("reorder", "noreorder")]),
+        # one row per length 32, 64, ..., 4096: [fused loop natural order, no reorder, one image trip per application natural order, no reorder]
+        # (fraction of the fp32 peak) and [natural order, no reorder] of the reference's contract over the compact kernel
+        "config3_by_length_frac": [[_r3(_get(c3, k, "reorder", "frac_fp32_peak")), _r3(_get(c3, k, "noreorder", "frac_fp32_peak")),
+                                    _r3(_get(c3, k, "reorder", "unfused", "frac_fp32_peak")), _r3(_get(c3, k, "noreorder", "unfused", "frac_fp32_peak"))] for k in LENGTHS if k in c3],
+        "contract_in_lds_ratio_by_length": [[_r3(_get(by_len, k, "reorder", "in_lds_ratio_to_compact")), _r3(_get(by_len, k, "noreorder", "in_lds_ratio_to_compact"))] for k in LENGTHS if k in by_len],
+        # FFT -> .H -> IFFT of the config-2 batch inside one user kernel: [reference contract, its register form, register-level engine]
+        "convolution_ms": [_get(cref, "convolution_1024", k, "ms") for k in ("contract", "contract_registers", "register_engine")],
+        "convolution_frac_hbm": [_get(cref, "convolution_1024", k, "frac") for k in ("contract", "contract_registers", "register_engine")],
         "config3_old_schedule_frac": _minmax([_get(c3, k, "reorder", "one_chain_per_workgroup_oldest_first", "frac_fp32_peak") for k in c3]),
         "in_lds_1024_fused_FFTps": _minmax([_get(c3, "1024", "reorder", "FFT/s"), _get(c3, "1024", "noreorder", "FFT/s")]),
         "config3_frac_fp32_peak": _minmax([_get(c3, k, o, "frac_fp32_peak") for k in c3 for o in ("reorder", "noreorder")]),
@@ -313,7 +326,14 @@ def compact_line(detail):
     line = _sig(line)
     text = json.dumps(line, allow_nan=False, separators=(",", ":"))
     if len(text) >= COMPACT_LIMIT:          # never again an unparseable line: drop the optional parts, largest first
-        for k in ("summary", "per_rank", "roofline_own_input", "multiple_path_FFTps"):
+        for k in ("roofline_own_input", "pair_search_detail", "per_rank", "summary", "multiple_path_FFTps"):
+            if k == "pair_search_detail":       # keep the verdicts, drop the figures of every allocation attempt
+                line["pair_search"] = [{"good_enough": a.get("good_enough"), "classification": a.get("classification"), "copy_ms": a.get("copy_ms"),
+                                        "chunks": a.get("chunks"), "seconds": a.get("seconds"), "kept": a.get("kept")} for a in (line.get("pair_search") or [])]
+                text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+                if len(text) < COMPACT_LIMIT:
+                    break
+                continue
             line[k] = None
             text = json.dumps(line, allow_nan=False, separators=(",", ":"))
             if len(text) < COMPACT_LIMIT:
@@ -372,21 +392,34 @@ def main():
     backend = os.environ.get("SMFFT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
+    group = None            # the process group of the barriers and reductions: RCCL's, or None = the default (gloo) group
     if world > 1:
+        import datetime
+
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # The default group is gloo on every rank (CPU, TCP to the launcher's store: nothing of the GPUs can keep it from coming up);
+        # RCCL is a second group on top, and whether it is used is decided ONCE for all ranks over the first
+        # (smfft_amd/sharding.py, agree_on_fast_group) -- never per rank.  Both groups carry timeouts: a rank that never arrives
+        # ends the job with an error.  SMFFT_BENCH_REQUIRE_RCCL=1: no gloo fallback at all (exit code 3).
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
         if backend == "nccl":
-            try:
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-                dist.barrier()          # first collective: RCCL over xGMI is really up
-            except Exception as e:      # the timings can still be reduced on the CPU
-                print(f"[bench] RCCL unavailable ({type(e).__name__}: {e}); reducing timings over gloo", file=sys.stderr)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
+            from smfft_amd.sharding import agree_on_fast_group
+
+            def rccl_group():
+                g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300))
+                probe = torch.ones(1, device=torch.device("cuda", local_rank))
+                dist.all_reduce(probe, group=g)          # first collective: RCCL over xGMI is really up
+                torch.cuda.synchronize(local_rank)
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"RCCL all-reduce returned {probe.item()} for {world} ranks")
+                return g
+            group, rccl_error = agree_on_fast_group(dist, rccl_group)
+            if group is None:
+                print(f"[bench] rank {rank}: RCCL not used by any rank ({rccl_error or 'another rank could not bring it up'}); timings reduced over gloo", file=sys.stderr)
+                if os.environ.get("SMFFT_BENCH_REQUIRE_RCCL", "0") not in ("", "0"):
+                    raise SystemExit(3)
                 backend = "gloo"
-                dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend=backend)
 
     import smfft_amd as sm  # raises if libsmfft_amd.so is missing
 
@@ -457,7 +490,10 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            if group is not None:
+                dist.barrier(group=group, device_ids=[local_rank])
+            else:
+                dist.barrier()
 
     def run_timed(i_ptr, o_ptr, contract):
         """pre-warm, W warm-up steps, K timed steps; returns (wall seconds, average kernel ms from stream events).
@@ -503,8 +539,8 @@ def main():
     assert err < 5e-7, f"timed output failed the spot check: relL2={err}"
 
     from smfft_amd.sharding import gather_stats, reduce_stats
-    wall_max, kernel_ms_max, ranks_seen = reduce_stats(dist, stats_dev, wall, kernel_ms, 1)
-    plain_wall_max, plain_kernel_ms_max, _ = reduce_stats(dist, stats_dev, plain_wall, plain_kernel_ms)
+    wall_max, kernel_ms_max, ranks_seen = reduce_stats(dist, stats_dev, wall, kernel_ms, 1, group=group)
+    plain_wall_max, plain_kernel_ms_max, _ = reduce_stats(dist, stats_dev, plain_wall, plain_kernel_ms, group=group)
 
     # same-run copy ceiling: the kernel's own access shape without the FFT (outside the timed region)
     def copy_ms(i_ptr, o_ptr):
@@ -520,7 +556,7 @@ def main():
     pair_copy_ms = copy_ms(pa.value, pb.value)
     # every rank's own outcome, so that a straggler (a rank whose allocator scan found no good output) shows in the line:
     # `value` = world * nffts / max_g(t_g) is hostage to the slowest rank, sum_g(nffts / t_g) is what the ranks did separately
-    rows = gather_stats(dist, stats_dev, [wall, kernel_ms, float(pair_info["good_enough"]), pair_copy_ms, float(len(pair_attempts))])
+    rows = gather_stats(dist, stats_dev, [wall, kernel_ms, float(pair_info["good_enough"]), pair_copy_ms, float(len(pair_attempts))], group=group)
     per_rank = {"wall_ms_per_step": [r[0] / args.steps * 1e3 for r in rows], "kernel_ms": [r[1] for r in rows],
                 "good_enough": [int(r[2]) for r in rows], "copy_ms": [r[3] for r in rows], "attempts": [int(r[4]) for r in rows]}
     value_sum_of_rates = sum(nffts / (r[0] / args.steps) for r in rows)
@@ -581,7 +617,7 @@ def main():
     mult = {}
     for reo in (0, 1):
         mult[reo] = median_ms(lambda t, reo=reo: sm.lib.smfft_ct_multiple_benchmark(pa.value, pb.value, n, nffts, 0, reo, t), settle_ms=SETTLE)
-    nr_max, re_max, _ = reduce_stats(dist, stats_dev, mult[0], mult[1])
+    nr_max, re_max, _ = reduce_stats(dist, stats_dev, mult[0], mult[1], group=group)
     mult = {k: {"ms": ms, "FFT/s": world * (nffts // 100) * 100 / (ms * 1e-3), "ms_is": "median of 11 launches after 40 ms of untimed ones (settled clocks), max over ranks", "n_gpus": world}
             for k, ms in (("noreorder", nr_max), ("reorder", re_max))}
 
@@ -612,9 +648,15 @@ def main():
             sm.lib.smfft_set_multiple_balance(-1)
             sm.lib.smfft_set_multiple_rotation(-1)
             row["reorder"]["one_chain_per_workgroup_oldest_first"] = {"ms": ms_old, "frac_fp32_peak": done * 5 * fn_n * math.log2(fn_n) / (ms_old * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
-            if fn_n >= 64:
-                ms_unf = median_ms(lambda t: sm.lib.smfft_ct_multiple_unfused_benchmark(pa.value, pb.value, fn_n, bn, 0, t), reps=7, settle_ms=SETTLE)
-                row["reorder"]["unfused"] = {"ms": ms_unf, "FFT/s": done / (ms_unf * 1e-3), "frac_fp32_peak": done * 5 * fn_n * math.log2(fn_n) / (ms_unf * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
+            # `unfused` = one image load + one image store per application (smfft_ct_multiple_percall_benchmark): the natural-order planar
+            # kernels, and the lane engines of N = 32 (both orderings) and N = 64 without reorder, whose fused loop touches no LDS memory
+            # between a chain's first and last application; the planar no-reorder kernels re-read the image as they are (unfused = fused)
+            for name, reo in (("reorder", 1), ("noreorder", 0)):
+                if reo == 0 and fn_n >= 128:
+                    row[name]["unfused"] = {k: row[name][k] for k in ("ms", "FFT/s", "frac_fp32_peak")}
+                    continue
+                ms_unf = median_ms(lambda t, reo=reo: sm.lib.smfft_ct_multiple_percall_benchmark(pa.value, pb.value, fn_n, bn, 0, reo, t), reps=7, settle_ms=SETTLE)
+                row[name]["unfused"] = {"ms": ms_unf, "FFT/s": done / (ms_unf * 1e-3), "frac_fp32_peak": done * 5 * fn_n * math.log2(fn_n) / (ms_unf * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
             c3[str(fn_n)] = row
         # config 4: real N = 2048, 262144 FFTs (2 GiB of reals <-> 2 GiB packed spectrum) -- and the other three real lengths
         # at the same byte count; first halves of the pair for R2C, second halves for C2R
@@ -741,6 +783,24 @@ def main():
                                                "in_lds_FFT/s": blocks64 * per64 * 100 / (msm64 * 1e-3), "in_lds_ratio_to_compact": compact64 / msm64}
                 by_len[str(fn_n)] = row
             cref["by_length"] = by_len
+            # The one APPLICATION of the product (reference README.md:10-18: "expected to be called within a GPU kernel"): batched circular
+            # convolution y = IFFT(FFT(x) . H) / N of the config-2 batch inside ONE user kernel, three ways -- a user's kernel on the
+            # reference's contract (blockDim = N/4, do_SMFFT_CT_DIT forward, a product in shared memory, do_SMFFT_CT_DIT inverse), the
+            # same thread shape on the register form of those functions, and the library's register-level engine -- on the pair of
+            # `roofline`; fraction of the HBM peak of input + output (examples/reference_shape_kernel.hip, examples/fft_convolution.hip)
+            import numpy as np
+            hspec = np.zeros(n, np.complex128)
+            hspec[:5] = [0.4, 0.3, 0.2, 0.1, -0.05j]
+            H = sm.DeviceBuffer.from_host(np.fft.fft(hspec).astype(np.complex64))
+            conv = {}
+            for key, sym in (("contract", "smfft_example_reference_shape_convolve_1024"), ("contract_registers", "smfft_example_reference_shape_convolve_1024_registers"),
+                             ("register_engine", "smfft_example_convolve_1024_registers")):
+                fn = getattr(ex, sym)
+                fn.argtypes = [vp, vp, vp, ci, vp]
+                ms = event_ms(lambda fn=fn: fn(pa.value, H.ptr, pb.value, nffts, sh), reps=9, settle_launches=8)
+                conv[key] = {"ms": ms, "TB/s": gb / ms, "frac": gb / ms * 1e3 / HBM_PEAK_GBPS}
+            H.free()
+            cref["convolution_1024"] = conv
         except (OSError, AttributeError) as e:
             cref = {"error": repr(e)}
         configs = {"timing": "median of 11 (7 where many cases) event-timed launches after 3 warm-ups, buffers of `roofline`; the in-LDS (multiple) figures after a further 40 ms of untimed launches (clocks settled, profiles/r03_warm_ramp.txt), HBM-bound figures that follow in-LDS ones after 15 ms of untimed launches",

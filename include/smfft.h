@@ -44,8 +44,14 @@ int smfft_ct_multiple_benchmark(const void* d_input, void* d_output, int FFT_siz
                                 int inverse, int reorder, double* FFT_time);
 /* The same benchmark on the natural-order compact kernel WITHOUT cross-application fusion: every one of the NREUSES applications
  * reads its input from the LDS image and leaves its output there -- what one call of do_SMFFT_CT_DIT costs a kernel whose data
- * live in LDS (CT:553-572).  N = 32 and the no-reorder variants have no fused form: use smfft_ct_multiple_benchmark. */
+ * live in LDS (CT:553-572). */
 int smfft_ct_multiple_unfused_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, int inverse, double* FFT_time);
+/* ... and for either ordering (round 6).  The kernels that keep a chain in registers across its applications -- the natural-order
+ * planar kernels (N >= 64) and the lane engines of N = 32 and of N = 64 without reorder, which touch no LDS memory between a chain's
+ * first and last application -- run with one image load and one image store per application, the shape of upstream's own loop
+ * (CT:553-572); the planar no-reorder kernels (N >= 128) re-read the image in every application as they are, so for them this IS
+ * smfft_ct_multiple_benchmark. */
+int smfft_ct_multiple_percall_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, int inverse, int reorder, double* FFT_time);
 
 /* ---- Stockham C2C family (un-normalised INVERSE transform, ST:76), N = 32 .. 4096 ------------
  * (upstream: 256 .. 4096; the smaller lengths are an extension) */
@@ -206,12 +212,9 @@ int smfft_get_multiple_rotation(void);
    SMFFT_HANDOFF_WAIT_US; THIS host thread) for data nobody has committed to parking runs the whole chain itself from d_input -- same
    bits -- and the late owner skips it.  So a launch finishes whatever else occupies the device; < 0: back to the process default. */
 void smfft_set_handoff_wait_us(int microseconds);
-/* Fault injection for the tests of that path (THIS host thread): in the next balanced launches the workgroup that parks chain `chain`
-   sleeps `milliseconds` before it commits to parking (after_commit = 0: the resumer takes the chain over) or between its commit and
-   the parked word (1: the resumer waits for the store it has been promised).  milliseconds <= 0: off. */
-void smfft_debug_delay_parking(int chain, int milliseconds, int after_commit);
-/* Introspection: buffers of hand-over words the library holds (one per balanced launch in flight, recycled by event; at most 32,
-   128 KiB each) and, in *in_flight, how many of them a launch is still using. */
+/* (fault injection for the tests of that path: include/smfft_debug.h)
+   Introspection: buffers of hand-over words the library holds (one per balanced launch in flight, recycled by event; at most 32,
+   256 KiB each -- 65536 chains x one word) and, in *in_flight, how many of them a launch is still using. */
 int smfft_schedule_buffers(int* in_flight);
 /* How many workgroups of a multiple kernel the device holds at once, COUNTED by a calibration launch over scratch buffers (family 0
    CT / 1 Stockham, path 1 or 2); *assumed = what the balanced schedule computes from the kernel's registers and LDS.  < 0: error. */

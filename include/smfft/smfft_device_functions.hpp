@@ -160,15 +160,19 @@ constexpr int quarter_late_passes(int n, bool reorder) {
     const int passes = ilog2c(n) / 2;
     return n >= 4096 ? (reorder ? passes : 4) : n >= 2048 ? 1 : n <= 128 ? passes : 0;
 }
-template <int N, int DIR, int REORDER>
+// KEEP_ALL (round 6): no late pass whatever the length.  The phased form of N = 2048 / 4096 (quarter_fft, kLastPhase) needs 56 / 64
+// registers with every twiddle kept -- still eight waves per SIMD -- and a late pass's global load sits right behind the one barrier
+// of its last phase, on the critical path of sixteen waves: kept, N = 4096 runs 13 ... 15 % faster in the in-LDS loop, N = 2048 1 ... 4 %
+// (profiles/r06_contract_phases.txt).  The round-5 form (OUT_REGS at these lengths) keeps its late passes.
+template <int N, int DIR, int REORDER, bool KEEP_ALL = false>
 struct QuarterTwiddles {
     using R = QuarterTwiddleRows<N>;
-    static constexpr int kLatePasses = quarter_late_passes(N, REORDER != 0);
+    static constexpr int kLatePasses = KEEP_ALL ? 0 : quarter_late_passes(N, REORDER != 0);
     static constexpr bool kRowSelects = N < 1024;      // how the wave-local ladder of THIS length swaps lane bits 2 / 3 (slots_swap)
     static constexpr bool late(int p) { return p >= R::kPasses - kLatePasses; }
     QuadTwiddle q[R::kPasses > 1 ? R::kPasses : 1];    // q[p], p = 1 .. kPasses - 1 (P = 4^p)
     float2 wr;                                         // the radix-2 pass of an odd log2 N
-    int kbase;
+    int kbase, kbase_high;                             // butterfly index of the passes with P <= 64 / of the passes above (the last phase of N >= 2048 numbers its threads differently)
     __device__ static __forceinline__ QuadTwiddle fetch(int p, int k) {
         const TwiddleValue tv = quarter_twiddle_rows<N>.w[R::row_start(p) + k];
         QuadTwiddle t;
@@ -177,12 +181,15 @@ struct QuarterTwiddles {
         t.w3 = late(p) ? t.w2 : cmul(t.w1, t.w2);      // (a late pass takes the two-stage butterfly: no third product)
         return t;
     }
-    // kb: the thread's butterfly index (k = kb mod P in every pass); r: its index in the radix-2 row
-    __device__ __forceinline__ void load(int kb, int r) {
+    // kb: the thread's butterfly index (k = kb mod P in every pass); r: its index in the radix-2 row; kb_high: the index for the passes with
+    // P >= 256 where it differs (quarter_fft's last phase)
+    __device__ __forceinline__ void load(int kb, int r) { load(kb, r, kb); }
+    __device__ __forceinline__ void load(int kb, int r, int kb_high) {
         kbase = kb;
+        kbase_high = kb_high;
 #pragma unroll
         for (int p = 1; p < R::kPasses; ++p)
-            if (!late(p)) q[p] = fetch(p, kb & ((1 << (2 * p)) - 1));
+            if (!late(p)) q[p] = fetch(p, (p >= 4 ? kb_high : kb) & ((1 << (2 * p)) - 1));
         if constexpr (R::kOdd) {
             const TwiddleValue tv = quarter_twiddle_rows<N>.w[R::row_start(R::kPasses) + r];
             wr = make_float2(tv.x, DIR ? -tv.y : tv.y);
@@ -190,7 +197,7 @@ struct QuarterTwiddles {
     }
     // the twiddles of pass `pass`, at the pass (pass: a constant where this is called -- a template argument or the counter of an unrolled loop)
     __device__ __forceinline__ QuadTwiddle of(int pass) const {
-        return late(pass) ? fetch(pass, kbase & ((1 << (2 * pass)) - 1)) : q[pass];
+        return late(pass) ? fetch(pass, (pass >= 4 ? kbase_high : kbase) & ((1 << (2 * pass)) - 1)) : q[pass];
     }
 };
 // the fused radix-2^2 butterfly on (x0, x1, x2, x3) = elements k, k + P, k + 2P, k + 3P; results in place
@@ -224,6 +231,13 @@ __device__ __forceinline__ void quad_butterfly(float2& x0, float2& x1, float2& x
 // price: the first pass must have read everything before anything is stored, and the last pass reads everything before it
 // stores in natural order -- one more synchronisation at either end (the natural-order first pass had one already).
 __host__ __device__ constexpr int quarter_swizzle(int i) { return i ^ ((i >> 8) & 31) ^ ((i >> 4) & 30) ^ ((i >> 2) & 24); }
+// The image of the ONE-wave natural-order transform (N = 256, round 6: quarter_fft's phases): pass 0's results go through LDS once --
+// scattered stores of positions 4 rev(t) + i, read back with slots = position bits (2, 3) -- and for eight position bits no XOR of shifts
+// into the five low bits serves both (sixteen contiguous lanes of a store differ in position bits 7 ... 4, which must reach the four bank
+// bits of a ds_write_b64; the 32 lanes of a read differ in bits 0, 1, 4, 5, 6).  Address bits 0 ... 3 take position bits 7, 6, 5, 4 in,
+// bit 4 takes bit 6 in: GF(2)-linear, a bijection of 0 ... 255, the identity on 0 ... 15 (so a thread's four addresses are again one
+// base XOR constants); tools/quarter_phases_model.py searched the family and counts both accesses conflict free.
+__host__ __device__ constexpr int quarter_image256(int p) { return p ^ ((p >> 7) & 1) ^ ((p >> 5) & 2) ^ ((p >> 3) & 4) ^ ((p >> 1) & 8) ^ ((p >> 2) & 16); }
 
 // ------------------------------------------------------------------------------------------------
 // N <= 256 (round 4): the same radix-2^2 ladder with NO LDS between its passes.  The N/4 threads of a transform are 8 ... 64
@@ -296,6 +310,50 @@ struct QuarterLanes {
             passes<P_INDEX + 1>(e, tw);
         }
     }
+    // The ladder from pass 1 on for a thread whose slots ALREADY hold index bits (2, 3) -- the natural-order transforms of N >= 256 read
+    // pass 0's scattered results back that way (quarter_fft, round 6): lane bits 0, 1 = index bits 0, 1, lane bits 2 ... 5 = index bits
+    // 4 ... 7, so pass 1 starts at once and the exchanges of the passes 2, 3 are the ones passes<2> makes anyway (with lane bits 2, 3 and
+    // 4, 5; REORDER = 0 numbering): sixteen DPP-fed selects per thread and transform fewer than reading four neighbours and transposing.
+    // k = lane mod P in every pass, and the thread ends with elements lane + 64 i as after run().
+    template <class TW>
+    __device__ static __forceinline__ void passes_from_slots23(float2 (&e)[4], const TW& tw) {
+        static_assert(N == 256 && !REORDER, "the wave-local ladder of an aligned block of 256 elements");
+        quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(1), TW::late(1));
+        passes<2>(e, tw);
+    }
+    // run() with the exchange between the passes 1 and 2 THROUGH LDS instead of through the row's DPP network (round 6; no reorder, the
+    // wave's aligned block of 256 elements as scratch).  A transpose of the lane bits 2, 3 is sixteen DPP-fed selects per thread --
+    // about 120 vector cycles of a wave -- and the vector unit is what bounds the no-reorder ladder (N = 1024: 600 vector cycles per
+    // wave and transform against 224 LDS cycles per BLOCK); four ds_write_b64 + four ds_read_b64 of the wave are 32 cycles of an LDS
+    // unit that is mostly idle here, no barrier (one wave), and the re-read deals the lanes afresh: slots = index bits (4, 5), lane
+    // bits 0 ... 3 = index bits 0 ... 3, lane bits 4, 5 = index bits 6, 7 -- so the last exchange is still the cheap one
+    // (v_permlane16/32_swap) and the thread ends with elements lane + 64 i as after run().  Image of the block: element p at
+    // p ^ ((p >> 2) & 28) -- sixteen contiguous lanes of a store differ in index bits 0, 1, 4, 5, the 32 lanes of a read in bits
+    // 0 ... 3 and 6: both conflict free (tools/quarter_phases_model.py).  k = lane mod P in every pass, as in run().
+    __host__ __device__ static constexpr int exchange_image(int p) { return p ^ ((p >> 2) & 28); }
+    template <class TW>
+    __device__ static __forceinline__ void run_exchanged(float2 (&e)[4], const TW& tw, float2* block, int lane, bool loads_precede) {
+        static_assert(N == 256 && !REORDER, "the wave-local ladder of an aligned block of 256 elements");
+        {   // pass 0: twiddles 1, 1, -+i
+            const float2 s0 = cadd(e[0], e[1]), d0 = csub(e[0], e[1]), s1 = cadd(e[2], e[3]), d1 = csub(e[2], e[3]);
+            const float2 jd1 = DIR ? make_float2(-d1.y, d1.x) : make_float2(d1.y, -d1.x);
+            e[0] = cadd(s0, s1), e[1] = cadd(d0, jd1), e[2] = csub(s0, s1), e[3] = csub(d0, jd1);
+        }
+        slots_swap<0, 0, TW::kRowSelects>(e);
+        slots_swap<1, 1, TW::kRowSelects>(e);
+        quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(1), TW::late(1));
+        if (loads_precede) fft_sync<false>();          // the wave's loads of the block precede its stores
+        // slots = index bits (2, 3); lane bits 0, 1 = bits 0, 1; lane bits 2 ... 5 = bits 4 ... 7
+        const int p0 = exchange_image((lane & 3) + 16 * (lane >> 2));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) block[p0 ^ (4 * j)] = e[j];           // (the image is linear and leaves 4 j alone)
+        fft_sync<false>();
+        const int q0 = exchange_image((lane & 15) + 64 * (lane >> 4));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = block[q0 ^ exchange_image(16 * j)];
+        quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(2), TW::late(2));
+        passes<3>(e, tw);
+    }
     // the thread's twiddles: k = base mod P in every pass
     __device__ static __forceinline__ QuarterTwiddles<N, DIR, REORDER> twiddles_of(int t) {
         QuarterTwiddles<N, DIR, REORDER> tw;
@@ -349,9 +407,35 @@ struct QuarterLanes {
 // the transform of a thread block's registers with s as scratch -- one LDS round trip and one synchronisation less at
 // either end (the kernels in the reference's launch shape below use it for N >= 256).
 // ENGINE: 0 = the default of the length (quarter_lanes_default), 1 = the LDS form, 2 = the lane form (N <= 256)
+//
+// PHASES (round 6; N >= 256, tools/quarter_phases_model.py replays them against numpy.fft and counts their LDS cycles).  A wave holds
+// 256 elements: six index bits in its lanes, two in the four slots of a thread, and runs every pass over the bits it holds on lanes
+// and registers (QuarterLanes).  The transform is cut where the owners of the bits change, and only there does it go through LDS:
+//   natural order  phase 0  thread t loads x[t + m N/4] and runs pass 0, which carries the bit reversal: results = positions 4 rev(t) + i,
+//                           scattered into the swizzled image (N = 256: quarter_image256);
+//                  phase 1  read back with SLOTS = POSITION BITS (2, 3) (lane bits 0, 1 = bits 0, 1; lane bits 2 ... 5 = bits 4 ... 7):
+//                           pass 1 starts at once -- round 5 read four neighbours and transposed twice first (sixteen DPP-fed selects) --
+//                           passes 1 ... 3 on the wave's aligned block of 256 positions; N = 256 ends here: slots = bits (6, 7),
+//                           lane = bits 0 ... 5, a conflict-free natural store (round 5's all-register form of this length stored
+//                           bit-reversed lanes: 54 % of its LDS cycles were bank conflicts);
+//   no reorder     phase 1  thread t loads x[4 t + i], passes 0 ... 3 on the wave's aligned block (as in round 4);
+//   N = 512 / 1024 the last pass (radix 2 on bit 8 / radix 4 on bits 8, 9) in the thread, from the swizzled image, natural store;
+//   N = 2048 / 4096 LAST PHASE: the block of 256 goes to the image in NATURAL layout; behind ONE barrier the wave owns position bits
+//                  8 ... n-1 and the low 16 - n bits (slots = bits 8, 9; the other lane bits = bits 10, 11): pass 4, slots <-> lane bits 4, 5
+//                  (v_permlane16/32_swap) and pass 5 (N = 2048: slot bit 0 <-> lane bit 5, the radix-2 pass), natural store.  Both
+//                  cross-wave passes between one pair of barriers -- round 5 made two trips through LDS with a barrier each (N = 4096:
+//                  43 % of the wave cycles waiting).  The natural layout is what lets every wave store into the very words it read
+//                  (no barrier in front of the stores); its price is a 2-way conflict on the four reads of N = 4096.
+//                  (OUT_REGS keeps the round-5 form there: its results must end as elements t + m N/4.)
+#ifndef SMFFT_QUARTER_PHASES
+#define SMFFT_QUARTER_PHASES 1         // 0: the round-5 form (A/B)
+#endif
 template <int N, int DIR, int REORDER, int BLOCK_THREADS, bool IN_REGS = false, bool OUT_REGS = false, int ENGINE = 0>
 __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, int region_offset = 0) {
-    if constexpr ((ENGINE == 2 || (ENGINE == 0 && quarter_lanes_default(N))) && N <= 256 && !OUT_REGS) {   // the ladder on lanes and registers (QuarterLanes above)
+    constexpr bool kLanesOn = ENGINE == 2 || (ENGINE == 0 && SMFFT_QUARTER_LANES != 0);
+    constexpr bool kPhases = kLanesOn && SMFFT_QUARTER_PHASES != 0;
+    constexpr bool kOneWaveNatural = kPhases && N == 256 && REORDER && BLOCK_THREADS <= 64;      // phase 0 + phase 1 inside one wave
+    if constexpr ((ENGINE == 2 || (ENGINE == 0 && quarter_lanes_default(N))) && N <= 256 && !OUT_REGS && !kOneWaveNatural && !(kPhases && N == 256 && !REORDER && BLOCK_THREADS <= 64)) {   // the ladder on lanes and registers (QuarterLanes above)
         QuarterLanes<N, DIR, REORDER>::template lds_to_lds<IN_REGS>(x, s, t, region_offset);
         return;
     }
@@ -363,35 +447,42 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
     // aligned groups of 32) and the elements of the first (no-reorder) and of the last pass (t + m N/4: thread and element
     // share their offset inside a group of 32): between those a wave-level fence orders everything.  What does cross waves:
     // the natural-order first pass (loads t + m N/4, stores 4 rev(t) + m), the passes with P >= 256 and the radix-2 pass.
-    constexpr int T_BITS = ilog2c(Q);
+    constexpr int T_BITS = ilog2c(Q), N_BITS = ilog2c(N);
     constexpr int kLastQuad = R::kOdd ? -1 : R::kPasses - 1;    // the pass whose results leave in natural order (none: the radix-2 pass is last)
+    constexpr bool kLanes512 = kLanesOn && N >= 512;
+    constexpr bool kOneWaveHead = kPhases && N == 256 && !REORDER && BLOCK_THREADS <= 64;
+    constexpr bool kLanesHead = (kLanes512 && !REORDER) || kOneWaveHead;
+    constexpr bool kLanesMiddle = (kLanes512 && REORDER) || kOneWaveNatural;
+    constexpr bool kSlots23 = kLanesMiddle && kPhases;          // phase 1 reads slots = position bits (2, 3)
+    constexpr bool kLastPhase = kPhases && N >= 2048 && !OUT_REGS && (kLanesHead || kLanesMiddle);
+    constexpr int kFirstLdsPass = (kLanesHead || kLanesMiddle) ? 4 : 1;
+    // the thread of the last phase: lanes 0 ... LOW-1 = position bits 0 ... LOW-1, wave = the bits up to 7, slots = bits (8, 9), the other
+    // lane bits = bits 10 (, 11); after the exchange in front of the last pass those lane bits hold bits 8 (, 9)
+    constexpr int LOW = 16 - N_BITS;
+    const int lane = t & 63, wave = t >> 6;
+    const int k_last = kLastPhase ? ((lane & ((1 << LOW) - 1)) | (wave << LOW) | ((lane >> LOW) << 8)) : t;
     // the twiddles first (QuarterTwiddles): k = t mod P in every pass of this form -- and in the wave-local ladder below, whose
-    // butterfly index is the lane = t mod 64 with P <= 64
-    QuarterTwiddles<N, DIR, REORDER> tw;
-    tw.load(t, t);
+    // butterfly index is the lane = t mod 64 with P <= 64; the last phase: k_last
+    QuarterTwiddles<N, DIR, REORDER, kLastPhase> tw;
+    tw.load(t, k_last, k_last);
     float2* sf = s + region_offset;
     float2 e[4];
     // N >= 512, no reorder: the first FOUR passes (index bits 0 ... 7) never leave the wave -- thread t = lane + 64 w starts with
     // elements 4 t + i, i.e. its wave owns the aligned block of 256 elements number w -- so they run on lanes and registers as
     // a 256-point ladder (QuarterLanes<256>: same twiddles W_4P^k, k = lane mod P); its results, elements 256 w + lane + 64 i, go
-    // to the swizzled image, and only the passes that cross waves (P >= 256 and the radix-2 pass) run through LDS:
-    // 2 LDS round trips instead of 5 at N = 512 / 1024, 3 instead of 6 at N = 2048 / 4096 (whose eight barriers become three).
-    // N >= 512, natural order: pass 0 carries the bit reversal (scattered stores into the swizzled image, across waves); after it the
-    // wave again owns the aligned block of 256 elements number w, thread t = lane + 64 w the four elements 4 t + i of it -- the
-    // state a no-reorder ladder is in after ITS pass 0 -- so the passes 1 ... 3 (P = 4, 16, 64: wave-local) run on lanes as well
-    // (QuarterLanes<256>::passes<1>): one LDS round trip instead of three, 5 -> 3 at N = 512 / 1024, 6 -> 4 at N = 2048 / 4096.
-    constexpr bool kLanes512 = (ENGINE == 2 || (ENGINE == 0 && SMFFT_QUARTER_LANES != 0)) && N >= 512;
-    constexpr bool kLanesHead = kLanes512 && !REORDER;
-    constexpr bool kLanesMiddle = kLanes512 && REORDER;
-    constexpr int kFirstLdsPass = (kLanesHead || kLanesMiddle) ? 4 : 1;
+    // to the image, and only the passes that cross waves (P >= 256 and the radix-2 pass) follow behind a barrier.
+    // Natural order: pass 0 carries the bit reversal (scattered stores into the swizzled image, across waves); after it the
+    // wave again owns the aligned block of 256 elements number w, and the passes 1 ... 3 (P = 4, 16, 64: wave-local) run on lanes as well.
     if constexpr (kLanesHead) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) e[i] = IN_REGS ? x[i] : sf[4 * t + i];
-        QuarterLanes<256, DIR, 0>::run(e, tw);
-        if constexpr (!IN_REGS) fft_sync<false>();            // the wave's own loads precede its stores into the same 256 elements
-        const int j0 = region_offset + (t & ~63) * 4 + (t & 63);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s[quarter_swizzle(j0 + 64 * i)] = e[i];
+        if constexpr (kPhases) {
+            QuarterLanes<256, DIR, 0>::run_exchanged(e, tw, sf + 256 * wave, lane, !IN_REGS);
+            fft_sync<false>();                                // the exchange's loads precede the stores into the same 256 elements
+        } else {
+            QuarterLanes<256, DIR, 0>::run(e, tw);
+            if constexpr (!IN_REGS) fft_sync<false>();        // the wave's own loads precede its stores into the same 256 elements
+        }
     } else {
     // ---- pass 0 (P = 1): twiddles 1, 1, -+i -----------------------------------------------------------------------
     int a;
@@ -412,21 +503,72 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
         if constexpr (kLastQuad == 0) {
             sf[a + 0] = cadd(s0, s1), sf[a + 2] = csub(s0, s1), sf[a + 1] = cadd(d0, jd1), sf[a + 3] = csub(d0, jd1);
         } else {
-            const int a0 = quarter_swizzle(region_offset + a);                          // a0 ^ m: the same aligned group of four
+            const int a0 = kOneWaveNatural ? region_offset + quarter_image256(a) : quarter_swizzle(region_offset + a);   // a0 ^ m: the same aligned group of four
             s[a0] = cadd(s0, s1), s[a0 ^ 2] = csub(s0, s1), s[a0 ^ 1] = cadd(d0, jd1), s[a0 ^ 3] = csub(d0, jd1);
         }
     }
     if constexpr (kLanesMiddle) {
         fft_sync<kBarrier>();                                      // every wave's scattered stores precede the loads
-        const int b0 = quarter_swizzle(region_offset + 4 * t);     // elements 4 t + i: one aligned group of four
+        if constexpr (kSlots23) {
+            // slots = position bits (2, 3): elements p1 + 4 j, p1 = position bits 0, 1 from lane bits 0, 1 and bits 4 ... 7 from lane bits 2 ... 5
+            const int p1 = (lane & 3) + 16 * (lane >> 2) + 256 * wave;
+            const int b0 = kOneWaveNatural ? region_offset + quarter_image256(p1) : quarter_swizzle(region_offset + p1);      // (both images leave 4 j alone)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) e[i] = s[b0 ^ i];
-        QuarterLanes<256, DIR, 0>::template passes<1>(e, tw);
+            for (int j = 0; j < 4; ++j) e[j] = s[b0 ^ (4 * j)];
+            QuarterLanes<256, DIR, 0>::passes_from_slots23(e, tw);
+        } else {
+            const int b0 = quarter_swizzle(region_offset + 4 * t);     // elements 4 t + i: one aligned group of four
+#pragma unroll
+            for (int i = 0; i < 4; ++i) e[i] = s[b0 ^ i];
+            QuarterLanes<256, DIR, 0>::template passes<1>(e, tw);
+        }
         fft_sync<false>();                                         // the wave's own loads precede its stores into the same 256 elements
-        const int j0 = region_offset + (t & ~63) * 4 + (t & 63);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s[quarter_swizzle(j0 + 64 * i)] = e[i];
     }
+    }
+    if constexpr (kLanesHead || kLanesMiddle) {
+        // the thread holds elements 256 w + lane + 64 i of its wave's block
+        if constexpr (N == 256) {                                  // (one wave, natural order: the results)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (OUT_REGS) x[i] = e[i];
+                else sf[t + 64 * i] = e[i];
+            }
+            return;
+        } else if constexpr (kLastPhase) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sf[t + 192 * wave + 64 * i] = e[i];      // natural layout: 256 w + lane + 64 i
+        } else {
+            const int j0 = region_offset + (t & ~63) * 4 + (t & 63);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[quarter_swizzle(j0 + 64 * i)] = e[i];
+        }
+    }
+    if constexpr (kLastPhase) {
+        // ---- the last phase (N = 2048 / 4096): passes 4 and 5 (the radix-2 pass) on lanes and registers --------------------------------
+        fft_sync<true>();                                          // every wave's block is in the image
+        const float2* src = sf + ((lane & ((1 << LOW) - 1)) | (wave << LOW) | ((lane >> LOW) << 10));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = src[256 * j];
+        quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(4), tw.late(4));
+        if constexpr (!R::kOdd) {
+            slots_swap<0, 4, true>(e);
+            slots_swap<1, 5, true>(e);
+            quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(5), tw.late(5));
+            fft_sync<false>();                                     // the wave's loads precede its stores into the same words
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sf[k_last + 1024 * i] = e[i];
+        } else {
+            slots_swap<0, 5, true>(e);                             // slots = (bit 10, bit 9): elements k, k + 1024, k + 512, k + 1536
+            const float2 w = tw.wr;
+            const float2 t1 = cmul(e[1], w), v3 = cmul(e[3], w);
+            const float2 t3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);
+            fft_sync<false>();
+            sf[k_last] = cadd(e[0], t1);
+            sf[k_last + N / 2] = csub(e[0], t1);
+            sf[k_last + Q] = cadd(e[2], t3);
+            sf[k_last + 3 * Q] = csub(e[2], t3);
+        }
+        return;
     }
     // ---- passes 1 .. (P = 4, 16, ...) -----------------------------------------------------------------------------
     if constexpr (R::kPasses > kFirstLdsPass) {

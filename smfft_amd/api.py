@@ -30,6 +30,7 @@ _SIGS = {
     "smfft_ct_external_benchmark": (_i, [_vp, _vp, _i, _i, _i, _i, _dp]),
     "smfft_ct_multiple_benchmark": (_i, [_vp, _vp, _i, _i, _i, _i, _dp]),
     "smfft_ct_multiple_unfused_benchmark": (_i, [_vp, _vp, _i, _i, _i, _dp]),
+    "smfft_ct_multiple_percall_benchmark": (_i, [_vp, _vp, _i, _i, _i, _i, _dp]),
     "smfft_st_external_benchmark": (_i, [_vp, _vp, _i, _i, _dp]),
     "smfft_st_external_benchmark_dir": (_i, [_vp, _vp, _i, _i, _i, _dp]),
     "smfft_st_multiple_benchmark": (_i, [_vp, _vp, _i, _i, _dp]),

@@ -13,6 +13,7 @@
 #include <utility>
 
 #include "../../include/smfft.h"
+#include "../../include/smfft_debug.h"
 #include "../../include/smfft_reference_api.h"
 #include "smfft_host_util.hpp"
 #include "smfft_launch.hpp"
@@ -165,11 +166,13 @@ bool wrapper_memory_ok(size_t pair_bytes_each, size_t needed, size_t free_mem) {
 // The L3 wrappers time nRuns launches right after a multi-GiB upload, i.e. on a device whose shader clock has fallen back: the
 // first tens of milliseconds of in-LDS launches then run 20-40 % under the settled rate (clocks follow the load on MI355X;
 // profiles/r03_warm_ramp.txt), and with upstream's nRuns = 20 the reported mean is mostly ramp.  The wrappers therefore run the
-// SAME launch untimed until it has accumulated SMFFT_WRAPPER_WARMUP_MS (default 40; 0 = upstream's behaviour) of kernel time,
-// then time nRuns launches exactly as upstream does (CT:862-871).  The results are the same launches' results.
+// SAME launch untimed until it has accumulated SMFFT_WRAPPER_WARMUP_MS of kernel time, then time nRuns launches exactly as upstream
+// does (CT:862-871).  DEFAULT 0 (round 6): upstream times its nRuns launches directly behind the upload, and so does the wrapper
+// unless the variable asks otherwise (tools/readme_table.py sets 40 for the settled figures and says so; bench.py does not go
+// through the wrappers).  The results are the same launches' results.
 template <class F>
 void wrapper_warm_up(F&& timed_launch) {
-    static const double budget = [] { const char* e = getenv("SMFFT_WRAPPER_WARMUP_MS"); return e ? atof(e) : 40.0; }();
+    static const double budget = [] { const char* e = getenv("SMFFT_WRAPPER_WARMUP_MS"); return e ? atof(e) : 0.0; }();
     double spent = 0;
     for (int i = 0; i < 4096 && spent < budget; ++i) {
         const double before = spent;
@@ -271,10 +274,13 @@ unsigned* schedule_acquire(int nchains, hipStream_t stream, unsigned* base, int*
         if (!b.flags) { if (empty < 0) empty = i; continue; }
         if (b.device != device || b.taken) continue;
         if (b.in_flight) {
+            // Recycled on hipSuccess ONLY.  Any other answer -- not ready, or an error of the query itself (a context error; another
+            // thread's global-mode stream capture makes the call illegal) -- says nothing about the launch that used the buffer, and two
+            // launches sharing hand-over words under different bases would not see each other's states: the buffer stays in flight
+            // and this launch looks further (no buffer to be had: one chain per workgroup).
             const hipError_t q = hipEventQuery(b.done);
-            if (q == hipErrorNotReady) { (void)hipGetLastError(); continue; }
-            b.in_flight = false;                      // complete (or the event is unusable: the buffer is idle either way once the stream has drained)
-            (void)hipGetLastError();
+            if (q != hipSuccess) { (void)hipGetLastError(); continue; }
+            b.in_flight = false;
         }
         chosen = i;
     }
@@ -344,6 +350,15 @@ int smfft_ct_multiple_unfused_benchmark(const void* d_input, void* d_output, int
     }
     const int slots = ct_multiple_slots(FFT_size, nFFTs);
     return timed([&] { return dispatch_ct((const float2*)d_input, (float2*)d_output, FFT_size, slots, inverse != 0, true, 2, 0); }, FFT_time);
+}
+
+int smfft_ct_multiple_percall_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, int inverse, int reorder, double* FFT_time) {
+    if (nFFTs / SMFFT_NREUSES == 0) {
+        if (FFT_time) *FFT_time = -1;
+        return 1;
+    }
+    const int slots = ct_multiple_slots(FFT_size, nFFTs);
+    return timed([&] { return dispatch_ct((const float2*)d_input, (float2*)d_output, FFT_size, slots, inverse != 0, reorder != 0, 2, 0); }, FFT_time);
 }
 
 int smfft_st_external_benchmark(const void* d_input, void* d_output, int FFT_size, int nFFTs, double* FFT_time) {

@@ -61,7 +61,7 @@ static int launch_compact(CompactKernel kernel, const float2* d_input, float2* d
             sch.per_wg = (int)per_wg;
             sch.base = base;
             sch.flags = flags;
-            sch.wait_ticks = opt.handoff_wait_us * 100u;            // 100 MHz
+            sch.wait_ticks = (opt.handoff_wait_us < 40000000u ? opt.handoff_wait_us : 40000000u) * 100u;      // 100 MHz ticks in 32 bits: at most 40 s
             sch.delay_chain = opt.delay_chain;
             sch.delay_ticks = opt.delay_ms * 100000u;
             sch.delay_after_commit = opt.delay_after_commit;
@@ -118,6 +118,18 @@ int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int i
     if (path == 2 && reorder) {     // no cross-application fusion (what one call of the device function costs)
         if (!inverse) return launch_compact(SMFFT_DIT_multiple_unfused<CT_CLASS(_forward)>, d_input, d_output, count, opt, stream);
         return launch_compact(SMFFT_DIT_multiple_unfused<CT_CLASS(_inverse)>, d_input, d_output, count, opt, stream);
+    }
+#endif
+#if SMFFT_N == 32
+    if (path == 2 && reorder) {     // the pair engine with an image load and an image store per application
+        if (!inverse) return launch_compact(SMFFT_DIT_multiple_unfused<CT_CLASS(_forward)>, d_input, d_output, count, opt, stream);
+        return launch_compact(SMFFT_DIT_multiple_unfused<CT_CLASS(_inverse)>, d_input, d_output, count, opt, stream);
+    }
+#endif
+#if SMFFT_N <= 64
+    if (path == 2 && !reorder) {    // the lane engines' no-reorder kernels, unfused the same way (N >= 128: the planar kernels re-read the image as they are)
+        if (!inverse) return launch_compact(SMFFT_DIT_multiple_unfused<CT_CLASS(_forward_noreorder)>, d_input, d_output, count, opt, stream);
+        return launch_compact(SMFFT_DIT_multiple_unfused<CT_CLASS(_inverse_noreorder)>, d_input, d_output, count, opt, stream);
     }
 #endif
     if (!inverse && reorder)  return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_forward)>, d_input, d_output, count, opt, stream);

@@ -319,6 +319,7 @@ __device__ __forceinline__ void trace_piece(unsigned long long* trace, int k, in
 // No cache-wide write-back or invalidate anywhere: with `fence(release / acquire, "agent")` around plain tile accesses -- rounds
 // 4's form -- every workgroup's `buffer_wbl2` scanned its XCD's L2, 10-90 us of a README launch (profiles/r05_handover_forms.txt).
 enum ChainState : unsigned { kChainOwned = 1u, kChainParked = 2u, kChainTaken = 3u };
+constexpr unsigned long long kChainWaitLimit = 120ull * 100000000ull;      // 100 MHz ticks
 
 // one word from thread 0 to every thread of the workgroup (single-wave workgroups: the barriers compile to nothing)
 __device__ __forceinline__ unsigned workgroup_broadcast(unsigned value) {
@@ -365,6 +366,10 @@ __device__ __forceinline__ int chain_resume_or_take(const MultipleSchedule& sch,
         for (;;) {
             unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (v == sch.base + kChainParked) break;
+            // An owner that has committed is running, so this wait ends -- unless the owner's workgroup faulted or the words are not
+            // this launch's (host-side misuse): after kChainWaitLimit (two minutes: a README chain takes milliseconds) the launch
+            // ends with an error instead of hanging the device silently.
+            if (wall_clock64() - t0 > kChainWaitLimit) __builtin_trap();
             if (v != sch.base + kChainOwned && wall_clock64() - t0 > sch.wait_ticks) {
                 if (__hip_atomic_compare_exchange_strong(word, &v, sch.base + kChainTaken, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     take = 1;
@@ -441,7 +446,11 @@ constexpr bool on_lanes(int n, int reorder) { return n == 32 || (n == 64 && !reo
 // a bit-reversal through LDS per application: profiles/r05_pair32.txt has both; the planar engine measured 10 % slower than that
 // one, profiles/r03_ab_planar_small.txt.)
 // (d_input / d_output are not __restrict__ here: a resumed piece READS the tile another workgroup of this launch parked in d_output)
-template <int N, int DIR, int REORDER>
+// FUSED = false (smfft_launch path 2; round 6): every application loads its registers from the image in LDS and stores its results
+// there -- the shape of the reference's own loop, which calls do_SMFFT_CT_DIT(s_input) NREUSES times (CT:553-572), and what ONE call
+// of the device function costs on these lengths.  Same bits as the fused loop (load / store flip sign BITS where the fused loop carries
+// a negated lane; flipping twice is exact).
+template <int N, int DIR, int REORDER, bool FUSED = true>
 __device__ __forceinline__ void c2c_multiple_body(const float2* d_input, float2* d_output, int nSlots, int nreuses, MultipleSchedule sch, float2* s) {
     static_assert(N == 32 || (N == 64 && !REORDER), "the planar engine takes everything else");
     using G = Geometry<N>;
@@ -469,6 +478,17 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* d_input, float2*
         // inlined copies of the same source into the kernel; their arithmetic is written with its rounding fixed (cmul_fixed,
         // SmallDft<..., FIXED>), or a chain cut on an odd application would not end with the bits of an uncut one.
         float2 r[16];
+        if constexpr (!FUSED) {
+            for (int f = piece.app0; f < piece.app1; ++f) {
+                priority.at_application();
+                eng.load(r, sf, f);
+                fft_sync<G::kMultiWave>();          // (the wave's loads of the image precede its stores)
+                if (f & 1) eng.apply(r, true);
+                else eng.apply(r, false);
+                eng.store(r, sf, f + 1);
+                fft_sync<G::kMultiWave>();
+            }
+        } else {
         eng.load(r, sf, piece.app0);
         int f = piece.app0;
         if (f & 1) {
@@ -489,6 +509,7 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* d_input, float2*
         fft_sync<G::kMultiWave>();              // (the wave's loads of the image precede its stores)
         eng.store(r, sf, piece.app1);
         fft_sync<G::kMultiWave>();
+        }
         priority.between_applications();
         trace_piece(sch.trace, k, 1);
         if (!piece.park) {
@@ -875,12 +896,20 @@ __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_size) SMFFT_DIT_multiple(
 // input from the LDS image and leaves its output there, which is what ONE call of the device function costs a user kernel
 // whose data live in LDS (CT:553-572 calls do_SMFFT_CT_DIT on s_input NREUSES times; nothing survives a call in registers).
 // smfft_launch(..., path = 2); bench.py reports it next to the fused figure and the reference-contract path.
+// (the planar no-reorder variants read their input from the image in every application as they are: path 2 launches SMFFT_DIT_multiple
+//  for them.  The lane engines -- N = 32, N = 64 without reorder -- keep a chain in registers from its first application to its last:
+//  their path 2 is c2c_multiple_body<..., false>, one image load and one image store per application.)
 template <class const_params>
 __global__ void SMFFT_COMPACT_BOUNDS(const_params::fft_size) SMFFT_DIT_multiple_unfused(const float2* d_input, float2* d_output, int nSlots, int nreuses, smfft::MultipleSchedule sch) {
     constexpr int N = const_params::fft_size;
-    static_assert(N >= smfft::kPlanarMinN && const_params::fft_reorder, "the no-reorder variants and N = 32 are unfused as they are");
-    __shared__ __attribute__((aligned(16))) float s_planes[smfft::compact_lds_floats<N>(smfft::PlanarGeometry<N, 1>::kLdsFloats)];
-    smfft::c2c_multiple_body_planar<N, const_params::fft_direction, 1, false>(d_input, d_output, nSlots, nreuses, sch, s_planes);
+    if constexpr (smfft::on_lanes(N, const_params::fft_reorder)) {
+        __shared__ float2 s_input[smfft::compact_lds_floats<N>(2 * smfft::Geometry<N>::kCompactLds) / 2];
+        smfft::c2c_multiple_body<N, const_params::fft_direction, const_params::fft_reorder, false>(d_input, d_output, nSlots, nreuses, sch, s_input);
+    } else {
+        static_assert(N >= smfft::kPlanarMinN && const_params::fft_reorder, "the planar no-reorder variants are unfused as they are");
+        __shared__ __attribute__((aligned(16))) float s_planes[smfft::compact_lds_floats<N>(smfft::PlanarGeometry<N, 1>::kLdsFloats)];
+        smfft::c2c_multiple_body_planar<N, const_params::fft_direction, 1, false>(d_input, d_output, nSlots, nreuses, sch, s_planes);
+    }
 }
 
 // Stockham C2C program: un-normalised INVERSE (+i) transform, natural order (ST:76, :429).

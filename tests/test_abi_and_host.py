@@ -16,7 +16,7 @@ def built(built_product):
 
 
 def _declared_c_functions():
-    text = open(os.path.join(ROOT, "include", "smfft.h")).read()
+    text = open(os.path.join(ROOT, "include", "smfft.h")).read() + open(os.path.join(ROOT, "include", "smfft_debug.h")).read()      # (the test-only entry points too)
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(smfft_[a-z0-9_]+)\s*\(", text)))
 

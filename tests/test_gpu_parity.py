@@ -41,6 +41,32 @@ def test_ct_external_golden_zero_mean(sm, golden, n):
     ref.assert_close_fp32(got, golden[f"ct_out_u11_{n}_inv0_reo1"], f"CT N={n} u11")
 
 
+@pytest.mark.parametrize("n,reo", [(32, 1), (32, 0), (64, 0), (128, 0)])
+def test_lane_engines_one_image_trip_per_application(sm, oracle_lib, n, reo):
+    """smfft_launch(path = 2) for the kernels that keep a chain in REGISTERS over its applications (round 6): the lane engines of
+    N = 32 and of N = 64 without reorder with one image load and one image store per application -- the shape of upstream's loop
+    (CT:553-572) -- give the bits of the fused loop (their load / store flip sign bits where the fused loop carries a negated lane:
+    exact), for odd and even application counts, and are k applications of the oracle; N = 128 without reorder re-reads the image
+    as it is (path 2 = path 1 there)."""
+    nffts = 100 * 64 + 3
+    rng = np.random.default_rng(n + 5 * reo)
+    x = ((rng.random((nffts, n), dtype=np.float32) - 0.5) + 1j * (rng.random((nffts, n), dtype=np.float32) - 0.5)).astype(np.complex64)
+    slots = _slots(n, nffts)
+    for reuses in (1, 2, 3, 4):
+        sm.lib.smfft_set_nreuses(reuses)
+        try:
+            fused = sm.c2c(x, False, bool(reo), path="multiple")
+            percall = sm.c2c(x, False, bool(reo), path="multiple_unfused")
+        finally:
+            sm.lib.smfft_set_nreuses(0)
+        assert np.array_equal(fused.view(np.uint32), percall.view(np.uint32)), (n, reo, reuses)
+        want = x[:slots].astype(np.complex128)
+        for _ in range(reuses):
+            want = oa.ct_c2c(oracle_lib, want, 0, reo, "f64")
+        l2, mx = ref.fft_errors(percall[:slots], want)
+        assert l2 <= 5e-7 * reuses ** 0.5 and mx <= 1e-6 * reuses ** 0.5, (n, reo, reuses, l2, mx)
+
+
 @pytest.mark.parametrize("n", ST_SIZES)
 def test_stockham_external_golden(sm, golden, n):
     got = sm.stockham_c2c(golden[f"c2c_in_u01_{n}"])
@@ -1588,19 +1614,27 @@ def test_bench_two_ranks_on_one_device(sm):
     assert len(doc["pair_search"]) >= 1 and sum(a["kept"] for a in doc["pair_search"]) == 1
 
 
-def test_bench_eight_ranks_dress_rehearsal_on_one_device(sm):
+@pytest.mark.parametrize("policy", ["plain", "default"])
+def test_bench_eight_ranks_dress_rehearsal_on_one_device(sm, policy):
     """The driver's 8-GPU command, rehearsed on the one device a box has: `bench.py --gpus 8` starts eight ranks
-    (no 8-GPU node has been available in any round), all pinned to device 0, timings and per-rank outcomes exchanged over gloo,
-    plain allocations (eight allocator scans at once on one device would measure the scans).  No curve is read off this: what is
-    checked is that the first real 8-rank run is not the first 8-rank run of the code -- ranks_seen 8, per_rank lists of 8,
-    value = 8 * nFFTs / max(t), ONE compact line under 4 KB, rc 0."""
+    (no 8-GPU node has been available in any round), all pinned to device 0, timings and per-rank outcomes exchanged over gloo.
+    policy = plain: ordinary allocations; default (round 6): the allocator's own placement search in every rank -- eight scans at
+    once on ONE device, each with an eighth of the default byte budget (a real 8-GPU node gives every rank a device of its own) --
+    so that `per_rank.good_enough` / `attempts` have been through eight concurrent scans before the first real 8-rank run.  No curve
+    is read off this (the scans disturb each other's timings: good_enough may be 0): what is checked is ranks_seen 8, per_rank
+    lists of 8, value = 8 * nFFTs / max(t), ONE compact line under 4 KB, rc 0."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(SMFFT_BENCH_DEVICE="0", SMFFT_BENCH_BACKEND="gloo", SMFFT_BENCH_PREWARM_S="0.1", SMFFT_PAIR_POLICY="plain")
+    env.update(SMFFT_BENCH_DEVICE="0", SMFFT_BENCH_BACKEND="gloo", SMFFT_BENCH_PREWARM_S="0.1")
+    if policy == "plain":
+        env.update(SMFFT_PAIR_POLICY="plain")
+    else:
+        env.pop("SMFFT_PAIR_POLICY", None)
+        env.update(SMFFT_PAIR_BUDGET_FRAC=str(0.25 / 8))
     nffts = 32768
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--nffts", str(nffts), "--no-configs"],
                        env=env, capture_output=True, text=True, timeout=1200)
@@ -1618,6 +1652,9 @@ def test_bench_eight_ranks_dress_rehearsal_on_one_device(sm):
     assert doc["value"] == pytest.approx(8 * nffts / (slowest * 1e-3), rel=1e-3)
     assert doc["value_sum_of_rates"] >= doc["value"] * 0.999
     assert doc["cpu_baseline"] is None      # the CPU baseline is rank 0's at N = 1 only (the tier's contract)
+    assert all(a >= 1 for a in per_rank["attempts"]) and all(g in (0, 1) for g in per_rank["good_enough"])
+    if policy == "default":
+        assert all(c > 0 for c in per_rank["copy_ms"])
 
 
 # ------------------------------------------------------------ analytic known-answer tests through the HIP path (8(c) item 3)

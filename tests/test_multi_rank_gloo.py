@@ -7,6 +7,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -73,3 +74,39 @@ def test_bench_gpus_flag_never_silently_runs_one_rank():
     p = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
     assert p.returncode != 0 and p.stdout.strip() == ""
     assert p.stderr.count("bench.py needs a GPU") == 2
+
+
+def _agree_worker(rank, world, port, fail_on, outdir):
+    sys.path.insert(0, ROOT)
+    from smfft_amd.sharding import agree_on_fast_group, gather_stats, reduce_stats
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def try_fast():
+        # (a second gloo group plays RCCL's part on the CPU: what is tested is that the ranks end up on the SAME group)
+        g = dist.new_group(backend="gloo")
+        if rank in fail_on:
+            raise RuntimeError("this rank could not bring the fast communicator up")
+        return g
+    group, error = agree_on_fast_group(dist, try_fast)
+    assert (error is not None) == (rank in fail_on)
+    # whatever was agreed, the reductions of bench.py run on it and see every rank
+    wall, kernel, errs = reduce_stats(dist, torch.device("cpu"), 1.0 + rank, 5.0, 1, group=group)
+    rows = gather_stats(dist, torch.device("cpu"), [float(rank)], group=group)
+    assert wall == float(world) and errs == world and [r[0] for r in rows] == [float(r) for r in range(world)]
+    with open(os.path.join(outdir, f"agreed{rank}.txt"), "w") as f:
+        f.write("fast" if group is not None else "default")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_on", [(), (1,), (0, 1)])
+def test_ranks_agree_on_the_communicator(tmp_path, fail_on):
+    """bench.py decides RCCL-or-gloo ONCE for all ranks (round 5 let every rank fall back on its own: RCCL up on some ranks only would
+    have hung the job): if any rank cannot bring the fast group up, no rank uses it."""
+    world = 2
+    mp.spawn(_agree_worker, args=(world, _free_port(), tuple(fail_on), str(tmp_path)), nprocs=world, join=True)
+    verdicts = {open(tmp_path / f"agreed{r}.txt").read() for r in range(world)}
+    assert verdicts == ({"fast"} if not fail_on else {"default"})

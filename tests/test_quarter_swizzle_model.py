@@ -64,3 +64,43 @@ def test_lane_and_register_form_of_the_ladder_is_the_dft():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import quarter_lanes_model
     assert quarter_lanes_model.check() < 1e-14
+
+
+def test_phased_form_of_the_ladder_is_the_dft_and_conflict_free():
+    """tools/quarter_phases_model.py (round 6): the reference-contract engine of N >= 256 cut into phases in which a wave owns eight
+    index bits -- natural order read back with slots = index bits (2, 3), the no-reorder ladder's middle exchange through the wave's
+    own block of LDS, the two cross-wave passes of N = 2048 / 4096 between one pair of barriers -- computes the DFT (natural order) /
+    the DFT of the bit-reversed input (no reorder), both directions, and every LDS access of it is conflict free under the gfx950
+    lane-group rules except the four natural-layout reads of N = 4096's last phase (2-way: the price of storing without a barrier)."""
+    import quarter_phases_model as qp
+    assert qp.check() < 1e-14
+    assert qp.M256 in qp.search_256()
+    assert all(qp.apply_rows(qp.M256, p) == qp.image256(p) for p in range(256))
+    for n in (256, 512, 1024, 2048):
+        for reorder in (1, 0):
+            total, ideal, _ = qp.lds_report(n, reorder)
+            assert total == ideal, (n, reorder, total, ideal)
+    for reorder in (1, 0):
+        total, ideal, _ = qp.lds_report(4096, reorder)
+        assert total == ideal + 16 * 4 * 2, (reorder, total, ideal)      # sixteen waves x four reads x two extra cycles
+
+
+def test_header_computes_the_phase_images(tmp_path):
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    import quarter_phases_model as qp
+    src = tmp_path / "img.hip"
+    src.write_text(r'''
+#include <cstdio>
+#include "smfft_device.hpp"
+int main() {
+    for (int i = 0; i < 256; ++i) printf("%d %d\n", smfft::quarter_image256(i), smfft::QuarterLanes<256, 0, 0>::exchange_image(i));
+    return 0;
+}
+''')
+    exe = tmp_path / "img"
+    subprocess.check_call([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                          stderr=subprocess.DEVNULL)
+    got = [tuple(int(v) for v in line.split()) for line in subprocess.check_output([str(exe)], text=True).splitlines()]
+    assert got == [(qp.image256(i), qp.exchange_image(i)) for i in range(256)]
