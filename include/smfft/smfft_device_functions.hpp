@@ -315,6 +315,9 @@ struct QuarterLanes {
     // 4 ... 7, so pass 1 starts at once and the exchanges of the passes 2, 3 are the ones passes<2> makes anyway (with lane bits 2, 3 and
     // 4, 5; REORDER = 0 numbering): sixteen DPP-fed selects per thread and transform fewer than reading four neighbours and transposing.
     // k = lane mod P in every pass, and the thread ends with elements lane + 64 i as after run().
+    // (The remaining exchange of lane bits 2, 3 through the wave's block of LDS as well -- run_exchanged's way -- measured 10 ... 29 % SLOWER
+    //  here: the natural-order transform already makes three trips through LDS, a fourth makes the LDS unit the bound;
+    //  profiles/r06_contract_phases.txt.)
     template <class TW>
     __device__ static __forceinline__ void passes_from_slots23(float2 (&e)[4], const TW& tw) {
         static_assert(N == 256 && !REORDER, "the wave-local ladder of an aligned block of 256 elements");

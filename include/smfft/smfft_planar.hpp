@@ -521,20 +521,28 @@ __device__ __forceinline__ void tile_to_planes(const float2* g, float* planes, l
     //  of being hoisted out of the loop over chains and kept in registers across the applications)
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
-    float2 val[16];
+    // (N = 4096: eight elements at a time.  The kernel sits at the 128-register cap of four waves per SIMD with 60 registers of
+    //  twiddles alive across this copy, and sixteen values in flight spilled 44-52 bytes per lane to scratch -- outside the application
+    //  loop, but a private segment all the same; a copy is once per hundred applications)
+    constexpr int kBatch = N >= 2048 ? 8 : 16;
     const bool full = first_fft + P::F <= limit_fft;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const int e = tid + TW * c;
-        const bool ok = full || (first_fft + e / N < limit_fft);
-        const float2 t = g[ok ? e : 0];
-        val[c] = ok ? t : make_float2(0.f, 0.f);
-    }
+    for (int c0 = 0; c0 < 16; c0 += kBatch) {
+        float2 val[kBatch];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        float* p = plane_word_of<N, DIR, REORDER>(planes, tid + TW * c);
-        p[0] = val[c].x;
-        p[P::kPlane] = val[c].y;
+        for (int c = 0; c < kBatch; ++c) {
+            const int e = tid + TW * (c0 + c);
+            const bool ok = full || (first_fft + e / N < limit_fft);
+            const float2 t = g[ok ? e : 0];
+            val[c] = ok ? t : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < kBatch; ++c) {
+            float* p = plane_word_of<N, DIR, REORDER>(planes, tid + TW * (c0 + c));
+            p[0] = val[c].x;
+            p[P::kPlane] = val[c].y;
+        }
+        if (kBatch < 16) asm volatile("" ::: "memory");      // the batches stay apart
     }
 }
 template <int N, int DIR, int REORDER>

@@ -17,6 +17,8 @@
 // limiter (vmem_throttle below).  Grids are grid-strided over tiles so a capped ("persistent") grid
 // keeps twiddles in registers.
 #pragma once
+#include <type_traits>
+
 #include "smfft/smfft_device_functions.hpp"
 #include "smfft/smfft_planar.hpp"
 
@@ -158,9 +160,9 @@ __device__ __forceinline__ void c2c_external_body(const float2* __restrict__ d_i
 // kCompactThreads (the thread index contributes its own FFT number and position); the pad term splits the same way
 // because kCompactThreads * c is a multiple of 2^kPadShift.
 template <int N, bool PADDED>
-__device__ __forceinline__ int compact_lds_base() {
+__device__ __forceinline__ int compact_lds_base(int tid) {
     using G = Geometry<N>;
-    const int t = threadIdx.x % N, j = threadIdx.x / N;
+    const int t = tid % N, j = tid / N;
     return j * G::SF + t + (PADDED ? (t >> G::kPadShift) : 0);
 }
 template <int N, bool PADDED>
@@ -174,40 +176,57 @@ __device__ __forceinline__ void tile_to_lds(const float2* g, float2* s, long fir
     using G = Geometry<N>;
     constexpr int C = G::kCompactTile / G::kCompactThreads;
     static_assert(N >= G::kCompactThreads || G::kCompactThreads % N == 0, "see compact_lds_base");
-    float2 v[C];
-    if (first_fft + G::kCompactFfts <= limit_fft) {      // whole tile inside the batch: loads back to back, no predicate
+    // (eight elements at a time: these kernels -- the lane engines' -- sit at the 128-register cap of four waves per SIMD with 30 registers
+    //  of twiddles alive across the copy, and sixteen values in flight pushed addresses of the piece loop into scratch; a copy is once per
+    //  hundred applications)
+    constexpr int kBatch = C > 8 ? 8 : C;
+    const int tid = (int)threadIdx.x;
+    float2* base = s + compact_lds_base<N, PADDED>(tid);
+    const bool full = first_fft + G::kCompactFfts <= limit_fft;
 #pragma unroll
-        for (int c = 0; c < C; ++c) v[c] = g[threadIdx.x + G::kCompactThreads * c];
-    } else {
+    for (int c0 = 0; c0 < C; c0 += kBatch) {
+        float2 v[kBatch];
+        if (full) {                                      // whole tile inside the batch: loads back to back, no predicate
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int e = threadIdx.x + G::kCompactThreads * c;
-            const bool ok = first_fft + e / N < limit_fft;
-            const float2 t = g[ok ? e : 0];              // g[0] belongs to FFT first_fft, which exists
-            v[c] = ok ? t : make_float2(0.f, 0.f);
+            for (int c = 0; c < kBatch; ++c) v[c] = g[tid + G::kCompactThreads * (c0 + c)];
+        } else {
+#pragma unroll
+            for (int c = 0; c < kBatch; ++c) {
+                const int e = tid + G::kCompactThreads * (c0 + c);
+                const bool ok = first_fft + e / N < limit_fft;
+                const float2 t = g[ok ? e : 0];          // g[0] belongs to FFT first_fft, which exists
+                v[c] = ok ? t : make_float2(0.f, 0.f);
+            }
         }
-    }
-    float2* base = s + compact_lds_base<N, PADDED>();
 #pragma unroll
-    for (int c = 0; c < C; ++c) base[compact_lds_offset<N, PADDED>(c)] = v[c];
+        for (int c = 0; c < kBatch; ++c) base[compact_lds_offset<N, PADDED>(c0 + c)] = v[c];
+        if (kBatch < C) asm volatile("" ::: "memory");   // the batches stay apart
+    }
 }
 template <int N, bool PADDED>
 __device__ __forceinline__ void lds_to_tile(float2* g, const float2* s, long first_fft, long limit_fft) {
     using G = Geometry<N>;
     constexpr int C = G::kCompactTile / G::kCompactThreads;
-    float2 v[C];
-    const float2* base = s + compact_lds_base<N, PADDED>();
+    constexpr int kBatch = C > 8 ? 8 : C;                // (as in tile_to_lds)
+    int tid = (int)threadIdx.x;
+    const float2* base = s + compact_lds_base<N, PADDED>(tid);
+    const bool full = first_fft + G::kCompactFfts <= limit_fft;
 #pragma unroll
-    for (int c = 0; c < C; ++c) v[c] = base[compact_lds_offset<N, PADDED>(c)];
-    if (first_fft + G::kCompactFfts <= limit_fft) {
+    for (int c0 = 0; c0 < C; c0 += kBatch) {
+        float2 v[kBatch];
 #pragma unroll
-        for (int c = 0; c < C; ++c) g[threadIdx.x + G::kCompactThreads * c] = v[c];
-    } else {
+        for (int c = 0; c < kBatch; ++c) v[c] = base[compact_lds_offset<N, PADDED>(c0 + c)];
+        if (full) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int e = threadIdx.x + G::kCompactThreads * c;
-            if (first_fft + e / N < limit_fft) g[e] = v[c];
+            for (int c = 0; c < kBatch; ++c) g[tid + G::kCompactThreads * (c0 + c)] = v[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < kBatch; ++c) {
+                const int e = tid + G::kCompactThreads * (c0 + c);
+                if (first_fft + e / N < limit_fft) g[e] = v[c];
+            }
         }
+        if (kBatch < C) asm volatile("" ::: "memory");
     }
 }
 
@@ -225,11 +244,12 @@ __device__ __forceinline__ void shared_tile_to_lds(const float2* g, float2* s, l
     constexpr int C = G::kCompactTile / G::kCompactThreads / 2;
     const long ffts = limit_fft - first_fft < G::kCompactFfts ? limit_fft - first_fft : G::kCompactFfts;
     const SharedTile tile(g, ffts * N * 8);
+    int tid = (int)threadIdx.x;
     float2 v[2 * C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) tile.load2(2 * (int)threadIdx.x + 2 * G::kCompactThreads * c, v[2 * c], v[2 * c + 1]);
+    for (int c = 0; c < C; ++c) tile.load2(2 * tid + 2 * G::kCompactThreads * c, v[2 * c], v[2 * c + 1]);
 #pragma unroll
-    for (int c = 0; c < 2 * C; ++c) s[compact_lds_index<N, PADDED>(2 * (int)threadIdx.x + (c & 1) + 2 * G::kCompactThreads * (c >> 1))] = v[c];
+    for (int c = 0; c < 2 * C; ++c) s[compact_lds_index<N, PADDED>(2 * tid + (c & 1) + 2 * G::kCompactThreads * (c >> 1))] = v[c];
 }
 template <int N, bool PADDED>
 __device__ __forceinline__ void lds_to_shared_tile(float2* g, const float2* s, long first_fft, long limit_fft) {
@@ -237,9 +257,14 @@ __device__ __forceinline__ void lds_to_shared_tile(float2* g, const float2* s, l
     constexpr int C = G::kCompactTile / G::kCompactThreads / 2;
     const long ffts = limit_fft - first_fft < G::kCompactFfts ? limit_fft - first_fft : G::kCompactFfts;
     const SharedTile tile(g, ffts * N * 8);
+    int tid = (int)threadIdx.x;
+    // (opaque copy of the thread index HERE ONLY: this copy's addresses are then computed where they are used instead of being carried
+    //  -- and, at N = 32, spilled -- across the applications.  The same in the other three copies frees forty registers and costs the
+    //  N = 32 natural-order kernel 8 % -- same instruction counts, another register assignment; profiles/r06_no_scratch.txt)
+    asm volatile("" : "+v"(tid));
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const int e = 2 * (int)threadIdx.x + 2 * G::kCompactThreads * c;
+        const int e = 2 * tid + 2 * G::kCompactThreads * c;
         tile.store2(e, s[compact_lds_index<N, PADDED>(e)], s[compact_lds_index<N, PADDED>(e + 1)]);
     }
 }
@@ -479,15 +504,26 @@ __device__ __forceinline__ void c2c_multiple_body(const float2* d_input, float2*
         // SmallDft<..., FIXED>), or a chain cut on an odd application would not end with the bits of an uncut one.
         float2 r[16];
         if constexpr (!FUSED) {
-            for (int f = piece.app0; f < piece.app1; ++f) {
+            // (an application's form follows from its number in the chain: unrolled by two like the fused loop, so that load, apply and
+            //  store see their parity at compile time)
+            auto one = [&](auto odd) {
                 priority.at_application();
-                eng.load(r, sf, f);
+                eng.load(r, sf, odd ? 1 : 0);
                 fft_sync<G::kMultiWave>();          // (the wave's loads of the image precede its stores)
-                if (f & 1) eng.apply(r, true);
-                else eng.apply(r, false);
-                eng.store(r, sf, f + 1);
+                eng.apply(r, odd);
+                eng.store(r, sf, odd ? 0 : 1);
                 fft_sync<G::kMultiWave>();
+            };
+            int f = piece.app0;
+            if (f & 1) {
+                one(std::true_type());
+                ++f;
             }
+            for (; f + 1 < piece.app1; f += 2) {
+                one(std::false_type());
+                one(std::true_type());
+            }
+            if (f < piece.app1) one(std::false_type());
         } else {
         eng.load(r, sf, piece.app0);
         int f = piece.app0;

@@ -83,8 +83,7 @@ def built():
 
 
 def test_in_lds_kernels_keep_four_waves_per_simd(built):
-    """the compact `multiple` kernels of the single-wave lengths and every R2C / C2R one: <= 128 VGPRs, nothing spilled -- the
-    two-wave R2C / C2R kernels of L = 2048 may spill set-up values (a handful of dwords), but never inside the application loop"""
+    """the compact `multiple` kernels of the single-wave lengths and every R2C / C2R one: <= 128 VGPRs, nothing spilled"""
     seen = 0
     for n, res in built["res"].items():
         for name, r in res.items():
@@ -92,23 +91,30 @@ def test_in_lds_kernels_keep_four_waves_per_simd(built):
             if single_wave_ct or name.startswith("FFT_GPU_R2C_C2R_multiple<"):
                 seen += 1
                 assert r["vgpr"] <= 128 and r["occ"] >= 4, (name, r)
-                if n <= 1024:
-                    assert r["scratch"] == 0, (name, r)
-                else:
-                    assert r["scratch"] <= 16, (name, r)
+                assert r["scratch"] == 0, (name, r)
     assert seen >= 8 + 6, seen          # 4 CT variants x 2 lengths, 2 RC directions x 3 lengths
 
 
-def test_multi_wave_in_lds_kernels_do_not_spill_in_the_application_loop(built):
-    """N = 2048 / 4096 are compiled for four waves per SIMD (128 registers): whatever they spill, they spill outside the loop over the
-    applications (block depth 2 of the kernel: the loop over a workgroup's pieces is depth 1)"""
+def test_no_in_lds_kernel_has_a_private_segment(built):
+    """Round 6: no shipped `multiple` kernel -- C2C fused and per-call, Stockham, R2C / C2R; N = 32, 64, 2048, 4096 compiled
+    here, 256 / 1024 / 2048 through the resource report above -- holds a scratch instruction anywhere or a private segment: round 5's
+    N = 4096 kernels sat at the 128-register cap with 40-52 bytes per lane spilled around their tile copies (sixteen values in flight
+    while 60 registers of twiddles were alive: the copies now move eight at a time), N = 32's carried addresses of the piece loop
+    across the applications."""
     checked = 0
     for n, isa in built["inst"].items():
         for mangled in re.findall(r"^(_Z\w*(?:SMFFT_DIT_multiple|FFT_GPU_multiple|FFT_GPU_R2C_C2R_multiple)\w*):", isa, re.M):
-            by_depth = _scratch_by_loop_depth(isa, mangled)
-            assert all(d < 2 for d in by_depth), (n, mangled, by_depth)
+            assert not _scratch_by_loop_depth(isa, mangled), (n, mangled, _scratch_by_loop_depth(isa, mangled))
+            m = re.search(r"\.amdhsa_kernel %s\n(.*?)\.end_amdhsa_kernel" % re.escape(mangled), isa, re.S)
+            assert m, mangled
+            seg = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(1))
+            assert seg and int(seg.group(1)) == 0, (n, mangled, seg and seg.group(1))
             checked += 1
-    assert checked >= 7 + 7 + 2, checked
+    assert checked >= 9 + 9 + 7 + 7, checked
+    for n, res in built["res"].items():
+        for name, r in res.items():
+            if "multiple" in name:
+                assert r["scratch"] == 0, (n, name, r)
 
 
 def test_external_kernel_budget(built):
@@ -132,10 +138,13 @@ def _loop_barriers(isa, mangled_fragment, demangled_fragment):
 
 def test_reference_shaped_multiple_loop_barriers_at_4096(built):
     """SMFFT_DIT_multiple<FFT_4096_*> in the reference's shape (1024 threads, NREUSES calls of do_SMFFT_CT_DIT with the loop's own
-    barrier): natural order <= 5 workgroup barriers per application (round 3: 8), no reorder <= 3 (CT:553-572)"""
+    barrier): natural order 4 workgroup barriers per application (round 3: 8, round 5: 5), no reorder 2 (round 5: 3) -- both cross-wave
+    passes behind ONE barrier (quarter_fft's last phase; CT:553-572); N = 2048 the same"""
     isa = built["isa"]
-    assert _loop_barriers(isa, "SMFFT_DIT_multipleI16FFT_4096_forwardE", "SMFFT_DIT_multiple<FFT_4096_forward>") <= 5
-    assert _loop_barriers(isa, "SMFFT_DIT_multipleI26FFT_4096_forward_noreorderE", "SMFFT_DIT_multiple<FFT_4096_forward_noreorder>") <= 3
+    assert _loop_barriers(isa, "SMFFT_DIT_multipleI16FFT_4096_forwardE", "SMFFT_DIT_multiple<FFT_4096_forward>") <= 4
+    assert _loop_barriers(isa, "SMFFT_DIT_multipleI26FFT_4096_forward_noreorderE", "SMFFT_DIT_multiple<FFT_4096_forward_noreorder>") <= 2
+    assert _loop_barriers(isa, "SMFFT_DIT_multipleI16FFT_2048_forwardE", "SMFFT_DIT_multiple<FFT_2048_forward>") <= 4
+    assert _loop_barriers(isa, "SMFFT_DIT_multipleI26FFT_2048_forward_noreorderE", "SMFFT_DIT_multiple<FFT_2048_forward_noreorder>") <= 2
 
 
 def _loops(body):
@@ -174,11 +183,11 @@ def test_lane_engine_applications_stay_in_registers(built):
 
 def test_reference_shaped_multiple_loop_keeps_its_twiddles(built):
     """SMFFT_DIT_multiple<P> in the reference's shape: the twiddles of do_SMFFT_CT_DIT are fetched in front of its first
-    synchronisation, so the loop of NREUSES calls holds no global load for the lengths that keep them (N = 256 ... 1024; N = 2048 keeps
-    all but its last pass) -- DESIGN.md 2.3, CT:553-572"""
+    synchronisation, so the loop of NREUSES calls holds no global load at any length (round 6: N = 2048 / 4096 keep theirs too --
+    56 / 64 registers, still eight waves per SIMD) -- DESIGN.md 2.3, CT:553-572"""
     isa = built["isa"]
     for frag, allowed in (("SMFFT_DIT_multipleI15FFT_256_forwardE", 0), ("SMFFT_DIT_multipleI16FFT_1024_forwardE", 0), ("SMFFT_DIT_multipleI26FFT_1024_forward_noreorderE", 0),
-                          ("SMFFT_DIT_multipleI16FFT_2048_forwardE", 1)):
+                          ("SMFFT_DIT_multipleI16FFT_2048_forwardE", 0), ("SMFFT_DIT_multipleI16FFT_4096_forwardE", 0), ("SMFFT_DIT_multipleI26FFT_4096_forward_noreorderE", 0)):
         m = re.search(r"^(_Z\w*%s\w*):[^\n]*\n(.*?)\n\s*s_endpgm" % frag, isa, re.S | re.M)
         assert m, frag
         body = m.group(2).split("\n")
