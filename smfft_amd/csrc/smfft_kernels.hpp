@@ -610,9 +610,17 @@ __device__ __forceinline__ void c2c_multiple_body_planar(const float2* d_input, 
                 eng.image_store(r);
             }
         } else {
+#ifdef SMFFT_TIMING_ONLY_NOREORDER_FORWARD
+            // TIMING ONLY (wrong results; tools/noreorder_bound.sh): the no-reorder loop WITHOUT its bit-reversed re-read -- what the kernel
+            // would cost if an application's results could be forwarded in registers as the natural-order kernel's are (DESIGN.md 5.2 shows
+            // why they cannot: the sixteen results of a thread are a coset of index bits, its sixteen inputs a contiguous block)
+            eng.image_load_bitrev(r, planes);
+#endif
             for (int f = 0; f < napps; ++f) {
                 priority.at_application();
+#ifndef SMFFT_TIMING_ONLY_NOREORDER_FORWARD
                 eng.image_load_bitrev(r, planes);
+#endif
                 eng.transform_from_pass1_slots(r, planes);
                 planar_sync<G::kMultiWave>();
                 eng.image_store(r);
