@@ -433,7 +433,20 @@ struct QuarterLanes {
 #ifndef SMFFT_QUARTER_PHASES
 #define SMFFT_QUARTER_PHASES 1         // 0: the round-5 form (A/B)
 #endif
-template <int N, int DIR, int REORDER, int BLOCK_THREADS, bool IN_REGS = false, bool OUT_REGS = false, int ENGINE = 0>
+// OUT_PHASED (with OUT_REGS; round 6): the results stay in x[] WHERE THE LAST PHASE LEAVES THEM -- x[i] = element quarter_phased_element<N>(t, i)
+// of the transform -- so that N = 2048 / 4096 can take the last phase with registers out as well (for N <= 1024 that is t + i N/4, as without it).
+template <int N>
+__device__ __forceinline__ int quarter_phased_element(int t, int i) {
+    constexpr int N_BITS = ilog2c(N), LOW = 16 - N_BITS;
+    if constexpr (N < 2048 || SMFFT_QUARTER_LANES == 0 || SMFFT_QUARTER_PHASES == 0) {
+        return t + i * (N / 4);
+    } else {
+        const int lane = t & 63, wave = t >> 6;
+        const int k_last = (lane & ((1 << LOW) - 1)) | (wave << LOW) | ((lane >> LOW) << 8);
+        return N_BITS == 12 ? k_last + 1024 * i : k_last + 1024 * (i & 1) + 512 * (i >> 1);
+    }
+}
+template <int N, int DIR, int REORDER, int BLOCK_THREADS, bool IN_REGS = false, bool OUT_REGS = false, int ENGINE = 0, bool OUT_PHASED = false>
 __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, int region_offset = 0) {
     constexpr bool kLanesOn = ENGINE == 2 || (ENGINE == 0 && SMFFT_QUARTER_LANES != 0);
     constexpr bool kPhases = kLanesOn && SMFFT_QUARTER_PHASES != 0;
@@ -457,7 +470,8 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
     constexpr bool kLanesHead = (kLanes512 && !REORDER) || kOneWaveHead;
     constexpr bool kLanesMiddle = (kLanes512 && REORDER) || kOneWaveNatural;
     constexpr bool kSlots23 = kLanesMiddle && kPhases;          // phase 1 reads slots = position bits (2, 3)
-    constexpr bool kLastPhase = kPhases && N >= 2048 && !OUT_REGS && (kLanesHead || kLanesMiddle);
+    static_assert(!OUT_PHASED || OUT_REGS, "OUT_PHASED qualifies OUT_REGS");
+    constexpr bool kLastPhase = kPhases && N >= 2048 && (!OUT_REGS || OUT_PHASED) && (kLanesHead || kLanesMiddle);
     constexpr int kFirstLdsPass = (kLanesHead || kLanesMiddle) ? 4 : 1;
     // the thread of the last phase: lanes 0 ... LOW-1 = position bits 0 ... LOW-1, wave = the bits up to 7, slots = bits (8, 9), the other
     // lane bits = bits 10 (, 11); after the exchange in front of the last pass those lane bits hold bits 8 (, 9)
@@ -557,6 +571,11 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
             slots_swap<0, 4, true>(e);
             slots_swap<1, 5, true>(e);
             quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(5), tw.late(5));
+            if constexpr (OUT_REGS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = e[i];           // elements k_last + 1024 i (quarter_phased_element)
+                return;
+            }
             fft_sync<false>();                                     // the wave's loads precede its stores into the same words
 #pragma unroll
             for (int i = 0; i < 4; ++i) sf[k_last + 1024 * i] = e[i];
@@ -565,6 +584,10 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
             const float2 w = tw.wr;
             const float2 t1 = cmul(e[1], w), v3 = cmul(e[3], w);
             const float2 t3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);
+            if constexpr (OUT_REGS) {                              // elements k_last, + 1024, + 512, + 1536
+                x[0] = cadd(e[0], t1), x[1] = csub(e[0], t1), x[2] = cadd(e[2], t3), x[3] = csub(e[2], t3);
+                return;
+            }
             fft_sync<false>();
             sf[k_last] = cadd(e[0], t1);
             sf[k_last + N / 2] = csub(e[0], t1);
@@ -730,6 +753,25 @@ __device__ void do_FFT_Stockham_C2C_registers(float2 (&x)[4], float2* s_scratch)
     constexpr int N = const_params::fft_length;
     smfft::quarter_fft<N, const_direction::fft_direction, 1, N / 4, true, true>(x, s_scratch, threadIdx.x);
 }
+// ... and with the results left where the transform's last phase puts them (round 6): x[i] = element element[i] of the result on return --
+// threadIdx.x + i N/4 for N <= 1024; for N = 2048 / 4096 the sixteen-element runs of smfft::quarter_phased_element, which spare those lengths
+// a trip through LDS and a barrier (a kernel that stores its results to global memory does not care which thread stores which element;
+// a store instruction of a wave still writes four 128-byte runs).  Inputs as for do_SMFFT_CT_DIT_registers.
+template <class const_params>
+__device__ void do_SMFFT_CT_DIT_registers_out(float2 (&x)[4], float2* s_scratch, int (&element)[4]) {
+    constexpr int N = const_params::fft_size;
+    static_assert(N >= 256 && const_params::fft_length == N, "one transform per block of N / 4 threads");
+    smfft::quarter_fft<N, const_params::fft_direction, const_params::fft_reorder, N / 4, true, true, 0, true>(x, s_scratch, threadIdx.x);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) element[i] = smfft::quarter_phased_element<N>(threadIdx.x, i);
+}
+template <class const_params, class const_direction>
+__device__ void do_FFT_Stockham_C2C_registers_out(float2 (&x)[4], float2* s_scratch, int (&element)[4]) {
+    constexpr int N = const_params::fft_length;
+    smfft::quarter_fft<N, const_direction::fft_direction, 1, N / 4, true, true, 0, true>(x, s_scratch, threadIdx.x);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) element[i] = smfft::quarter_phased_element<N>(threadIdx.x, i);
+}
 
 template <class const_params>
 __device__ void do_FFT_Stockham_mk6(float2* s_input) {
@@ -810,9 +852,10 @@ __global__ void SMFFT_DIT_external(float2* d_input, float2* d_output) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
             x[m] = const_params::fft_reorder ? d_input[block + threadIdx.x + m * const_params::fft_length_quarter] : d_input[block + 4 * threadIdx.x + m];
-        do_SMFFT_CT_DIT_registers<const_params>(x, s_input);
+        int element[4];
+        do_SMFFT_CT_DIT_registers_out<const_params>(x, s_input, element);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) d_output[block + threadIdx.x + m * const_params::fft_length_quarter] = x[m];
+        for (int m = 0; m < 4; ++m) d_output[block + element[m]] = x[m];
         return;
     }
     const int base = threadIdx.x + blockIdx.x * const_params::fft_length;
@@ -867,9 +910,10 @@ __global__ void FFT_GPU_external(float2* d_input, float2* d_output) {
         float2 x[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) x[k] = d_input[base + k * const_params::fft_quarter];
-        do_FFT_Stockham_C2C_registers<const_params, FFT_inverse>(x, s_input);
+        int element[4];
+        do_FFT_Stockham_C2C_registers_out<const_params, FFT_inverse>(x, s_input, element);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) d_output[base + k * const_params::fft_quarter] = x[k];
+        for (int k = 0; k < 4; ++k) d_output[base - threadIdx.x + element[k]] = x[k];
         return;
     }
 #pragma unroll
@@ -925,9 +969,9 @@ __global__ void FFT_GPU_R2C_C2R_external(float2* d_input, float2* d_output) {
             __syncthreads();
             smfft::hermitian_pass_quarter<L, 1>(s_input, threadIdx.x, herm);
             __syncthreads();
-            smfft::quarter_fft<L, 1, 1, L / 4, false, true>(x, s_input, threadIdx.x);
+            smfft::quarter_fft<L, 1, 1, L / 4, false, true, 0, true>(x, s_input, threadIdx.x);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) d_output[base + k * const_params::fft_quarter] = x[k];
+            for (int k = 0; k < 4; ++k) d_output[base - threadIdx.x + smfft::quarter_phased_element<L>(threadIdx.x, k)] = x[k];
         }
         return;
     }

@@ -9,9 +9,17 @@ import sys
 d = sys.argv[1]
 total = int(sys.argv[2]) if len(sys.argv) > 2 else (1 << 29)
 agg = collections.defaultdict(list)
-for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+# (gpurun merges every call's files into gpurun_out/: only the LATEST run's csv of a directory is read)
+import os
+for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]:
     for r in csv.DictReader(open(f)):
-        agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        # the reference-shaped kernels of include/smfft/smfft_device_functions.hpp carry the library's kernels' NAMES with two arguments:
+        # kept apart by their signature
+        full = r["Kernel_Name"]
+        name = full.split("(")[0]
+        if re.search(r"\(HIP_vector_type<float, 2u>( const)?\*, HIP_vector_type<float, 2u>\*\)$", full):
+            name += " [reference shape <<<nFFTs, N/4>>>]"
+        agg[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
 names = sorted({k[0] for k in agg})
 for name in names:
     m = re.search(r"FFT_(\d+)", name)
