@@ -402,6 +402,118 @@ struct QuarterLanes {
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// N = 64, 128 (N = 32 is written out as well, and loses: below), natural order (round 6): the road N = 256 takes (quarter_fft's phases) for the lengths of which a block holds SEVERAL
+// transforms -- upstream's 32 threads = 128 / N of them (CT:586-595), the _wave64 classes' 64 threads = 256 / N; all in one wave.
+// Pass 0 on x[t + m N/4], ONE trip through the block's image -- results 4 rev(t) + i scattered, read back with slots = index bits (2, 3),
+// lane bits 0, 1 = bits 0, 1 of the thread's index in its transform, the bits above = index bits 4 ... -- then pass 1 at once, the exchange
+// with lane bits 2, 3 (selects) and pass 2 (N >= 64), and the radix-2 pass of N = 128 (slot bit 0 <-> lane bit 4: v_permlane16_swap) / N = 32
+// (slot bit 0 <-> lane bit 2).  Against QuarterLanes::lds_to_lds (every exchange on lanes): sixteen DPP-fed selects per thread and
+// transform fewer (N = 128: 32 + 4 swaps -> 16 + 4; N = 64: 32 -> 16; N = 32: 24 -> 8) for four ds_write_b64 + four ds_read_b64 on an
+// LDS unit these kernels leave idle, and a thread ends with elements u + (N/4) i: a lane-linear natural store where the ladder stored
+// bit-reversed lanes.  Images (tools/quarter_phases_model.py searched them; both accesses conflict free for 32- and 64-thread blocks):
+// address bit b of the BLOCK-level index q = f N + p takes the parity of q & mask[b] in -- GF(2)-linear, triangular (a bijection of every
+// aligned group of 32 elements), the identity on 0 ... 3.
+template <int N>
+__host__ __device__ constexpr int quarter_small_image(int q) {
+    constexpr int m0 = N == 32 ? 144 : 16, m1 = N == 128 ? 64 : 4, m2 = N == 128 ? 96 : N == 64 ? 72 : 32, m3 = N == 32 ? 64 : 32;
+    return q ^ (__builtin_popcount(q & m0) & 1) ^ ((__builtin_popcount(q & m1) & 1) << 1) ^ ((__builtin_popcount(q & m2) & 1) << 2) ^ ((__builtin_popcount(q & m3) & 1) << 3);
+}
+template <int N, int DIR>
+__device__ __forceinline__ void quarter_small_natural(float2* s, int t, int region_offset) {
+    static_assert(N == 32 || N == 64 || N == 128, "N = 256 and above: quarter_fft");
+    constexpr int Q = N / 4, T_BITS = ilog2c(Q);
+    QuarterTwiddles<N, DIR, 1> tw;
+    tw.load(t, t);                                           // k = t mod P in every pass: lane bits 0 ... hold index bits 0 ... by the time a pass needs them
+    float2* sf = s + region_offset;
+    float2 e[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) e[((m & 1) << 1) | (m >> 1)] = sf[t + m * Q];
+    const int a = 4 * (int)(__brev((unsigned)t) >> (32 - T_BITS));
+    fft_sync<false>();                                       // the wave's loads precede its scattered stores (every transform of the block is in this wave)
+    {
+        const float2 s0 = cadd(e[0], e[1]), d0 = csub(e[0], e[1]), s1 = cadd(e[2], e[3]), d1 = csub(e[2], e[3]);
+        const float2 jd1 = DIR ? make_float2(-d1.y, d1.x) : make_float2(d1.y, -d1.x);
+        const int a0 = quarter_small_image<N>(region_offset + a);
+        s[a0] = cadd(s0, s1), s[a0 ^ 2] = csub(s0, s1), s[a0 ^ 1] = cadd(d0, jd1), s[a0 ^ 3] = csub(d0, jd1);
+    }
+    fft_sync<false>();
+    const int p1 = N == 128 ? ((t & 3) | (((t >> 2) & 3) << 4) | ((t >> 4) << 6)) : ((t & 3) | ((t >> 2) << 4));
+    const int b0 = quarter_small_image<N>(region_offset + p1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e[j] = s[b0 ^ quarter_small_image<N>(4 * j)];
+    quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(1), tw.late(1));
+    if constexpr (N >= 64) {
+        slots_swap<0, 2, true>(e);
+        slots_swap<1, 3, true>(e);
+        quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(2), tw.late(2));
+    }
+    fft_sync<false>();                                       // the wave's loads of the image precede its natural stores
+    if constexpr (N == 64) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sf[t + 16 * i] = e[i];
+    } else {
+        slots_swap<0, N == 128 ? 4 : 2, true>(e);            // slots = (the top index bit, the one below): elements t, t + N/2, t + N/4, t + 3N/4
+        const float2 w = tw.wr;
+        const float2 t1 = cmul(e[1], w), v3 = cmul(e[3], w);
+        const float2 t3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);
+        sf[t] = cadd(e[0], t1);
+        sf[t + N / 2] = csub(e[0], t1);
+        sf[t + Q] = cadd(e[2], t3);
+        sf[t + 3 * Q] = csub(e[2], t3);
+    }
+}
+
+// ... and without reorder (N = 64, 128): the ladder of QuarterLanes with its MIDDLE exchange -- lane bits 2, 3, sixteen DPP-fed selects --
+// through the block's image instead (the block-level form of QuarterLanes<256>::run_exchanged: same image q ^ ((q >> 2) & 28), which also
+// keeps the two transforms that share a 32-lane read group of N = 64 apart).  The re-read deals the lanes afresh: slots = index bits (4, 5),
+// lane bits 0 ... 3 = bits 0 ... 3, lane bit 4 = bit 6 (N = 128: its radix-2 pass behind a v_permlane16_swap).
+// (N = 32, either ordering: the trip through LDS measured 21 % SLOWER than its three exchanges on lanes -- eight lanes per transform leave
+//  the natural accesses 4-way conflicted and the vector work is small; it keeps QuarterLanes.  profiles/r06_contract_small.txt)
+template <int N, int DIR>
+__device__ __forceinline__ void quarter_small_noreorder(float2* s, int t, int region_offset) {
+    static_assert(N == 64 || N == 128, "N = 256 and above: quarter_fft; N = 32: QuarterLanes");
+    constexpr int Q = N / 4;
+    QuarterTwiddles<N, DIR, 0> tw;
+    tw.load(t, t);
+    float2* sf = s + region_offset;
+    float2 e[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = sf[4 * t + i];
+    {   // pass 0: twiddles 1, 1, -+i
+        const float2 s0 = cadd(e[0], e[1]), d0 = csub(e[0], e[1]), s1 = cadd(e[2], e[3]), d1 = csub(e[2], e[3]);
+        const float2 jd1 = DIR ? make_float2(-d1.y, d1.x) : make_float2(d1.y, -d1.x);
+        e[0] = cadd(s0, s1), e[1] = cadd(d0, jd1), e[2] = csub(s0, s1), e[3] = csub(d0, jd1);
+    }
+    slots_swap<0, 0, true>(e);
+    slots_swap<1, 1, true>(e);
+    quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(1), tw.late(1));
+    fft_sync<false>();                                       // the wave's loads precede its stores into the block
+    // slots = index bits (2, 3); lane bits 0, 1 = bits 0, 1; the lane bits above = bits 4 ...
+    const int p0 = QuarterLanes<256, DIR, 0>::exchange_image(region_offset + (t & 3) + 16 * (t >> 2));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[p0 ^ (4 * j)] = e[j];
+    fft_sync<false>();
+    const int q0 = QuarterLanes<256, DIR, 0>::exchange_image(region_offset + (t & 15) + 64 * (t >> 4));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e[j] = s[q0 ^ QuarterLanes<256, DIR, 0>::exchange_image(16 * j)];
+    quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(2), tw.late(2));
+    fft_sync<false>();
+    if constexpr (N == 64) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sf[t + 16 * i] = e[i];
+    } else {
+        slots_swap<0, 4, true>(e);                           // slots = (bit 6, bit 5): elements t, t + 64, t + 32, t + 96
+        const float2 w = tw.wr;
+        const float2 t1 = cmul(e[1], w), v3 = cmul(e[3], w);
+        const float2 t3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);
+        sf[t] = cadd(e[0], t1);
+        sf[t + N / 2] = csub(e[0], t1);
+        sf[t + Q] = cadd(e[2], t3);
+        sf[t + 3 * Q] = csub(e[2], t3);
+    }
+}
+
 // BLOCK_THREADS: threads the caller's block has (what decides between a wave-level fence and a workgroup barrier);
 // s: the block's LDS region, region_offset: where this thread's transform starts in it (f * N).
 // IN_REGS: the first pass takes its four inputs from x[] instead of loading them from s -- x[m] = element t + m N/4 (natural
@@ -451,6 +563,11 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
     constexpr bool kLanesOn = ENGINE == 2 || (ENGINE == 0 && SMFFT_QUARTER_LANES != 0);
     constexpr bool kPhases = kLanesOn && SMFFT_QUARTER_PHASES != 0;
     constexpr bool kOneWaveNatural = kPhases && N == 256 && REORDER && BLOCK_THREADS <= 64;      // phase 0 + phase 1 inside one wave
+    if constexpr (kPhases && (N == 64 || N == 128) && !IN_REGS && !OUT_REGS && BLOCK_THREADS <= 64) {      // one trip through the block's image instead of an exchange (two) on lanes
+        if constexpr (REORDER) quarter_small_natural<N, DIR>(s, t, region_offset);
+        else quarter_small_noreorder<N, DIR>(s, t, region_offset);
+        return;
+    }
     if constexpr ((ENGINE == 2 || (ENGINE == 0 && quarter_lanes_default(N))) && N <= 256 && !OUT_REGS && !kOneWaveNatural && !(kPhases && N == 256 && !REORDER && BLOCK_THREADS <= 64)) {   // the ladder on lanes and registers (QuarterLanes above)
         QuarterLanes<N, DIR, REORDER>::template lds_to_lds<IN_REGS>(x, s, t, region_offset);
         return;

@@ -85,6 +85,24 @@ def test_phased_form_of_the_ladder_is_the_dft_and_conflict_free():
         assert total == ideal + 16 * 4 * 2, (reorder, total, ideal)      # sixteen waves x four reads x two extra cycles
 
 
+@pytest.mark.parametrize("n", [64, 128])
+@pytest.mark.parametrize("lanes", [32, 64])
+def test_small_lengths_take_one_trip_through_the_blocks_image(n, lanes):
+    """N = 64 / 128 on the reference's contract (quarter_small_natural / quarter_small_noreorder; upstream's 32-thread blocks and the 64-thread
+    _wave64 classes): replayed in NumPy against numpy.fft inside check(); here: the scattered stores of pass 0 and the slot-(2,3) read-back of the
+    natural-order form are conflict free under the gfx950 lane-group rules in both block shapes (the no-reorder form's exchange is checked
+    inside check()); what conflicts is the contract's own natural layout of several transforms per wave."""
+    import numpy as np
+    import quarter_phases_model as qp
+    log = []
+    qp.transform_small(n, 0, np.zeros((lanes // (n // 4), n), complex), log)
+    assert len(log) == 16
+    for kind, addr in log[4:12]:                     # four scattered stores, four reads
+        group, banks = (32, 32) if kind == "r" else (16, 16)
+        for g in range(0, lanes, group):
+            assert len({a % banks for a in addr[g:g + group]}) == group, (n, lanes, kind)
+
+
 def test_header_computes_the_phase_images(tmp_path):
     hipcc = "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -95,7 +113,8 @@ def test_header_computes_the_phase_images(tmp_path):
 #include <cstdio>
 #include "smfft_device.hpp"
 int main() {
-    for (int i = 0; i < 256; ++i) printf("%d %d\n", smfft::quarter_image256(i), smfft::QuarterLanes<256, 0, 0>::exchange_image(i));
+    for (int i = 0; i < 256; ++i) printf("%d %d %d %d %d\n", smfft::quarter_image256(i), smfft::QuarterLanes<256, 0, 0>::exchange_image(i),
+                                         smfft::quarter_small_image<32>(i), smfft::quarter_small_image<64>(i), smfft::quarter_small_image<128>(i));
     return 0;
 }
 ''')
@@ -103,4 +122,4 @@ int main() {
     subprocess.check_call([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
                           stderr=subprocess.DEVNULL)
     got = [tuple(int(v) for v in line.split()) for line in subprocess.check_output([str(exe)], text=True).splitlines()]
-    assert got == [(qp.image256(i), qp.exchange_image(i)) for i in range(256)]
+    assert got == [(qp.image256(i), qp.exchange_image(i), qp.small_image(32, i), qp.small_image(64, i), qp.small_image(128, i)) for i in range(256)]

@@ -295,6 +295,221 @@ def image256(p):
     return p ^ ((p >> 7) & 1) ^ ((p >> 5) & 2) ^ ((p >> 3) & 4) ^ ((p >> 1) & 8) ^ ((p >> 2) & 16)
 
 
+# ---- N = 32, 64, 128, natural order (round 6): the same road as N = 256 -- pass 0, ONE trip through the block's image, read back with
+# slots = position bits (2, 3) -- for the transforms of which a block holds several (upstream: 32 threads = 128 / N transforms; the _wave64
+# classes: 64 threads = 256 / N).  Images: address bit b of the block-level index q = f N + p takes the parity of q & SMALL_MASKS[N][b] in
+# (found by search_small(): scattered stores and slot-(2,3) reads conflict free for 32- and 64-thread blocks).
+SMALL_MASKS = {128: [16, 64, 96, 32, 0], 64: [16, 4, 72, 32, 0], 32: [144, 4, 32, 64, 0]}
+
+
+def small_image(N, q):
+    a = q
+    for b, m in enumerate(SMALL_MASKS[N]):
+        if bin(q & m).count("1") & 1:
+            a ^= 1 << b
+    return a
+
+
+def small_readback_position(N, u, j):
+    """position (within its transform) that the thread with index u in its transform reads into slot j"""
+    if N == 128:
+        return (u & 3) | (j << 2) | (((u >> 2) & 3) << 4) | ((u >> 4) << 6)
+    return (u & 3) | (j << 2) | ((u >> 2) << 4)
+
+
+def transform_small(N, DIR, xs, log=None):
+    """xs: (transforms of the block, N) natural-order inputs; returns their DFTs.  One wave: lane = f Q + u"""
+    F = xs.shape[0]
+    Q, TB = N // 4, (N // 4).bit_length() - 1
+    lanes = F * Q
+    assert lanes in (32, 64)
+    sign = 1 if DIR else -1
+    img = np.zeros(F * N, complex)
+
+    def note(kind, addr):
+        if log is not None:
+            log.append((kind, list(addr) + [addr[0]] * (64 - len(addr))))      # (inactive lanes of a 32-thread block take no part)
+    stores = [[] for _ in range(4)]
+    for m in range(4):
+        note("r", [(l // Q) * N + (l % Q) + m * Q for l in range(lanes)])
+    for l in range(lanes):
+        f, u = l // Q, l % Q
+        e = [0] * 4
+        for m in range(4):
+            e[((m & 1) << 1) | (m >> 1)] = xs[f, u + m * Q]
+        s0, d0, s1, d1 = e[0] + e[1], e[0] - e[1], e[2] + e[3], e[2] - e[3]
+        jd1 = d1 * (1j * sign)
+        a = f * N + 4 * rev(u, TB)
+        for i, v in enumerate([s0 + s1, d0 + jd1, s0 - s1, d0 - jd1]):
+            img[small_image(N, a + i)] = v
+            stores[i].append(small_image(N, a + i))
+    for i in range(4):
+        note("w", stores[i])
+    E = np.zeros((lanes, 4), complex)
+    P_ = np.zeros((lanes, 4), int)
+    for j in range(4):
+        addr = []
+        for l in range(lanes):
+            f, u = l // Q, l % Q
+            p = small_readback_position(N, u, j)
+            E[l, j], P_[l, j] = img[small_image(N, f * N + p)], p
+            addr.append(small_image(N, f * N + p))
+        note("r", addr)
+
+    def swap(slot_bit, lane_bit):
+        nonlocal E, P_
+        ne, npos = E.copy(), P_.copy()
+        for l in range(lanes):
+            partner = l ^ (1 << lane_bit)
+            for i in range(4):
+                if (i >> slot_bit) & 1:
+                    continue
+                hi = i | (1 << slot_bit)
+                if (l >> lane_bit) & 1 == 0:
+                    ne[l, hi], npos[l, hi] = E[partner, i], P_[partner, i]
+                else:
+                    ne[l, i], npos[l, i] = E[partner, hi], P_[partner, hi]
+        E, P_ = ne, npos
+    for l in range(lanes):
+        E[l] = quad(E[l], P_[l], 4, sign)
+    if N >= 64:
+        swap(0, 2)
+        swap(1, 3)
+        for l in range(lanes):
+            E[l] = quad(E[l], P_[l], 16, sign)
+    out = np.zeros((F, N), complex)
+    if N == 64:
+        for i in range(4):
+            note("w", [(l // Q) * N + int(P_[l, i]) for l in range(lanes)])
+        for l in range(lanes):
+            for i in range(4):
+                assert int(P_[l, i]) == (l % Q) + 16 * i
+                out[l // Q, int(P_[l, i])] = E[l, i]
+        return out
+    swap(0, 4 if N == 128 else 2)
+    half = N // 2
+    for l in range(lanes):
+        u = l % Q
+        assert [int(q) for q in P_[l]] == [u, u + half, u + Q, u + half + Q], (N, l, P_[l])
+        wv = np.exp(sign * 2j * np.pi * u / N)
+        x0, x1, x2, x3 = E[l]
+        t1, t3 = x1 * wv, x3 * wv * (1j * sign)
+        out[l // Q, u], out[l // Q, u + half], out[l // Q, u + Q], out[l // Q, u + half + Q] = x0 + t1, x0 - t1, x2 + t3, x2 - t3
+    for off in (0, half, Q, half + Q):
+        note("w", [(l // Q) * N + (l % Q) + off for l in range(lanes)])
+    return out
+
+
+def transform_small_noreorder(N, DIR, xs, log=None):
+    """N = 64, 128 without reorder (quarter_small_noreorder): pass 0 on x[4 u + i], the exchange with lane bits 0, 1, pass 1, the MIDDLE exchange
+    through the block's image (exchange_image of the block-level index), pass 2, and N = 128's radix-2 pass behind a swap with lane bit 4"""
+    F = xs.shape[0]
+    Q = N // 4
+    lanes = F * Q
+    sign = 1 if DIR else -1
+    img = np.zeros(F * N, complex)
+    E = np.zeros((lanes, 4), complex)
+    P_ = np.zeros((lanes, 4), int)
+
+    def note(kind, addr):
+        if log is not None:
+            log.append((kind, list(addr) + [addr[0]] * (64 - len(addr))))
+
+    def swap(slot_bit, lane_bit):
+        nonlocal E, P_
+        ne, npos = E.copy(), P_.copy()
+        for l in range(lanes):
+            partner = l ^ (1 << lane_bit)
+            for i in range(4):
+                if (i >> slot_bit) & 1:
+                    continue
+                hi = i | (1 << slot_bit)
+                if (l >> lane_bit) & 1 == 0:
+                    ne[l, hi], npos[l, hi] = E[partner, i], P_[partner, i]
+                else:
+                    ne[l, i], npos[l, i] = E[partner, hi], P_[partner, hi]
+        E, P_ = ne, npos
+    for l in range(lanes):
+        f, u = l // Q, l % Q
+        e = [xs[f, 4 * u + i] for i in range(4)]
+        s0, d0, s1, d1 = e[0] + e[1], e[0] - e[1], e[2] + e[3], e[2] - e[3]
+        jd1 = d1 * (1j * sign)
+        E[l] = [s0 + s1, d0 + jd1, s0 - s1, d0 - jd1]
+        P_[l] = [4 * u + i for i in range(4)]
+    swap(0, 0)
+    swap(1, 1)
+    for l in range(lanes):
+        E[l] = quad(E[l], P_[l], 4, sign)
+    for j in range(4):
+        addr = []
+        for l in range(lanes):
+            f, u = l // Q, l % Q
+            p = (u & 3) + 4 * j + 16 * (u >> 2)
+            assert int(P_[l, j]) == p
+            img[exchange_image(f * N + p)] = E[l, j]
+            addr.append(exchange_image(f * N + p))
+        note("w", addr)
+    for j in range(4):
+        addr = []
+        for l in range(lanes):
+            f, u = l // Q, l % Q
+            p = (u & 15) + 16 * j + 64 * (u >> 4)
+            E[l, j], P_[l, j] = img[exchange_image(f * N + p)], p
+            addr.append(exchange_image(f * N + p))
+        note("r", addr)
+    for l in range(lanes):
+        E[l] = quad(E[l], P_[l], 16, sign)
+    out = np.zeros((F, N), complex)
+    if N == 64:
+        for l in range(lanes):
+            for i in range(4):
+                assert int(P_[l, i]) == (l % Q) + 16 * i
+                out[l // Q, int(P_[l, i])] = E[l, i]
+        return out
+    swap(0, 4)
+    for l in range(lanes):
+        u = l % Q
+        assert [int(q) for q in P_[l]] == [u, u + 64, u + 32, u + 96]
+        wv = np.exp(sign * 2j * np.pi * u / N)
+        x0, x1, x2, x3 = E[l]
+        t1, t3 = x1 * wv, x3 * wv * (1j * sign)
+        out[l // Q, u], out[l // Q, u + 64], out[l // Q, u + 32], out[l // Q, u + 96] = x0 + t1, x0 - t1, x2 + t3, x2 - t3
+    return out
+
+
+def search_small(N, trials=200000, seed=1):
+    """random search over images whose address bits 0 ... 4 take the parity of at most two HIGHER bits of the block-level index in: the first
+    found with scattered stores (groups of 16 contiguous lanes, mod 16) and slot-(2,3) reads (groups of 32, mod 32) conflict free for
+    blocks of 32 and of 64 threads"""
+    import random
+    rnd = random.Random(seed)
+    Q, TB = N // 4, (N // 4).bit_length() - 1
+    cand = [[m for m in range(256) if m & ((1 << (b + 1)) - 1) == 0 and bin(m).count("1") <= 2] for b in range(5)]
+
+    def image(q, masks):
+        a = q
+        for b, m in enumerate(masks):
+            if bin(q & m).count("1") & 1:
+                a ^= 1 << b
+        return a
+
+    def free(masks, lanes):
+        for i in range(4):
+            row = [image((l // Q) * N + 4 * rev(l % Q, TB) + i, masks) for l in range(lanes)]
+            if any(len({a % 16 for a in row[g:g + 16]}) != 16 for g in range(0, lanes, 16)):
+                return False
+        for j in range(4):
+            row = [image((l // Q) * N + small_readback_position(N, l % Q, j), masks) for l in range(lanes)]
+            if any(len({a % 32 for a in row[g:g + 32]}) != 32 for g in range(0, lanes, 32)):
+                return False
+        return True
+    for _ in range(trials):
+        masks = [rnd.choice(cand[b]) for b in range(5)]
+        if free(masks, 32) and free(masks, 64):
+            return masks
+    return None
+
+
 def check(verbose=False):
     worst = 0.0
     rng = np.random.default_rng(1)
@@ -310,7 +525,55 @@ def check(verbose=False):
                 worst = max(worst, err)
                 if verbose:
                     print(f"N={N} dir={DIR} reorder={REO}: max error {err:.2e}")
+    for N in (32, 64, 128):
+        for lanes in (32, 64):
+            F = lanes // (N // 4)
+            for DIR in (0, 1):
+                xs = rng.standard_normal((F, N)) + 1j * rng.standard_normal((F, N))
+                got = transform_small(N, DIR, xs)
+                want = (np.fft.ifft(xs, axis=-1) * N) if DIR else np.fft.fft(xs, axis=-1)
+                err = np.abs(got - want).max() / np.abs(want).max()
+                worst = max(worst, err)
+                if verbose:
+                    print(f"N={N} natural order, {lanes}-thread block ({F} transforms) dir={DIR}: max error {err:.2e}")
+                if N >= 64:
+                    log = []
+                    got = transform_small_noreorder(N, DIR, xs, log)
+                    xr = xs[:, n_rev(N)]
+                    want = (np.fft.ifft(xr, axis=-1) * N) if DIR else np.fft.fft(xr, axis=-1)
+                    err = np.abs(got - want).max() / np.abs(want).max()
+                    worst = max(worst, err)
+                    for kind, addr in log:      # the middle exchange through the block's image: conflict free in both block shapes
+                        group, banks = (32, 32) if kind == "r" else (16, 16)
+                        for g in range(0, lanes, group):
+                            assert len({a % banks for a in addr[g:g + group]}) == group, (N, lanes, kind)
+                    if verbose:
+                        print(f"N={N} no reorder, {lanes}-thread block dir={DIR}: max error {err:.2e}; exchange conflict free")
     return worst
+
+
+def lds_report_small(N, lanes):
+    log = []
+    F = lanes // (N // 4)
+    transform_small(N, 0, np.zeros((F, N), complex), log)
+    groups = 1 if lanes == 32 else 2
+    total = ideal = 0
+    for kind, addr in log:
+        a = addr[:lanes] + [addr[0]] * (64 - lanes)
+        if kind == "r":
+            c = sum(max(collections_count([x % 32 for x in set(a[g:g + 32])])) for g in range(0, lanes, 32))
+            total, ideal = total + c, ideal + groups
+        else:
+            c = sum(max(collections_count([x % 16 for x in set(a[g:g + 16])])) for g in range(0, lanes, 16))
+            total, ideal = total + max(6, c), ideal + 6
+    return total, ideal
+
+
+def collections_count(values):
+    load = {}
+    for v in values:
+        load[v] = load.get(v, 0) + 1
+    return load.values()
 
 
 if __name__ == "__main__":
@@ -320,6 +583,9 @@ if __name__ == "__main__":
         print(len(sols), "conflict-free images of N = 256; the header's is one of them:", M256 in sols)
     assert all(apply_rows(M256, p) == image256(p) for p in range(256))
     print("worst relative error", check(verbose=True))
+    for N in (32, 64, 128):
+        for lanes in (32, 64):
+            print(f"N={N} natural order, {lanes}-thread block: LDS cycles / conflict free {lds_report_small(N, lanes)}")
     for N in (256, 512, 1024, 2048, 4096):
         for REO in (1, 0):
             total, ideal, count = lds_report(N, REO)
