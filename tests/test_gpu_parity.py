@@ -1614,6 +1614,33 @@ def test_bench_two_ranks_on_one_device(sm):
     assert len(doc["pair_search"]) >= 1 and sum(a["kept"] for a in doc["pair_search"]) == 1
 
 
+@pytest.mark.parametrize("require", [0, 1])
+def test_bench_rccl_that_cannot_come_up_falls_back_or_fails_on_every_rank(sm, require):
+    """The RCCL path FAILS INSTEAD OF HANGING.  Two ranks pinned to ONE device with the default backend: RCCL refuses
+    ("Duplicate GPU detected") -- a communicator that cannot come up, on real hardware.  bench.py decides once for all ranks over the gloo
+    group that is already up: both ranks reduce their timings over gloo and the line says so (require = 0), or, with
+    SMFFT_BENCH_REQUIRE_RCCL=1, every rank exits with code 3.  Seconds either way, never a hang."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "SMFFT_BENCH_BACKEND")}
+    env.update(SMFFT_BENCH_DEVICE="0", SMFFT_BENCH_PREWARM_S="0.2", SMFFT_PAIR_POLICY="plain")
+    if require:
+        env.update(SMFFT_BENCH_REQUIRE_RCCL="1")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--nffts", "65536",
+                        "--no-cpu-baseline", "--no-configs"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.stderr.count("RCCL not used by any rank") == 2, p.stderr[-3000:]
+    if require:
+        assert p.returncode == 3 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")], (p.returncode, p.stdout[-500:])
+        return
+    assert p.returncode == 0, p.stderr[-3000:]
+    doc = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert doc["n_gpus"] == 2 and doc["ranks_seen"] == 2 and doc["comm_backend"] == "gloo"
+    assert len(doc["per_rank"]["kernel_ms"]) == 2 and doc["value"] > 0
+
+
 @pytest.mark.parametrize("policy", ["plain", "default"])
 def test_bench_eight_ranks_dress_rehearsal_on_one_device(sm, policy):
     """The driver's 8-GPU command, rehearsed on the one device a box has: `bench.py --gpus 8` starts eight ranks
