@@ -11,6 +11,14 @@
 #ifndef SMFFT_N
 #error "compile with -DSMFFT_N=<transform length>"
 #endif
+// SMFFT_INST_PART: 0 (default: tools that compile this file by itself) = everything of the length in one object; the Makefile builds two
+// objects per length -- 1 = the external (HBM-bound) kernels and the dispatch, 2 = the in-LDS (`multiple`) kernels -- because the two
+// kinds want different code generation: the in-LDS kernels of N >= 128 run 2 ... 5 % faster without LLVM's post-RA machine scheduler
+// (-mllvm -enable-post-misched=0), the external kernels 1.5 ... 2.7 % SLOWER, N = 32's lane engine 15 % slower
+// (profiles/r06_post_misched.txt); the flags per length are the Makefile's MULT_FLAGS_<N> (tools/inst_flags.py reads them for the ISA tests).
+#ifndef SMFFT_INST_PART
+#define SMFFT_INST_PART 0
+#endif
 
 #define SMFFT_PASTE3_(a, b, c) a##b##c
 #define SMFFT_PASTE3(a, b, c) SMFFT_PASTE3_(a, b, c)
@@ -18,6 +26,24 @@
 
 namespace smfft {
 
+// the in-LDS half of launch_ct / launch_st / launch_rc (path 1 or 2), defined in part 2
+template <int N>
+int launch_ct_multiple(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, const LaunchOptions& opt, hipStream_t stream);
+template <int N>
+int launch_st_multiple(const float2* d_input, float2* d_output, int count, const LaunchOptions& opt, hipStream_t stream);
+template <int L>
+int launch_rc_multiple(const float2* d_input, float2* d_output, int count, int inverse, const LaunchOptions& opt, hipStream_t stream);
+template <>
+int launch_ct_multiple<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, const LaunchOptions& opt, hipStream_t stream);
+template <>
+int launch_st_multiple<SMFFT_N>(const float2* d_input, float2* d_output, int count, const LaunchOptions& opt, hipStream_t stream);
+#if SMFFT_N >= 256 && SMFFT_N <= 2048
+template <>
+int launch_rc_multiple<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, const LaunchOptions& opt, hipStream_t stream);
+#endif
+#define ST_CLASS SMFFT_PASTE3(FFT_, SMFFT_N, )
+
+#if SMFFT_INST_PART != 1
 // One launch of a compact (in-LDS) kernel over `count` FFT slots.  Unbalanced: one chain per workgroup, grid-strided under the
 // grid cap.  Balanced (the default when the batch is more chains than the chip holds at once): a persistent grid of the
 // co-resident workgroups, each owning an equal share of the launch's ntiles * nreuses applications (MultipleSchedule).
@@ -97,22 +123,7 @@ static int launch_compact(CompactKernel kernel, const float2* d_input, float2* d
 }
 
 template <>
-int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, const LaunchOptions& opt, hipStream_t stream) {
-    if (count <= 0) return 0;
-    dim3 grid(grid_for(count, 4096 / SMFFT_N, opt.grid_cap)), block(256);
-    const int pace = opt.pace;
-    if (path == 0) {
-#if SMFFT_N == 4096
-#define SMFFT_EXTERNAL_REORDER_KERNEL SMFFT_DIT_external_occ3
-#else
-#define SMFFT_EXTERNAL_REORDER_KERNEL SMFFT_DIT_external
-#endif
-        if (!inverse && reorder)  SMFFT_EXTERNAL_REORDER_KERNEL<CT_CLASS(_forward)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
-        if (!inverse && !reorder) SMFFT_DIT_external<CT_CLASS(_forward_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
-        if (inverse && reorder)   SMFFT_EXTERNAL_REORDER_KERNEL<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
-        if (inverse && !reorder)  SMFFT_DIT_external<CT_CLASS(_inverse_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
-        return (int)hipGetLastError();
-    }
+int launch_ct_multiple<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, const LaunchOptions& opt, hipStream_t stream) {
     // in-LDS path: compact workgroups (one wave per 1024 elements for N <= 1024, one FFT per workgroup above)
 #if SMFFT_N >= 64
     if (path == 2 && reorder) {     // no cross-application fusion (what one call of the device function costs)
@@ -136,6 +147,41 @@ int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int i
     if (!inverse && !reorder) return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_forward_noreorder)>, d_input, d_output, count, opt, stream);
     if (inverse && reorder)   return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_inverse)>, d_input, d_output, count, opt, stream);
     return launch_compact(SMFFT_DIT_multiple<CT_CLASS(_inverse_noreorder)>, d_input, d_output, count, opt, stream);
+}
+
+template <>
+int launch_st_multiple<SMFFT_N>(const float2* d_input, float2* d_output, int count, const LaunchOptions& opt, hipStream_t stream) {
+    return launch_compact(FFT_GPU_multiple<ST_CLASS>, d_input, d_output, count, opt, stream);
+}
+#if SMFFT_N >= 256 && SMFFT_N <= 2048
+template <>
+int launch_rc_multiple<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, const LaunchOptions& opt, hipStream_t stream) {
+    if (!inverse) return launch_compact(FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_forward>, d_input, d_output, count, opt, stream);
+    return launch_compact(FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_inverse>, d_input, d_output, count, opt, stream);
+}
+#endif
+#endif  // SMFFT_INST_PART != 1
+
+#if SMFFT_INST_PART != 2
+template <>
+int launch_ct<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int reorder, int path, const LaunchOptions& opt, hipStream_t stream) {
+    if (count <= 0) return 0;
+    dim3 grid(grid_for(count, 4096 / SMFFT_N, opt.grid_cap)), block(256);
+    const int pace = opt.pace;
+    if (path == 0) {
+#if SMFFT_N == 4096
+#define SMFFT_EXTERNAL_REORDER_KERNEL SMFFT_DIT_external_occ3
+#else
+#define SMFFT_EXTERNAL_REORDER_KERNEL SMFFT_DIT_external
+#endif
+        if (!inverse && reorder)  SMFFT_EXTERNAL_REORDER_KERNEL<CT_CLASS(_forward)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
+        if (!inverse && !reorder) SMFFT_DIT_external<CT_CLASS(_forward_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
+        if (inverse && reorder)   SMFFT_EXTERNAL_REORDER_KERNEL<CT_CLASS(_inverse)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
+        if (inverse && !reorder)  SMFFT_DIT_external<CT_CLASS(_inverse_noreorder)><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
+        return (int)hipGetLastError();
+    }
+    // in-LDS path: compact workgroups (one wave per 1024 elements for N <= 1024, one FFT per workgroup above): part 2
+    return launch_ct_multiple<SMFFT_N>(d_input, d_output, count, inverse, reorder, path, opt, stream);
 }
 
 #if SMFFT_N == 1024
@@ -175,11 +221,10 @@ int launch_stream_read(const float2* d_input, long n_float2, int grid_cap, hipSt
 }
 #endif
 
-#define ST_CLASS SMFFT_PASTE3(FFT_, SMFFT_N, )
 template <>
 int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int path, const LaunchOptions& opt, hipStream_t stream) {
     if (count <= 0) return 0;
-    if (path != 0) return launch_compact(FFT_GPU_multiple<ST_CLASS>, d_input, d_output, count, opt, stream);
+    if (path != 0) return launch_st_multiple<SMFFT_N>(d_input, d_output, count, opt, stream);
     dim3 grid(grid_for(count, 4096 / SMFFT_N, opt.grid_cap)), block(256);
     const int pace = opt.pace;
 #if SMFFT_N == 4096
@@ -195,10 +240,7 @@ int launch_st<SMFFT_N>(const float2* d_input, float2* d_output, int count, int p
 template <>
 int launch_rc<SMFFT_N>(const float2* d_input, float2* d_output, int count, int inverse, int path, const LaunchOptions& opt, hipStream_t stream) {
     if (count <= 0) return 0;
-    if (path != 0) {
-        if (!inverse) return launch_compact(FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_forward>, d_input, d_output, count, opt, stream);
-        return launch_compact(FFT_GPU_R2C_C2R_multiple<ST_CLASS, FFT_inverse>, d_input, d_output, count, opt, stream);
-    }
+    if (path != 0) return launch_rc_multiple<SMFFT_N>(d_input, d_output, count, inverse, opt, stream);
     dim3 grid(grid_for(count, 4096 / SMFFT_N, opt.grid_cap)), block(256);
     const int pace = opt.pace;
     if (!inverse) FFT_GPU_R2C_C2R_external<ST_CLASS, FFT_forward><<<grid, block, 0, stream>>>(d_input, d_output, count, pace);
@@ -206,5 +248,7 @@ int launch_rc<SMFFT_N>(const float2* d_input, float2* d_output, int count, int i
     return (int)hipGetLastError();
 }
 #endif
+
+#endif  // SMFFT_INST_PART != 2
 
 }  // namespace smfft

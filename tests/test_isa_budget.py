@@ -10,6 +10,9 @@ from concurrent.futures import ThreadPoolExecutor
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import sys
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from inst_flags import part_flags  # noqa: E402  (the product's two objects per length and their flags: smfft_amd/csrc/Makefile)
 HIPCC = "/opt/rocm/bin/hipcc"
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include")]
 
@@ -23,10 +26,13 @@ def _demangle(names):
 
 def _resources(n):
     src = os.path.join(ROOT, "smfft_amd", "csrc", "smfft_inst.hip")
-    p = subprocess.run([HIPCC] + FLAGS + [f"-DSMFFT_N={n}", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
-    assert p.returncode == 0, p.stderr[-2000:]
+    report = ""
+    for part in (1, 2):      # what ships: the external kernels' object and the in-LDS kernels' object, each with its flags
+        p = subprocess.run([HIPCC] + FLAGS + part_flags(n, part) + [f"-DSMFFT_N={n}", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr[-2000:]
+        report += p.stderr
     rows, cur = [], None
-    for line in p.stderr.splitlines():
+    for line in report.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
             cur = {"mangled": m.group(1)}
@@ -52,7 +58,7 @@ def _example_isa():
 
 def _inst_isa(n):
     out = f"/tmp/smfft_test_isa_{os.getpid()}_{n}.s"
-    p = subprocess.run([HIPCC] + FLAGS + [f"-DSMFFT_N={n}", "-S", "--cuda-device-only", os.path.join(ROOT, "smfft_amd", "csrc", "smfft_inst.hip"), "-o", out], capture_output=True, text=True)
+    p = subprocess.run([HIPCC] + FLAGS + part_flags(n, 2) + [f"-DSMFFT_N={n}", "-S", "--cuda-device-only", os.path.join(ROOT, "smfft_amd", "csrc", "smfft_inst.hip"), "-o", out], capture_output=True, text=True)      # the in-LDS kernels' object
     assert p.returncode == 0, p.stderr[-2000:]
     text = open(out).read()
     os.remove(out)

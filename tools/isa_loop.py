@@ -25,8 +25,12 @@ def main():
             extra.append(a)
     src = os.path.join(ROOT, "smfft_amd", "csrc", "smfft_inst.hip")
     out = f"/tmp/smfft_isa_{n}.s"
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from inst_flags import part_flags
+    # the object the picked kernel ships in: part 2 (in-LDS kernels, with the Makefile's MULT_FLAGS_<N>) unless an external kernel is asked for
+    part = 1 if "external" in pick else 2
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", f"-DSMFFT_N={n}", "-I" + os.path.join(ROOT, "include"),
-           "-S", "--cuda-device-only", src, "-o", out] + extra
+           "-S", "--cuda-device-only", src, "-o", out] + part_flags(n, part) + extra
     p = subprocess.run(cmd, capture_output=True, text=True)
     if p.returncode != 0:
         sys.stderr.write(p.stderr[-4000:])

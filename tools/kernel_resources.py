@@ -13,14 +13,19 @@ def main():
     n = sys.argv[1] if len(sys.argv) > 1 else "1024"
     extra = sys.argv[2:]
     src = os.path.join(ROOT, "smfft_amd", "csrc", "smfft_inst.hip")
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", f"-DSMFFT_N={n}", "-I" + os.path.join(ROOT, "include"),
-           "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"] + extra
-    p = subprocess.run(cmd, capture_output=True, text=True)
-    if p.returncode != 0:
-        sys.stderr.write(p.stderr[-4000:])
-        raise SystemExit(p.returncode)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from inst_flags import part_flags
+    report = ""
+    for part in (1, 2):      # the product's two objects per length, each with its flags (smfft_amd/csrc/Makefile)
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", f"-DSMFFT_N={n}", "-I" + os.path.join(ROOT, "include"),
+               "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"] + part_flags(n, part) + extra
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        if p.returncode != 0:
+            sys.stderr.write(p.stderr[-4000:])
+            raise SystemExit(p.returncode)
+        report += p.stderr
     rows, cur = [], None
-    for line in p.stderr.splitlines():
+    for line in report.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
             name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
