@@ -84,3 +84,29 @@ def test_compact_line_worst_case_is_bounded_and_strict():
 def test_sig_rounds_and_removes_non_finite():
     assert bench._sig(1.23456789012) == 1.23457
     assert bench._sig({"a": [float("nan"), math.inf, 2]}) == {"a": [None, None, 2]}
+
+
+def test_compact_line_of_round_6_with_eight_ranks_keeps_its_summary():
+    """the round-6 record (profiles/r06_bench_detail.json) carries the per-length tables of the three in-LDS readings, the contract ratios per
+    length and the convolution kernels; with eight ranks' own outcomes and two allocation attempts the line still fits and drops nothing"""
+    path = os.path.join(ROOT, "profiles", "r06_bench_detail.json")
+    if not os.path.exists(path):
+        pytest.skip("no round-6 record in this checkout")
+    detail = json.load(open(path))
+    detail["n_gpus"] = 8
+    detail["per_rank"] = {"wall_ms_per_step": [1.3071234567] * 8, "kernel_ms": [1.3064439392089844] * 8, "good_enough": [1] * 8,
+                          "copy_ms": [0.3633233308792114] * 8, "attempts": [2] * 8}
+    detail["pair_attempts"] = [dict(detail["pair_attempts"][0]), dict(detail["pair_attempts"][0], kept=True)]
+    text = bench.compact_line(detail)
+    assert len(text) < bench.COMPACT_LIMIT, len(text)
+    line = _strict(text)
+    s = line["summary"]
+    assert len(s["config3_by_length_frac"]) == 8 and all(len(row) == 4 for row in s["config3_by_length_frac"])
+    assert len(s["contract_in_lds_ratio_by_length"]) == 8
+    for row in s["contract_in_lds_ratio_by_length"][3:6]:
+        assert min(row) >= 0.55, row                      # N = 256, 512, 1024 (VERDICT r05 item 1)
+    for row in s["contract_in_lds_ratio_by_length"][6:]:
+        assert min(row) >= 0.47, row                      # N = 2048, 4096
+    assert len(s["convolution_ms"]) == 3 and s["convolution_ms"][0] > s["convolution_ms"][1] > s["convolution_ms"][2] > 1.3
+    assert min(s["config3_frac_2048_4096"]) >= 0.54
+    assert len(line["per_rank"]["kernel_ms"]) == 8 and line["roofline_own_input"] is not None
