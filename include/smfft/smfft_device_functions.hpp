@@ -943,7 +943,10 @@ __device__ void do_FFT_Stockham_R2C_C2R(float2* s_input) {
 // fill / transform in LDS / drain on the LDS form of the ladder, which measured 3-6 % faster there (profiles/r04_contract_lanes.txt).
 template <class const_params>
 __global__ void SMFFT_DIT_external(float2* d_input, float2* d_output) {
-    if constexpr (SMFFT_CONTRACT_FUSED_IO && SMFFT_QUARTER_LANES != 0 && const_params::fft_size <= 128 && const_params::fft_length_quarter == 32) {
+    // (N = 128 natural order in upstream's 32-thread blocks: fill / do_SMFFT_CT_DIT / drain instead -- since round 6 that function makes one trip through
+    //  the block's image where this LDS-free ladder pays two more exchanges on lanes: 1.92 -> 1.84 ms on the config-2 batch)
+    constexpr bool kStagedSmall = SMFFT_QUARTER_PHASES != 0 && const_params::fft_size == 128 && const_params::fft_reorder != 0;
+    if constexpr (SMFFT_CONTRACT_FUSED_IO && SMFFT_QUARTER_LANES != 0 && const_params::fft_size <= 128 && const_params::fft_length_quarter == 32 && !kStagedSmall) {
         constexpr int N = const_params::fft_size, Q = N / 4;
         using L = smfft::QuarterLanes<N, const_params::fft_direction, const_params::fft_reorder>;
         const int t = threadIdx.x % Q;
@@ -983,7 +986,7 @@ __global__ void SMFFT_DIT_external(float2* d_input, float2* d_output) {
     s_input[threadIdx.x + const_params::fft_length_half] = d_input[base + const_params::fft_length_half];
     s_input[threadIdx.x + const_params::fft_length_three_quarters] = d_input[base + const_params::fft_length_three_quarters];
     __syncthreads();
-    if constexpr (const_params::fft_size <= 128) {     // the LDS form of the ladder between fill and drain (3-6 % faster there than do_SMFFT_CT_DIT's lane form)
+    if constexpr (const_params::fft_size <= 128 && !(kStagedSmall && const_params::fft_length_quarter == 32)) {     // the LDS form of the ladder between fill and drain (3-6 % faster there than do_SMFFT_CT_DIT's lane form)
         constexpr int N = const_params::fft_size;
         smfft::quarter_fft_inplace<N, const_params::fft_direction, const_params::fft_reorder, const_params::fft_length / 4, 1>(s_input, threadIdx.x % (N / 4), (threadIdx.x / (N / 4)) * N);
     } else {
