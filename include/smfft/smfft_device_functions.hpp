@@ -633,7 +633,11 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
     int a;
     if constexpr (REORDER) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) e[((m & 1) << 1) | (m >> 1)] = IN_REGS ? x[m] : (kPhases && N <= 2048) ? lds_load_single(sf + t + m * Q) : sf[t + m * Q];   // e[i] = x[bitrev(4j + i)], i = rev2(m)
+        for (int m = 0; m < 4; ++m) {                                                   // e[i] = x[bitrev(4j + i)], i = rev2(m)
+            if constexpr (IN_REGS) e[((m & 1) << 1) | (m >> 1)] = x[m];
+            else if constexpr (kPhases && N <= 2048) e[((m & 1) << 1) | (m >> 1)] = lds_load_single(sf + t + m * Q);
+            else e[((m & 1) << 1) | (m >> 1)] = sf[t + m * Q];
+        }
         a = 4 * (int)(T_BITS ? __brev((unsigned)t) >> (32 - (T_BITS ? T_BITS : 1)) : 0);
         if constexpr (!IN_REGS) fft_sync<kBarrier>();                                   // every load precedes the scattered stores
         // (a timing-only build WITHOUT this barrier is within +-1.5 % at every length, N = 4096 5 % slower: an image that lets every wave scatter

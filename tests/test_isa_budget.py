@@ -200,3 +200,17 @@ def test_reference_shaped_multiple_loop_keeps_its_twiddles(built):
         a, b = max(_loops(body), key=lambda ab: ab[1] - ab[0])
         loads = sum("global_load" in l for l in body[a:b + 1])
         assert loads <= allowed, (frag, loads)
+
+
+def test_reference_shaped_loops_hold_no_packed_fp32(built):
+    """Packed fp32 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) runs at half rate on gfx950 and costs moves to line register pairs up; the
+    library is built with -fno-slp-vectorize, but a float2 that reaches arithmetic as a <2 x float> value gets packed all the same -- round 6 lost
+    11 % at N = 4096 natural order to ten v_pk_add_f32 that a ternary between two float2 loads brought in.  No reference-shaped `multiple` loop
+    (the in-LDS benchmark shape, CT:553-572) holds one."""
+    isa = built["isa"]
+    seen = 0
+    for m in re.finditer(r"^(_Z18SMFFT_DIT_multipleI\w+):[^\n]*\n(.*?)\n\s*s_endpgm", isa, re.S | re.M):
+        packed = [l.strip() for l in m.group(2).split("\n") if re.match(r"\s*v_pk_(add|mul|fma)_f32", l)]
+        assert not packed, (m.group(1), packed[:3])
+        seen += 1
+    assert seen >= 16, seen
