@@ -17,18 +17,26 @@ __global__ void __launch_bounds__(256) convolve_kernel(const float2* __restrict_
     constexpr int N = Fwd::fft_size;
     __shared__ float2 s[Fwd::tile_sm_required];
     const long first = (long)blockIdx.x * Fwd::fft_per_block;
+    // a thread meets N / 256 different points of the spectrum (e mod N with e = threadIdx.x + 256 i): the filter's values for
+    // them are fetched with the series, not between the transforms behind a barrier
+    constexpr int kPoints = N > 256 ? N / 256 : 1;
+    float2 h[kPoints];
     // natural order, series j of the workgroup at s[j*fft_region + n]
-    for (int e = threadIdx.x; e < 4096; e += 256) {
-        const int j = e / N, n = e % N;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = threadIdx.x + 256 * i, j = e / N, n = e % N;
         s[j * Fwd::fft_region + n] = (first + j < nSeries) ? x[first * N + e] : make_float2(0.f, 0.f);
     }
+#pragma unroll
+    for (int i = 0; i < kPoints; ++i) h[i] = H[(threadIdx.x + 256 * i) % N];
     __syncthreads();
     smfft::tiled::do_SMFFT_CT_DIT<Fwd>(s);
     __syncthreads();
-    for (int e = threadIdx.x; e < 4096; e += 256) {
-        const int j = e / N, k = e % N;
-        const float2 a = s[j * Fwd::fft_region + k], h = H[k];
-        s[j * Fwd::fft_region + k] = make_float2(a.x * h.x - a.y * h.y, a.x * h.y + a.y * h.x);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = threadIdx.x + 256 * i, j = e / N, k = e % N;
+        const float2 a = s[j * Fwd::fft_region + k], g = h[i % kPoints];
+        s[j * Fwd::fft_region + k] = make_float2(a.x * g.x - a.y * g.y, a.x * g.y + a.y * g.x);
     }
     __syncthreads();
     smfft::tiled::do_SMFFT_CT_DIT<Inv>(s);

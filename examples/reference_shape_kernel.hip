@@ -163,18 +163,23 @@ extern "C" int smfft_example_reference_shape_ct_multiple_wave64(void* d_in, void
 // who knows nothing but the reference's contract -- one block per series, blockDim.x = N / 4, do_SMFFT_CT_DIT<forward>,
 // a pointwise product in shared memory, do_SMFFT_CT_DIT<inverse> (README.md:10-16).  examples/fft_convolution.hip has the
 // same pipeline on the engine's tiled contract and on its register-level interface.
+// Two lines of ordinary kernel hygiene, both the user's own (round 6; tools/ab_convolution.py, profiles/r06_convolution_user_kernel.txt):
+// the filter's four values are fetched WITH the series -- fetched between the two transforms, behind a barrier, their L2 latency
+// was exposed once per block: 2.05 -> 1.88 ms on the config-2 batch -- and the kernel states its block size (-> 1.79 ms).
 template <class Fwd, class Inv>
-__global__ void user_convolution_kernel(const float2* d_x, const float2* d_H, float2* d_y) {
+__global__ void __launch_bounds__(Fwd::fft_length_quarter) user_convolution_kernel(const float2* d_x, const float2* d_H, float2* d_y) {
     __shared__ float2 s_data[Fwd::fft_sm_required];
     constexpr int N = Fwd::fft_length, Q = Fwd::fft_length_quarter;
     const int offset = blockIdx.x * N;
+    float2 h[4];
     for (int k = 0; k < 4; k++) s_data[threadIdx.x + k * Q] = d_x[offset + threadIdx.x + k * Q];
+    for (int k = 0; k < 4; k++) h[k] = d_H[threadIdx.x + k * Q];
     __syncthreads();
     do_SMFFT_CT_DIT<Fwd>(s_data);
     __syncthreads();
     for (int k = 0; k < 4; k++) {
-        const float2 a = s_data[threadIdx.x + k * Q], h = d_H[threadIdx.x + k * Q];
-        s_data[threadIdx.x + k * Q] = make_float2(a.x * h.x - a.y * h.y, a.x * h.y + a.y * h.x);
+        const float2 a = s_data[threadIdx.x + k * Q];
+        s_data[threadIdx.x + k * Q] = make_float2(a.x * h[k].x - a.y * h[k].y, a.x * h[k].y + a.y * h[k].x);
     }
     __syncthreads();
     do_SMFFT_CT_DIT<Inv>(s_data);
@@ -187,16 +192,17 @@ __global__ void user_convolution_kernel(const float2* d_x, const float2* d_H, fl
 // ... and with the register form of the same functions (do_SMFFT_CT_DIT_registers: a thread's four elements
 // threadIdx.x + m N/4 in and out, the shared array as scratch): the series never lies in shared memory in natural order.
 template <class Fwd, class Inv>
-__global__ void user_convolution_kernel_registers(const float2* d_x, const float2* d_H, float2* d_y) {
+__global__ void __launch_bounds__(Fwd::fft_length_quarter) user_convolution_kernel_registers(const float2* d_x, const float2* d_H, float2* d_y) {
     __shared__ float2 s_scratch[Fwd::fft_sm_required];
     constexpr int N = Fwd::fft_length, Q = Fwd::fft_length_quarter;
     const int offset = blockIdx.x * N;
-    float2 x[4];
+    float2 x[4], h[4];
     for (int k = 0; k < 4; k++) x[k] = d_x[offset + threadIdx.x + k * Q];
+    for (int k = 0; k < 4; k++) h[k] = d_H[threadIdx.x + k * Q];
     do_SMFFT_CT_DIT_registers<Fwd>(x, s_scratch);
     for (int k = 0; k < 4; k++) {
-        const float2 a = x[k], h = d_H[threadIdx.x + k * Q];
-        x[k] = make_float2((a.x * h.x - a.y * h.y) * (1.0f / N), (a.x * h.y + a.y * h.x) * (1.0f / N));
+        const float2 a = x[k];
+        x[k] = make_float2((a.x * h[k].x - a.y * h[k].y) * (1.0f / N), (a.x * h[k].y + a.y * h[k].x) * (1.0f / N));
     }
     __syncthreads();   // the forward transform's last reads of s_scratch are done before the inverse one writes it
     do_SMFFT_CT_DIT_registers<Inv>(x, s_scratch);

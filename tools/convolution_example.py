@@ -28,7 +28,7 @@ h[:5] = [0.4, 0.3, 0.2, 0.1, -0.05j]
 H = sm.DeviceBuffer.from_host(np.fft.fft(h).astype(np.complex64))
 
 
-def timed(fn, reps=11, warm=3):
+def timed(fn, reps=11, warm=25):   # 25 launches = 35...60 ms: the clocks have settled (profiles/r03_warm_ramp.txt)
     import time
     for _ in range(warm):
         fn()
