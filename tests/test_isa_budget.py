@@ -214,3 +214,20 @@ def test_reference_shaped_loops_hold_no_packed_fp32(built):
         assert not packed, (m.group(1), packed[:3])
         seen += 1
     assert seen >= 16, seen
+
+
+def test_convolution_example_fetches_its_filter_with_the_series(built):
+    """The user's convolution kernels on the reference's contract (examples/reference_shape_kernel.hip, README.md:10-18): the filter's
+    values are fetched with the series.  Fetched between the two transforms they sat behind a barrier, one exposed L2 latency per
+    block (round 6: 2.05 -> 1.88 ms on the config-2 batch; profiles/r06_convolution_user_kernel.txt).  In the ISA: no global load
+    behind the forward transform's first LDS write-back, i.e. every load (series, filter, the device function's twiddles, fetched at
+    its top) is in front of the second barrier of the kernel."""
+    isa = built["isa"]
+    for frag in ("user_convolution_kernelI16FFT_1024_forward16FFT_1024_inverseE", "user_convolution_kernel_registersI16FFT_1024_forward16FFT_1024_inverseE"):
+        m = re.search(r"^(_Z\d+%s\w*):[^\n]*\n(.*?)\n\s*s_endpgm" % frag, isa, re.S | re.M)
+        assert m, frag
+        body = [l.strip() for l in m.group(2).split("\n")]
+        barriers = [i for i, l in enumerate(body) if l.startswith("s_barrier")]
+        loads = [i for i, l in enumerate(body) if l.startswith("global_load")]
+        assert len(loads) >= 8 and len(barriers) >= 4, (frag, len(loads), len(barriers))
+        assert max(loads) < barriers[1], (frag, max(loads), barriers[:3])
