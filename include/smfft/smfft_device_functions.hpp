@@ -164,7 +164,9 @@ constexpr int quarter_late_passes(int n, bool reorder) {
 // registers with every twiddle kept -- still eight waves per SIMD -- and a late pass's global load sits right behind the one barrier
 // of its last phase, on the critical path of sixteen waves: kept, N = 4096 runs 13 ... 15 % faster in the in-LDS loop, N = 2048 1 ... 4 %
 // (profiles/r06_contract_phases.txt).  The round-5 form (OUT_REGS at these lengths) keeps its late passes.
-template <int N, int DIR, int REORDER, bool KEEP_ALL = false>
+// HIGH_FROM: the first pass whose butterfly index comes from kb_high (4: the last phase of N >= 2048; 3: the natural-order transforms of
+// N = 512 / 1024 in PAIRS of passes -- quarter_fft -- whose threads are numbered anew at the second image).
+template <int N, int DIR, int REORDER, bool KEEP_ALL = false, int HIGH_FROM = 4>
 struct QuarterTwiddles {
     using R = QuarterTwiddleRows<N>;
     static constexpr int kLatePasses = KEEP_ALL ? 0 : quarter_late_passes(N, REORDER != 0);
@@ -189,7 +191,7 @@ struct QuarterTwiddles {
         kbase_high = kb_high;
 #pragma unroll
         for (int p = 1; p < R::kPasses; ++p)
-            if (!late(p)) q[p] = fetch(p, (p >= 4 ? kb_high : kb) & ((1 << (2 * p)) - 1));
+            if (!late(p)) q[p] = fetch(p, (p >= HIGH_FROM ? kb_high : kb) & ((1 << (2 * p)) - 1));
         if constexpr (R::kOdd) {
             const TwiddleValue tv = quarter_twiddle_rows<N>.w[R::row_start(R::kPasses) + r];
             wr = make_float2(tv.x, DIR ? -tv.y : tv.y);
@@ -197,7 +199,7 @@ struct QuarterTwiddles {
     }
     // the twiddles of pass `pass`, at the pass (pass: a constant where this is called -- a template argument or the counter of an unrolled loop)
     __device__ __forceinline__ QuadTwiddle of(int pass) const {
-        return late(pass) ? fetch(pass, (pass >= 4 ? kbase_high : kbase) & ((1 << (2 * pass)) - 1)) : q[pass];
+        return late(pass) ? fetch(pass, (pass >= HIGH_FROM ? kbase_high : kbase) & ((1 << (2 * pass)) - 1)) : q[pass];
     }
 };
 // the fused radix-2^2 butterfly on (x0, x1, x2, x3) = elements k, k + P, k + 2P, k + 3P; results in place
@@ -556,6 +558,23 @@ __device__ __forceinline__ void quarter_small_noreorder(float2* s, int t, int re
 #ifndef SMFFT_QUARTER_PHASES
 #define SMFFT_QUARTER_PHASES 1         // 0: the round-5 form (A/B)
 #endif
+// Natural order in PAIRS of passes (round 6, last day; N = 512, 1024 with results to LDS): a phase is TWO passes with one exchange between
+// them, and that exchange is always the one of the lane bits 4, 5 (v_permlane16/32_swap) -- never the sixteen DPP-fed selects of the lane
+// bits 2, 3 that a phase of three passes needs; the trips through LDS stay as many as before and conflict free (tools/quarter_phases_model.py,
+// transform_pairs):
+//   pass (0,1) in the thread, scattered as before; [pass (2,3) | <-> 4, 5 | pass (4,5)] on the wave's aligned block of 256
+//   (slots = bits 2, 3; lane bits 0 ... 5 = bits 0, 1, 6, 7, 4, 5); swizzled image;
+//   N = 1024: [pass (6,7) | <-> 4, 5 | pass (8,9)] with wave = bits 4, 5: a barrier in front of the natural stores;
+//   N = 512:  [pass (6,7) | slot bit 0 <-> lane bit 5 | radix 2 on bit 8] with wave = bit 5: the wave owns whole aligned groups
+//             of 32, which the swizzle permutes -- it stores into the words it read, no barrier.
+// Measured in the in-LDS loop against the three-pass phase (one process): N = 512 +3 %, N = 1024 +4 % -- a third of what the instruction
+// count promised (a select costs the vector unit less, a v_permlane*_swap more, than the 7.4 and 9 cycles measured in isolation); the same at
+// N = 256 ([pass 0 | <-> 5, 4 | pass 1] image [pass 2 | <-> 4, 5 | pass 3]: sixteen swaps for sixteen selects + eight swaps) measured 2 % SLOWER
+// and was taken out again (profiles/r06_contract_pairs.txt).
+// 0: slots = bits (2, 3) read-back and three passes per phase at these lengths too (the form of the rest of round 6; A/B)
+#ifndef SMFFT_QUARTER_PAIRS
+#define SMFFT_QUARTER_PAIRS 1
+#endif
 // OUT_PHASED (with OUT_REGS; round 6): the results stay in x[] WHERE THE LAST PHASE LEAVES THEM -- x[i] = element quarter_phased_element<N>(t, i)
 // of the transform -- so that N = 2048 / 4096 can take the last phase with registers out as well (for N <= 1024 that is t + i N/4, as without it).
 template <int N>
@@ -601,6 +620,7 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
     static_assert(!OUT_PHASED || OUT_REGS, "OUT_PHASED qualifies OUT_REGS");
     constexpr bool kLastPhase = kPhases && N >= 2048 && (!OUT_REGS || OUT_PHASED) && (kLanesHead || kLanesMiddle);
     constexpr int kFirstLdsPass = (kLanesHead || kLanesMiddle) ? 4 : 1;
+    constexpr bool kPairs = kPhases && SMFFT_QUARTER_PAIRS != 0 && REORDER && (N == 512 || N == 1024) && kLanesMiddle && !OUT_REGS;
     // the thread of the last phase: lanes 0 ... LOW-1 = position bits 0 ... LOW-1, wave = the bits up to 7, slots = bits (8, 9), the other
     // lane bits = bits 10 (, 11); after the exchange in front of the last pass those lane bits hold bits 8 (, 9)
     constexpr int LOW = 16 - N_BITS;
@@ -608,8 +628,12 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
     const int k_last = kLastPhase ? ((lane & ((1 << LOW) - 1)) | (wave << LOW) | ((lane >> LOW) << 8)) : t;
     // the twiddles first (QuarterTwiddles): k = t mod P in every pass of this form -- and in the wave-local ladder below, whose
     // butterfly index is the lane = t mod 64 with P <= 64; the last phase: k_last
-    QuarterTwiddles<N, DIR, REORDER, kLastPhase> tw;
-    tw.load(t, k_last, k_last);
+    // (pairs: the numbering of the threads changes at the second image -- the passes 1, 2 k = lane bits 0, 1, 4, 5, then k = the low bits of the
+    //  thread's last-phase element k_pairs)
+    const int k_pairs = N == 1024 ? ((lane & 15) | (wave << 4) | ((lane >> 4) << 6)) : ((lane & 31) | (wave << 5) | ((lane >> 5) << 6));
+    QuarterTwiddles<N, DIR, REORDER, kLastPhase, kPairs ? 3 : 4> tw;
+    if constexpr (kPairs) tw.load((lane & 3) | ((lane >> 4) << 2), k_pairs, k_pairs);
+    else tw.load(t, k_last, k_last);
     float2* sf = s + region_offset;
     float2 e[4];
     // N >= 512, no reorder: the first FOUR passes (index bits 0 ... 7) never leave the wave -- thread t = lane + 64 w starts with
@@ -660,7 +684,52 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
     }
     if constexpr (kLanesMiddle) {
         fft_sync<kBarrier>();                                      // every wave's scattered stores precede the loads
-        if constexpr (kSlots23) {
+        if constexpr (kPairs) {
+            // ---- [pass 1 | <-> 4, 5 | pass 2] on the wave's aligned block: slots = position bits (2, 3); lane bits 0, 1 = bits 0, 1; 2, 3 = bits 6, 7; 4, 5 = bits 4, 5
+            const int pb = (lane & 3) | ((lane >> 4) << 4) | (((lane >> 2) & 3) << 6) | (wave << 8);
+            const int b0 = quarter_swizzle(region_offset + pb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = s[b0 ^ (4 * j)];
+            quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(1), tw.late(1));
+            slots_swap<0, 4, true>(e);
+            slots_swap<1, 5, true>(e);
+            quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(2), tw.late(2));
+            fft_sync<false>();                                     // the wave's loads precede its stores into the same 256 elements
+            // slots = bits (4, 5); lane bits 4, 5 = bits 2, 3
+            const int c0 = quarter_swizzle(region_offset + ((lane & 3) | ((lane >> 4) << 2) | (((lane >> 2) & 3) << 6) | (wave << 8)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[c0 ^ quarter_swizzle(16 * j)] = e[j];
+            fft_sync<kBarrier>();                                  // the owners change: every wave's block is in the image
+            if constexpr (N == 1024) {
+                // ---- [pass 3 | <-> 4, 5 | pass 4]: slots = bits (6, 7); lane bits 0 ... 3 = bits 0 ... 3; wave = bits 4, 5; lane bits 4, 5 = bits 8, 9
+                const int d0 = quarter_swizzle(region_offset + ((lane & 15) | (wave << 4) | ((lane >> 4) << 8)));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = s[d0 ^ quarter_swizzle(64 * j)];
+                quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(3), tw.late(3));
+                slots_swap<0, 4, true>(e);
+                slots_swap<1, 5, true>(e);
+                quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(4), tw.late(4));
+                fft_sync<kBarrier>();                              // every wave's loads of the image precede the natural stores (a wave owns half of every group of 32)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sf[k_pairs + 256 * i] = e[i];
+            } else {
+                // ---- [pass 3 | slot bit 0 <-> lane bit 5 | radix 2 on bit 8]: slots = bits (6, 7); lane bits 0 ... 4 = bits 0 ... 4; wave = bit 5; lane bit 5 = bit 8
+                const int d0 = quarter_swizzle(region_offset + ((lane & 31) | (wave << 5) | ((lane >> 5) << 8)));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = s[d0 ^ quarter_swizzle(64 * j)];
+                quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(3), tw.late(3));
+                slots_swap<0, 5, true>(e);                         // slots = (bit 8, bit 7): elements k, k + 256, k + 128, k + 384
+                const float2 w = tw.wr;
+                const float2 t1 = cmul(e[1], w), v3 = cmul(e[3], w);
+                const float2 t3 = DIR ? make_float2(-v3.y, v3.x) : make_float2(v3.y, -v3.x);
+                fft_sync<false>();                                 // the wave's loads precede its stores into the same groups of 32
+                sf[k_pairs] = cadd(e[0], t1);
+                sf[k_pairs + N / 2] = csub(e[0], t1);
+                sf[k_pairs + Q] = cadd(e[2], t3);
+                sf[k_pairs + 3 * Q] = csub(e[2], t3);
+            }
+            return;
+        } else if constexpr (kSlots23) {
             // slots = position bits (2, 3): elements p1 + 4 j, p1 = position bits 0, 1 from lane bits 0, 1 and bits 4 ... 7 from lane bits 2 ... 5
             const int p1 = (lane & 3) + 16 * (lane >> 2) + 256 * wave;
             const int b0 = kOneWaveNatural ? region_offset + quarter_image256(p1) : quarter_swizzle(region_offset + p1);      // (both images leave 4 j alone)

@@ -692,12 +692,12 @@ def test_example_convolution_kernel(sm, n, sym):
 
 
 # ------------------------------------ the reference's own device contract (examples/reference_shape_kernel.hip)
-# builds of examples/reference_shape_kernel.hip: the default one, and the three documented compile-time switches of the reference-contract
+# builds of examples/reference_shape_kernel.hip: the default one, and the four documented compile-time switches of the reference-contract
 # header that change its kernels: -DSMFFT_WAVE64_SMALL=1 (the upstream class names of N <= 128 describe
 # 64-thread blocks), -DSMFFT_CONTRACT_FUSED_IO=0 (the two-argument kernels keep upstream's fill / call / drain form) and
 # -DSMFFT_QUARTER_PHASES=0 (round 5's form of the engine: every exchange of the ladders on lanes, two trips through LDS for the cross-wave
-# passes of N >= 2048)
-EXAMPLE_BUILDS = ["", "_wave64small", "_unfused_io", "_no_phases"]
+# passes of N >= 2048), -DSMFFT_QUARTER_PAIRS=0 (natural order of N = 512 / 1024 in phases of three passes, as N = 256 and N >= 2048 are)
+EXAMPLE_BUILDS = ["", "_wave64small", "_unfused_io", "_no_phases", "_no_pairs"]
 
 
 def _examples(sm, build=""):

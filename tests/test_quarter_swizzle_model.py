@@ -85,6 +85,24 @@ def test_phased_form_of_the_ladder_is_the_dft_and_conflict_free():
         assert total == ideal + 16 * 4 * 2, (reorder, total, ideal)      # sixteen waves x four reads x two extra cycles
 
 
+@pytest.mark.parametrize("n", [512, 1024])
+def test_natural_order_in_pairs_of_passes_is_the_dft_and_conflict_free(n):
+    """quarter_fft's natural-order form of N = 512 / 1024 in PAIRS of passes (round 6, last day; SMFFT_QUARTER_PAIRS): every phase two passes
+    with the exchange of the lane bits 4, 5 between them; tools/quarter_phases_model.py, transform_pairs replays lanes, slots, swaps and the
+    swizzled image against numpy.fft, both directions; every LDS access is conflict free under the gfx950 lane-group rules, as many accesses as
+    in the three-pass form; N = 512 stores into the words it read (asserted inside the model)."""
+    import numpy as np
+    import quarter_phases_model as qp
+    rng = np.random.default_rng(n)
+    for direction in (0, 1):
+        x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        got = qp.transform_pairs(n, direction, x)
+        want = np.fft.ifft(x) * n if direction else np.fft.fft(x)
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-14
+    total, ideal, count = qp.lds_report_pairs(n)
+    assert total == ideal and count == qp.lds_report(n, 1)[2], (total, ideal, count)
+
+
 @pytest.mark.parametrize("n", [64, 128])
 @pytest.mark.parametrize("lanes", [32, 64])
 def test_small_lengths_take_one_trip_through_the_blocks_image(n, lanes):

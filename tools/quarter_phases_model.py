@@ -8,6 +8,7 @@ between passes); phases are joined by one trip through the LDS image and a workg
                   phase 1: passes (2,3) (4,5) (6,7) on the wave's aligned block of 256 positions
                   N = 256: results are final (slots = bits 6, 7; lane = position bits 0..5): natural store, conflict free
                   N = 512 / 1024: image 2 (swizzled); the last pass (radix 2 on bit 8 / radix 4 on bits 8, 9) in the thread, natural store
+                                  (the form of -DSMFFT_QUARTER_PAIRS=0 and of the register-out variants; the header's default: transform_pairs below)
                   N = 2048 / 4096: image 2 (natural layout); LAST PHASE below
   no reorder      phase 1: thread t loads x[4 t + i], passes (0,1) ... (6,7) on the wave's aligned block; the exchange between the passes
                   (2,3) and (4,5) goes through the wave's own block of the image (no barrier) instead of through sixteen DPP-fed selects
@@ -238,6 +239,151 @@ def transform(N, DIR, REORDER, x, log=None):
             for lane in range(64):
                 out[int(L.pos[lane, i])] = L.e[lane, i]
     return out
+
+
+def transform_pairs(N, DIR, x, log=None):
+    """Natural order in PAIRS of passes (round 6, last day; the header's form for N = 512 / 1024, SMFFT_QUARTER_PAIRS; the N = 256 form below
+    measured 2 % slower than the three-pass phase on the GPU and is not in the header): a phase is two passes with ONE exchange between them, and
+    that exchange is always the one of the lane bits 4, 5 (v_permlane16/32_swap) -- never the sixteen DPP-fed selects of a lane bit 0 ... 3.
+      N = 256          [pass (0,1) on x[t + 64 m] | slots <-> lane bits 5, 4 | pass (2,3)]  image256  [pass (4,5) | <-> 4, 5 | pass (6,7)]
+      N = 512 / 1024   pass (0,1) in the thread, scattered (as before); [pass (2,3) | <-> 4, 5 | pass (4,5)] on the wave's aligned block;
+                       swizzled image; N = 1024: [pass (6,7) | <-> 4, 5 | pass (8,9)], wave = position bits 4, 5 -- a barrier in front of the natural store;
+                       N = 512: [pass (6,7) | slot bit 0 <-> lane bit 5 | radix 2 on bit 8], wave = position bit 5: whole groups of 32, no barrier."""
+    n = N.bit_length() - 1
+    assert n in (8, 9, 10)
+    Q, TB = N // 4, n - 2
+    sign = 1 if DIR else -1
+    waves = N // 256
+    img = np.zeros(N, complex)
+
+    def note(kind, addr):
+        if log is not None:
+            log.append((kind, list(addr)))
+
+    def pass0(e):
+        s0, d0, s1, d1 = e[0] + e[1], e[0] - e[1], e[2] + e[3], e[2] - e[3]
+        jd1 = d1 * (1j * sign)
+        return [s0 + s1, d0 + jd1, s0 - s1, d0 - jd1]
+
+    out = np.zeros(N, complex)
+    for m in range(4):
+        for w in range(waves):
+            note("r", [64 * w + lane + m * Q for lane in range(64)])
+    if n == 8:
+        L = Wave()
+        for lane in range(64):
+            e = [0] * 4
+            for m in range(4):
+                e[((m & 1) << 1) | (m >> 1)] = x[lane + m * Q]
+            L.e[lane] = pass0(e)
+            L.pos[lane] = [4 * rev(lane, 6) + i for i in range(4)]
+        L.swap(0, 5)       # lane bit 5 holds position bit 2, lane bit 4 position bit 3
+        L.swap(1, 4)
+        for lane in range(64):
+            L.e[lane] = quad(L.e[lane], L.pos[lane], 4, sign)
+        for j in range(4):
+            addr = [image256(int(L.pos[lane, j])) for lane in range(64)]
+            note("w", addr)
+            for lane in range(64):
+                img[addr[lane]] = L.e[lane, j]
+        for j in range(4):
+            addr = []
+            for lane in range(64):
+                p = (lane & 15) + 16 * j + 64 * (lane >> 4)
+                L.e[lane, j], L.pos[lane, j] = img[image256(p)], p
+                addr.append(image256(p))
+            note("r", addr)
+        for lane in range(64):
+            L.e[lane] = quad(L.e[lane], L.pos[lane], 16, sign)
+        L.swap(0, 4)
+        L.swap(1, 5)
+        for lane in range(64):
+            L.e[lane] = quad(L.e[lane], L.pos[lane], 64, sign)
+        for i in range(4):
+            assert [int(L.pos[lane, i]) for lane in range(64)] == [lane + 64 * i for lane in range(64)]
+            note("w", [lane + 64 * i for lane in range(64)])
+            for lane in range(64):
+                out[lane + 64 * i] = L.e[lane, i]
+        return out
+    sw = product_swizzle
+    stores = [[] for _ in range(4)]
+    for t in range(Q):
+        e = [0] * 4
+        for m in range(4):
+            e[((m & 1) << 1) | (m >> 1)] = x[t + m * Q]
+        a = 4 * rev(t, TB)
+        for i, v in enumerate(pass0(e)):
+            img[sw(a + i)] = v
+            stores[i].append(sw(a + i))
+    for i in range(4):
+        for w in range(waves):
+            note("w", stores[i][64 * w:64 * w + 64])
+    # phase B: slots = position bits (2, 3); lane bits 0, 1 = bits 0, 1; lane bits 2, 3 = bits 6, 7; lane bits 4, 5 = bits 4, 5; wave = bits 8 (, 9)
+    ladders = [Wave() for _ in range(waves)]
+    for w, L in enumerate(ladders):
+        for j in range(4):
+            addr = []
+            for lane in range(64):
+                p = (lane & 3) | (j << 2) | ((lane >> 4) << 4) | (((lane >> 2) & 3) << 6) | (w << 8)
+                L.e[lane, j], L.pos[lane, j] = img[sw(p)], p
+                addr.append(sw(p))
+            note("r", addr)
+        for lane in range(64):
+            L.e[lane] = quad(L.e[lane], L.pos[lane], 4, sign)
+        L.swap(0, 4)
+        L.swap(1, 5)
+        for lane in range(64):
+            L.e[lane] = quad(L.e[lane], L.pos[lane], 16, sign)
+    for j in range(4):
+        for w, L in enumerate(ladders):
+            addr = [sw(int(L.pos[lane, j])) for lane in range(64)]
+            note("w", addr)
+            for lane in range(64):
+                img[addr[lane]] = L.e[lane, j]
+    # phase C
+    for w in range(waves):
+        L = Wave()
+        for j in range(4):
+            addr = []
+            for lane in range(64):
+                if n == 10:
+                    p = (lane & 15) | (w << 4) | (j << 6) | ((lane >> 4) << 8)
+                else:
+                    p = (lane & 31) | (w << 5) | (j << 6) | ((lane >> 5) << 8)
+                L.e[lane, j], L.pos[lane, j] = img[sw(p)], p
+                addr.append(sw(p))
+            note("r", addr)
+        for lane in range(64):
+            L.e[lane] = quad(L.e[lane], L.pos[lane], 64, sign)
+        if n == 10:
+            L.swap(0, 4)
+            L.swap(1, 5)
+            for lane in range(64):
+                L.e[lane] = quad(L.e[lane], L.pos[lane], 256, sign)
+        else:
+            L.swap(0, 5)            # slots = (bit 8, bit 7)
+            for lane in range(64):
+                p0 = int(L.pos[lane, 0])
+                assert [int(q) for q in L.pos[lane]] == [p0, p0 + 256, p0 + 128, p0 + 384]
+                wv = np.exp(sign * 2j * np.pi * p0 / N)
+                x0, x1, x2, x3 = L.e[lane]
+                t1, t3 = x1 * wv, x3 * wv * (1j * sign)
+                L.e[lane] = [x0 + t1, x0 - t1, x2 + t3, x2 - t3]
+        for i in range(4):
+            note("w", [int(L.pos[lane, i]) for lane in range(64)])
+            for lane in range(64):
+                out[int(L.pos[lane, i])] = L.e[lane, i]
+        if n == 9:
+            # in place: the words a wave stores to (natural layout) are the words it read (the swizzle permutes aligned groups of 32; the wave owns whole groups)
+            read_words = {sw((lane & 31) | (w << 5) | (j << 6) | ((lane >> 5) << 8)) for lane in range(64) for j in range(4)}
+            assert read_words == {int(L.pos[lane, i]) for lane in range(64) for i in range(4)}
+    return out
+
+
+def lds_report_pairs(N):
+    log = []
+    transform_pairs(N, 0, np.zeros(N, complex), log)
+    return sum(access_cycles(k, a) for k, a in log), sum(2 if k == "r" else 6 for k, a in log), len(log)
 
 
 def access_cycles(kind, addr):
@@ -590,3 +736,6 @@ if __name__ == "__main__":
         for REO in (1, 0):
             total, ideal, count = lds_report(N, REO)
             print(f"N={N} reorder={REO}: {count} wave-level LDS accesses per transform, {total} LDS cycles ({ideal} conflict free)")
+    for N in (256, 512, 1024):
+        total, ideal, count = lds_report_pairs(N)
+        print(f"N={N} natural order in pairs of passes: {count} wave-level LDS accesses per transform, {total} LDS cycles ({ideal} conflict free)")
