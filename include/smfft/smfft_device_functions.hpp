@@ -174,7 +174,7 @@ struct QuarterTwiddles {
     static constexpr bool late(int p) { return p >= R::kPasses - kLatePasses; }
     QuadTwiddle q[R::kPasses > 1 ? R::kPasses : 1];    // q[p], p = 1 .. kPasses - 1 (P = 4^p)
     float2 wr;                                         // the radix-2 pass of an odd log2 N
-    int kbase, kbase_high;                             // butterfly index of the passes with P <= 64 / of the passes above (the last phase of N >= 2048 numbers its threads differently)
+    int kbase, kbase_high, kbase_first;                // butterfly index of the passes with P <= 64 / of the passes above (the last phase of N >= 2048 numbers its threads differently) / of pass 1 where that differs
     __device__ static __forceinline__ QuadTwiddle fetch(int p, int k) {
         const TwiddleValue tv = quarter_twiddle_rows<N>.w[R::row_start(p) + k];
         QuadTwiddle t;
@@ -186,12 +186,14 @@ struct QuarterTwiddles {
     // kb: the thread's butterfly index (k = kb mod P in every pass); r: its index in the radix-2 row; kb_high: the index for the passes with
     // P >= 256 where it differs (quarter_fft's last phase)
     __device__ __forceinline__ void load(int kb, int r) { load(kb, r, kb); }
-    __device__ __forceinline__ void load(int kb, int r, int kb_high) {
+    __device__ __forceinline__ void load(int kb, int r, int kb_high) { load(kb, r, kb_high, kb); }
+    __device__ __forceinline__ void load(int kb, int r, int kb_high, int kb_first) {
         kbase = kb;
         kbase_high = kb_high;
+        kbase_first = kb_first;
 #pragma unroll
         for (int p = 1; p < R::kPasses; ++p)
-            if (!late(p)) q[p] = fetch(p, (p >= HIGH_FROM ? kb_high : kb) & ((1 << (2 * p)) - 1));
+            if (!late(p)) q[p] = fetch(p, (p == 1 ? kb_first : p >= HIGH_FROM ? kb_high : kb) & ((1 << (2 * p)) - 1));
         if constexpr (R::kOdd) {
             const TwiddleValue tv = quarter_twiddle_rows<N>.w[R::row_start(R::kPasses) + r];
             wr = make_float2(tv.x, DIR ? -tv.y : tv.y);
@@ -199,7 +201,7 @@ struct QuarterTwiddles {
     }
     // the twiddles of pass `pass`, at the pass (pass: a constant where this is called -- a template argument or the counter of an unrolled loop)
     __device__ __forceinline__ QuadTwiddle of(int pass) const {
-        return late(pass) ? fetch(pass, (pass >= HIGH_FROM ? kbase_high : kbase) & ((1 << (2 * pass)) - 1)) : q[pass];
+        return late(pass) ? fetch(pass, (pass == 1 ? kbase_first : pass >= HIGH_FROM ? kbase_high : kbase) & ((1 << (2 * pass)) - 1)) : q[pass];
     }
 };
 // the fused radix-2^2 butterfly on (x0, x1, x2, x3) = elements k, k + P, k + 2P, k + 3P; results in place
@@ -575,6 +577,11 @@ __device__ __forceinline__ void quarter_small_noreorder(float2* s, int t, int re
 #ifndef SMFFT_QUARTER_PAIRS
 #define SMFFT_QUARTER_PAIRS 1
 #endif
+// ... and at N = 2048 (inputs from LDS): [pass 0 | <-> 5, 4 | pass 1] in front of the scattered store -- the thread loads
+// x[(lane & 15) + 16 wave + 128 (lane >> 4) + m N/4]: its lane bits 4, 5 hold the input bits under the slots' (position bits 3, 2); a 2-way conflicted
+// read of the caller's natural layout -- then [pass 2 | <-> 4, 5 | pass 3] on the wave's aligned block (run_exchanged's read-back), then the
+// last phase as before: 2 + 2 + 1.5 passes instead of 1 + 3 + 1.5, +7.5 ... 8.3 % in the in-LDS loop.  The same at N = 4096 (2 + 2 + 2): nothing
+// (-0.7 ... +0.2 %; sixteen waves per block, two blocks per CU: the block's own latency chain bounds it, and that chain is as long) -- not taken.
 // OUT_PHASED (with OUT_REGS; round 6): the results stay in x[] WHERE THE LAST PHASE LEAVES THEM -- x[i] = element quarter_phased_element<N>(t, i)
 // of the transform -- so that N = 2048 / 4096 can take the last phase with registers out as well (for N <= 1024 that is t + i N/4, as without it).
 template <int N>
@@ -621,6 +628,8 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
     constexpr bool kLastPhase = kPhases && N >= 2048 && (!OUT_REGS || OUT_PHASED) && (kLanesHead || kLanesMiddle);
     constexpr int kFirstLdsPass = (kLanesHead || kLanesMiddle) ? 4 : 1;
     constexpr bool kPairs = kPhases && SMFFT_QUARTER_PAIRS != 0 && REORDER && (N == 512 || N == 1024) && kLanesMiddle && !OUT_REGS;
+    constexpr bool kPairsHead = kPhases && SMFFT_QUARTER_PAIRS != 0 && REORDER && N == 2048 && kLastPhase && kLanesMiddle && !IN_REGS;
+    constexpr int W_BITS = N_BITS - 8;                   // waves of the block (N >= 512)
     // the thread of the last phase: lanes 0 ... LOW-1 = position bits 0 ... LOW-1, wave = the bits up to 7, slots = bits (8, 9), the other
     // lane bits = bits 10 (, 11); after the exchange in front of the last pass those lane bits hold bits 8 (, 9)
     constexpr int LOW = 16 - N_BITS;
@@ -633,6 +642,7 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
     const int k_pairs = N == 1024 ? ((lane & 15) | (wave << 4) | ((lane >> 4) << 6)) : ((lane & 31) | (wave << 5) | ((lane >> 5) << 6));
     QuarterTwiddles<N, DIR, REORDER, kLastPhase, kPairs ? 3 : 4> tw;
     if constexpr (kPairs) tw.load((lane & 3) | ((lane >> 4) << 2), k_pairs, k_pairs);
+    else if constexpr (kPairsHead) tw.load(t, k_last, k_last, ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1));
     else tw.load(t, k_last, k_last);
     float2* sf = s + region_offset;
     float2 e[4];
@@ -659,6 +669,7 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
 #pragma unroll
         for (int m = 0; m < 4; ++m) {                                                   // e[i] = x[bitrev(4j + i)], i = rev2(m)
             if constexpr (IN_REGS) e[((m & 1) << 1) | (m >> 1)] = x[m];
+            else if constexpr (kPairsHead) e[((m & 1) << 1) | (m >> 1)] = sf[(lane & 15) + 16 * wave + ((lane >> 4) << (4 + W_BITS)) + m * Q];
             else if constexpr (kPhases && N <= 2048) e[((m & 1) << 1) | (m >> 1)] = lds_load_single(sf + t + m * Q);
             else e[((m & 1) << 1) | (m >> 1)] = sf[t + m * Q];
         }
@@ -677,6 +688,17 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
         const float2 jd1 = DIR ? make_float2(-d1.y, d1.x) : make_float2(d1.y, -d1.x);   // -+i * d1
         if constexpr (kLastQuad == 0) {
             sf[a + 0] = cadd(s0, s1), sf[a + 2] = csub(s0, s1), sf[a + 1] = cadd(d0, jd1), sf[a + 3] = csub(d0, jd1);
+        } else if constexpr (kPairsHead) {
+            e[0] = cadd(s0, s1), e[1] = cadd(d0, jd1), e[2] = csub(s0, s1), e[3] = csub(d0, jd1);
+            slots_swap<0, 5, true>(e);                             // lane bits 5, 4 hold position bits 2, 3
+            slots_swap<1, 4, true>(e);
+            quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(1), tw.late(1));
+            // slots = position bits (2, 3); lane bits 5, 4 = bits 0, 1; wave = bits 4 ... (reversed); lane bits 0 ... 3 = the four highest (reversed)
+            const int pw = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | ((int)(__brev((unsigned)wave) >> (32 - W_BITS)) << 4) |
+                           ((int)(__brev((unsigned)(lane & 15)) >> 28) << (4 + W_BITS));
+            const int a0 = quarter_swizzle(region_offset + pw);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[a0 ^ (4 * j)] = e[j];
         } else {
             const int a0 = kOneWaveNatural ? region_offset + quarter_image256(a) : quarter_swizzle(region_offset + a);   // a0 ^ m: the same aligned group of four
             s[a0] = cadd(s0, s1), s[a0 ^ 2] = csub(s0, s1), s[a0 ^ 1] = cadd(d0, jd1), s[a0 ^ 3] = csub(d0, jd1);
@@ -729,6 +751,13 @@ __device__ __forceinline__ void quarter_fft(float2 (&x)[4], float2* s, int t, in
                 sf[k_pairs + 3 * Q] = csub(e[2], t3);
             }
             return;
+        } else if constexpr (kPairsHead) {
+            // ---- [pass 2 | <-> 4, 5 | pass 3] on the wave's aligned block: slots = position bits (4, 5); lane bits 0 ... 3 = bits 0 ... 3; lane bits 4, 5 = bits 6, 7
+            const int b0 = quarter_swizzle(region_offset + ((lane & 15) | ((lane >> 4) << 6) | (wave << 8)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = s[b0 ^ quarter_swizzle(16 * j)];
+            quad_butterfly<DIR>(e[0], e[1], e[2], e[3], tw.of(2), tw.late(2));
+            QuarterLanes<256, DIR, 0>::template passes<3>(e, tw);
         } else if constexpr (kSlots23) {
             // slots = position bits (2, 3): elements p1 + 4 j, p1 = position bits 0, 1 from lane bits 0, 1 and bits 4 ... 7 from lane bits 2 ... 5
             const int p1 = (lane & 3) + 16 * (lane >> 2) + 256 * wave;

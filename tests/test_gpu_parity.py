@@ -696,7 +696,7 @@ def test_example_convolution_kernel(sm, n, sym):
 # header that change its kernels: -DSMFFT_WAVE64_SMALL=1 (the upstream class names of N <= 128 describe
 # 64-thread blocks), -DSMFFT_CONTRACT_FUSED_IO=0 (the two-argument kernels keep upstream's fill / call / drain form) and
 # -DSMFFT_QUARTER_PHASES=0 (round 5's form of the engine: every exchange of the ladders on lanes, two trips through LDS for the cross-wave
-# passes of N >= 2048), -DSMFFT_QUARTER_PAIRS=0 (natural order of N = 512 / 1024 in phases of three passes, as N = 256 and N >= 2048 are)
+# passes of N >= 2048), -DSMFFT_QUARTER_PAIRS=0 (natural order of N = 512 / 1024 / 2048 with a phase of three passes, as N = 256 and N = 4096 have)
 EXAMPLE_BUILDS = ["", "_wave64small", "_unfused_io", "_no_phases", "_no_pairs"]
 
 

@@ -85,12 +85,13 @@ def test_phased_form_of_the_ladder_is_the_dft_and_conflict_free():
         assert total == ideal + 16 * 4 * 2, (reorder, total, ideal)      # sixteen waves x four reads x two extra cycles
 
 
-@pytest.mark.parametrize("n", [512, 1024])
+@pytest.mark.parametrize("n", [512, 1024, 2048])
 def test_natural_order_in_pairs_of_passes_is_the_dft_and_conflict_free(n):
-    """quarter_fft's natural-order form of N = 512 / 1024 in PAIRS of passes (round 6, last day; SMFFT_QUARTER_PAIRS): every phase two passes
+    """quarter_fft's natural-order form of N = 512 / 1024 / 2048 in PAIRS of passes (round 6, last day; SMFFT_QUARTER_PAIRS): every phase two passes
     with the exchange of the lane bits 4, 5 between them; tools/quarter_phases_model.py, transform_pairs replays lanes, slots, swaps and the
     swizzled image against numpy.fft, both directions; every LDS access is conflict free under the gfx950 lane-group rules, as many accesses as
-    in the three-pass form; N = 512 stores into the words it read (asserted inside the model)."""
+    in the three-pass form; N = 512 stores into the words it read (asserted inside the model).  N = 2048 runs pass 1 in front of the scattered
+    store: its four loads of the caller's natural layout are 2-way conflicted (eight waves x four reads x two cycles), nothing else."""
     import numpy as np
     import quarter_phases_model as qp
     rng = np.random.default_rng(n)
@@ -100,7 +101,7 @@ def test_natural_order_in_pairs_of_passes_is_the_dft_and_conflict_free(n):
         want = np.fft.ifft(x) * n if direction else np.fft.fft(x)
         assert np.abs(got - want).max() / np.abs(want).max() < 1e-14
     total, ideal, count = qp.lds_report_pairs(n)
-    assert total == ideal and count == qp.lds_report(n, 1)[2], (total, ideal, count)
+    assert total == ideal + (64 if n == 2048 else 0) and count == qp.lds_report(n, 1)[2], (total, ideal, count)
 
 
 @pytest.mark.parametrize("n", [64, 128])

@@ -250,11 +250,13 @@ def transform_pairs(N, DIR, x, log=None):
                        swizzled image; N = 1024: [pass (6,7) | <-> 4, 5 | pass (8,9)], wave = position bits 4, 5 -- a barrier in front of the natural store;
                        N = 512: [pass (6,7) | slot bit 0 <-> lane bit 5 | radix 2 on bit 8], wave = position bit 5: whole groups of 32, no barrier."""
     n = N.bit_length() - 1
-    assert n in (8, 9, 10)
+    assert n in (8, 9, 10, 11, 12)
     Q, TB = N // 4, n - 2
     sign = 1 if DIR else -1
     waves = N // 256
     img = np.zeros(N, complex)
+    if n >= 11:
+        return transform_pairs_head(N, DIR, x, log)
 
     def note(kind, addr):
         if log is not None:
@@ -377,6 +379,104 @@ def transform_pairs(N, DIR, x, log=None):
             # in place: the words a wave stores to (natural layout) are the words it read (the swizzle permutes aligned groups of 32; the wave owns whole groups)
             read_words = {sw((lane & 31) | (w << 5) | (j << 6) | ((lane >> 5) << 8)) for lane in range(64) for j in range(4)}
             assert read_words == {int(L.pos[lane, i]) for lane in range(64) for i in range(4)}
+    return out
+
+
+def transform_pairs_head(N, DIR, x, log=None):
+    """N = 2048 (the header's form; N = 4096 replayed as well -- measured no faster there, not in the header): [pass (0,1) | slots <-> lane bits 5, 4 |
+    pass (2,3)] in front of the scattered store -- the thread loads x[(lane & 15) + 16 wave + 16 W (lane >> 4) + m N/4], W waves -- then
+    [pass (4,5) | <-> 4, 5 | pass (6,7)] on the wave's aligned block, then the LAST PHASE of transform()."""
+    n = N.bit_length() - 1
+    Q = N // 4
+    sign = 1 if DIR else -1
+    waves, wb = N // 256, n - 8
+    img = np.zeros(N, complex)
+    sw = product_swizzle
+
+    def note(kind, addr):
+        if log is not None:
+            log.append((kind, list(addr)))
+
+    heads = []
+    for w in range(waves):
+        L = Wave()
+        for m in range(4):
+            note("r", [(lane & 15) + 16 * w + ((lane >> 4) << (4 + wb)) + m * Q for lane in range(64)])
+        for lane in range(64):
+            t_in = (lane & 15) + 16 * w + ((lane >> 4) << (4 + wb))          # the input index without the slots' bits
+            e = [0] * 4
+            for m in range(4):
+                e[((m & 1) << 1) | (m >> 1)] = x[t_in + m * Q]
+            s0, d0, s1, d1 = e[0] + e[1], e[0] - e[1], e[2] + e[3], e[2] - e[3]
+            jd1 = d1 * (1j * sign)
+            L.e[lane] = [s0 + s1, d0 + jd1, s0 - s1, d0 - jd1]
+            L.pos[lane] = [4 * rev(t_in, n - 2) + i for i in range(4)]
+        L.swap(0, 5)
+        L.swap(1, 4)
+        for lane in range(64):
+            L.e[lane] = quad(L.e[lane], L.pos[lane], 4, sign)
+            pw = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (rev(w, wb) << 4) | (rev(lane & 15, 4) << (4 + wb))
+            assert [int(q) for q in L.pos[lane]] == [pw + 4 * j for j in range(4)]
+        heads.append(L)
+    for j in range(4):
+        for L in heads:
+            addr = [sw(int(L.pos[lane, j])) for lane in range(64)]
+            note("w", addr)
+            for lane in range(64):
+                img[addr[lane]] = L.e[lane, j]
+    blocks = []
+    for w in range(waves):
+        L = Wave()
+        for j in range(4):
+            addr = []
+            for lane in range(64):
+                p = (lane & 15) | (j << 4) | ((lane >> 4) << 6) | (w << 8)
+                L.e[lane, j], L.pos[lane, j] = img[sw(p)], p
+                addr.append(sw(p))
+            note("r", addr)
+        for lane in range(64):
+            L.e[lane] = quad(L.e[lane], L.pos[lane], 16, sign)
+        L.swap(0, 4)
+        L.swap(1, 5)
+        for lane in range(64):
+            L.e[lane] = quad(L.e[lane], L.pos[lane], 64, sign)
+            assert [int(q) for q in L.pos[lane]] == [256 * w + lane + 64 * i for i in range(4)]
+        blocks.append(L)
+    for i in range(4):                     # natural layout
+        for w, L in enumerate(blocks):
+            note("w", [256 * w + lane + 64 * i for lane in range(64)])
+            for lane in range(64):
+                img[256 * w + lane + 64 * i] = L.e[lane, i]
+    out = np.zeros(N, complex)
+    low = 16 - n
+    for w in range(waves):
+        L = Wave()
+        for j in range(4):
+            addr = []
+            for lane in range(64):
+                p = (lane & ((1 << low) - 1)) | (w << low) | (j << 8) | ((lane >> low) << 10)
+                L.e[lane, j], L.pos[lane, j] = img[p], p
+                addr.append(p)
+            note("r", addr)
+        for lane in range(64):
+            L.e[lane] = quad(L.e[lane], L.pos[lane], 256, sign)
+        if n == 12:
+            L.swap(0, 4)
+            L.swap(1, 5)
+            for lane in range(64):
+                L.e[lane] = quad(L.e[lane], L.pos[lane], 1024, sign)
+        else:
+            L.swap(0, 5)
+            for lane in range(64):
+                p0 = int(L.pos[lane, 0])
+                wv = np.exp(sign * 2j * np.pi * p0 / N)
+                x0, x1, x2, x3 = L.e[lane]
+                t1, t3 = x1 * wv, x3 * wv * (1j * sign)
+                L.e[lane] = [x0 + t1, x0 - t1, x2 + t3, x2 - t3]
+        for i in range(4):
+            note("w", [int(L.pos[lane, i]) for lane in range(64)])
+            for lane in range(64):
+                out[int(L.pos[lane, i])] = L.e[lane, i]
     return out
 
 
@@ -736,6 +836,6 @@ if __name__ == "__main__":
         for REO in (1, 0):
             total, ideal, count = lds_report(N, REO)
             print(f"N={N} reorder={REO}: {count} wave-level LDS accesses per transform, {total} LDS cycles ({ideal} conflict free)")
-    for N in (256, 512, 1024):
+    for N in (256, 512, 1024, 2048, 4096):
         total, ideal, count = lds_report_pairs(N)
         print(f"N={N} natural order in pairs of passes: {count} wave-level LDS accesses per transform, {total} LDS cycles ({ideal} conflict free)")
